@@ -1,0 +1,485 @@
+// Context-Cluster core (the token mixer between fc1/fc_v and fc2), forward and backward.
+// Reference: Cluster.forward backbone/fusion/vr_coc.py:158-190 (fold, 2x2 adaptive-avg-pool centre
+// proposals, cosine similarity :114-125, sigmoid(beta + alpha*cos), hard argmax assignment, weighted
+// aggregate, dispatch, unfold).  The reference materialises [b,4,N,D] broadcast products twice; here one
+// workgroup owns one region-head (N points x D dims, M = 4 centres), keeps its feature / value points in
+// registers (8 lanes per point, 4 dims per lane, float4 global accesses that cover whole 128-B lines at
+// D = 32) and does every reduction with wave shuffles + one LDS hop.  HBM traffic is the algorithmic
+// minimum: read f, v, write out (forward); read f, v, g, write df, dv (backward).
+// All reductions have a fixed order: results are bitwise reproducible run to run.
+#include "common.h"
+
+namespace {
+
+struct ClusterArgs {
+  const float* f; const float* v; long ld;
+  const float* alpha; const float* beta;
+  float* out; long ldo;
+  unsigned char* idx; float* wgt;
+  // backward
+  const float* g; long ldg;
+  float* df; float* dv; long lddf;
+  float* ab_partial;   // [blocks][2]
+  int B, H, W, E, D, fold;
+};
+
+constexpr int MAXW = 16;   // waves per workgroup
+
+// Sum vals[m*4+q] (this lane's 4 dims of centre m) over every point of the workgroup.
+// Result: dst[m*32 + d] * scale.  part: [NW][128] scratch.
+__device__ __forceinline__ void reduce_md(float (&vals)[16], float* part, float* dst, float scale, int tid, int T) {
+  const int lane = tid & 63, wave = tid >> 6, NW = T >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float x = vals[i];
+    x += __shfl_xor(x, 8, 64);
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    vals[i] = x;
+  }
+  if (lane < 8) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[wave * 128 + m * 32 + 4 * lane + q] = vals[m * 4 + q];
+  }
+  __syncthreads();
+  for (int i = tid; i < 128; i += T) {
+    float s = 0.f;
+    for (int w = 0; w < NW; ++w) s += part[w * 128 + i];
+    dst[i] = s * scale;
+  }
+  __syncthreads();
+}
+
+// Sum 4 per-lane scalars over the workgroup -> dst[0..3].  part: [NW][4] scratch.
+__device__ __forceinline__ void reduce4(float (&vals)[4], float* part, float* dst, int tid, int T) {
+  const int lane = tid & 63, wave = tid >> 6, NW = T >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vals[i] = wave_sum(vals[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[wave * 4 + i] = vals[i];
+  }
+  __syncthreads();
+  if (tid < 4) {
+    float s = 0.f;
+    for (int w = 0; w < NW; ++w) s += part[w * 4 + tid];
+    dst[tid] = s;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float group8_sum(float x) {
+  x += __shfl_xor(x, 1, 64);
+  x += __shfl_xor(x, 2, 64);
+  x += __shfl_xor(x, 4, 64);
+  return x;
+}
+
+// LDS carve (floats): part[MAXW*128] | cen[128] | vcen[128] | agg[128] | afin[128] | t1[128] | t2[128] | misc[32]
+constexpr int SM_PART = 0, SM_CEN = MAXW * 128, SM_VCEN = SM_CEN + 128, SM_AGG = SM_VCEN + 128,
+              SM_AFIN = SM_AGG + 128, SM_T1 = SM_AFIN + 128, SM_T2 = SM_T1 + 128, SM_MISC = SM_T2 + 128,
+              SM_TOTAL = SM_MISC + 32;
+
+template <int NPT, bool BWD, int MAXT>
+__global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
+  __shared__ float sm[SM_TOTAL];
+  const int T = blockDim.x, tid = threadIdx.x, sub = tid & 7, pip = tid >> 3, PP = T >> 3;
+  int rid = blockIdx.x;
+  const int fold = p.fold;
+  const int f2 = rid % fold; rid /= fold;
+  const int f1 = rid % fold; rid /= fold;
+  const int e = rid % p.E;
+  const int b = rid / p.E;
+  const int h = p.H / fold, w = p.W / fold, N = h * w;
+  const int y0 = f1 * h, x0 = f2 * w;
+  const int D = p.D;
+  const bool dim_ok = 4 * sub < D;
+  const int hh = (h + 1) / 2, hl = h / 2, wh = (w + 1) / 2, wl = w / 2;
+  const float invq = 1.f / (float)(hh * wh);
+  const float alpha = p.alpha[0], beta = p.beta[0];
+
+  float f[NPT][4], v[NPT][4];
+  long row[NPT];
+  bool ok[NPT];
+  unsigned inq[NPT];   // bit m set: point lies in pooling window m
+#pragma unroll
+  for (int s = 0; s < NPT; ++s) {
+    const int n = s * PP + pip;
+    ok[s] = n < N;
+    const int i = ok[s] ? n / w : 0, j = ok[s] ? n - i * w : 0;
+    row[s] = ((long)(b * p.H + y0 + i) * p.W + x0 + j);
+    const unsigned r0 = i < hh, r1 = i >= hl, c0 = j < wh, c1 = j >= wl;
+    inq[s] = ok[s] ? ((r0 & c0) | ((r0 & c1) << 1) | ((r1 & c0) << 2) | ((r1 & c1) << 3)) : 0u;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+    if (ok[s] && dim_ok) {
+      a = *reinterpret_cast<const f32x4*>(p.f + row[s] * p.ld + e * D + 4 * sub);
+      c = *reinterpret_cast<const f32x4*>(p.v + row[s] * p.ld + e * D + 4 * sub);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f[s][q] = a[q];
+      v[s][q] = c[q];
+    }
+  }
+
+  // ---- centres of f and v (2x2 adaptive average pooling over the region)
+  {
+    float cs[16], vs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cs[i] = vs[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NPT; ++s)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (inq[s] & (1u << m)) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            cs[m * 4 + q] += f[s][q];
+            vs[m * 4 + q] += v[s][q];
+          }
+        }
+    reduce_md(cs, sm + SM_PART, sm + SM_CEN, invq, tid, T);
+    reduce_md(vs, sm + SM_PART, sm + SM_VCEN, invq, tid, T);
+  }
+  float cl[4][4], cnorm[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      cl[m][q] = sm[SM_CEN + m * 32 + 4 * sub + q];
+      s2 += cl[m][q] * cl[m][q];
+    }
+    cnorm[m] = fmaxf(sqrtf(group8_sum(s2)), 1e-12f);
+  }
+
+  // ---- similarity, hard assignment
+  float wg[NPT], fn[NPT], cosk[NPT];
+  int kk[NPT];
+#pragma unroll
+  for (int s = 0; s < NPT; ++s) {
+    float n2 = 0.f, dt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      n2 += f[s][q] * f[s][q];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) dt[m] += f[s][q] * cl[m][q];
+    }
+    n2 = group8_sum(n2);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dt[m] = group8_sum(dt[m]);
+    const float nf = fmaxf(sqrtf(n2), 1e-12f);
+    fn[s] = nf;
+    float best = -1.f, bc = 0.f;
+    int k = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float c = dt[m] / (nf * cnorm[m]);
+      const float sg = vr_sigmoid(beta + alpha * c);
+      if (sg > best) {   // strict: first maximum wins, as torch.max(dim)
+        best = sg;
+        k = m;
+        bc = c;
+      }
+    }
+    if (BWD && ok[s]) k = p.idx[row[s] * p.E + e];   // replay the forward's assignment
+    if (BWD) {
+      bc = 0.f;
+      best = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (k == m) {
+          bc = dt[m] / (nf * cnorm[m]);
+          best = vr_sigmoid(beta + alpha * bc);
+        }
+    }
+    wg[s] = best;
+    kk[s] = k;
+    cosk[s] = bc;
+  }
+
+  // ---- aggregate: a_m = (sum_{k(n)=m} w_n v_n + vc_m) / (cnt_m + 1)
+  {
+    float ag[16], cnt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ag[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NPT; ++s)
+      if (ok[s]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (kk[s] == m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ag[m * 4 + q] += wg[s] * v[s][q];
+            if (sub == 0) cnt[m] += 1.f;
+          }
+      }
+    reduce_md(ag, sm + SM_PART, sm + SM_AGG, 1.f, tid, T);
+    reduce4(cnt, sm + SM_PART, sm + SM_MISC, tid, T);
+    for (int i = tid; i < 128; i += T) sm[SM_AFIN + i] = (sm[SM_AGG + i] + sm[SM_VCEN + i]) / (sm[SM_MISC + (i >> 5)] + 1.f);
+    __syncthreads();
+  }
+
+  if (!BWD) {
+#pragma unroll
+    for (int s = 0; s < NPT; ++s) {
+      if (!ok[s]) continue;
+      if (dim_ok) {
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = wg[s] * sm[SM_AFIN + kk[s] * 32 + 4 * sub + q];
+        *reinterpret_cast<f32x4*>(p.out + row[s] * p.ldo + e * D + 4 * sub) = o;
+      }
+      if (sub == 0) {
+        p.idx[row[s] * p.E + e] = (unsigned char)kk[s];
+        if (p.wgt) p.wgt[row[s] * p.E + e] = wg[s];
+      }
+    }
+    return;
+  }
+
+  // ================================ backward ================================
+  float g[NPT][4];
+#pragma unroll
+  for (int s = 0; s < NPT; ++s) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (ok[s] && dim_ok) a = *reinterpret_cast<const f32x4*>(p.g + row[s] * p.ldg + e * D + 4 * sub);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[s][q] = a[q];
+  }
+  // da_m = sum_{k(n)=m} w_n g_n ;  at_m = da_m / (cnt_m + 1)   -> SM_T1
+  {
+    float da[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) da[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NPT; ++s)
+      if (ok[s]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (kk[s] == m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) da[m * 4 + q] += wg[s] * g[s][q];
+          }
+      }
+    reduce_md(da, sm + SM_PART, sm + SM_T1, 1.f, tid, T);
+    for (int i = tid; i < 128; i += T) sm[SM_T1 + i] = sm[SM_T1 + i] / (sm[SM_MISC + (i >> 5)] + 1.f);
+    __syncthreads();
+  }
+  // per point: dw, dz, dcos; dv; accumulate d c_hat
+  float dcs[NPT];
+  float dal = 0.f, dbe = 0.f;
+  {
+    float dch[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dch[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NPT; ++s) {
+      dcs[s] = 0.f;
+      if (!ok[s]) continue;      // whole 8-lane groups share ok[s]: shuffles below stay converged per group
+      const int k = kk[s];
+      float at[4], ak[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        at[q] = sm[SM_T1 + k * 32 + 4 * sub + q];
+        ak[q] = sm[SM_AFIN + k * 32 + 4 * sub + q];
+      }
+      float dwp = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dwp += g[s][q] * ak[q] + at[q] * v[s][q];
+      const float dw = group8_sum(dwp);
+      const float dz = dw * wg[s] * (1.f - wg[s]);
+      if (sub == 0) {
+        dbe += dz;
+        dal += dz * cosk[s];
+      }
+      const float dc = alpha * dz;
+      dcs[s] = dc;
+      // dv_n = w_n * at_k + sum_{m: n in Q_m} at_m / |Q_m|
+      if (dim_ok) {
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = wg[s] * at[q];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (inq[s] & (1u << m)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] += invq * sm[SM_T1 + m * 32 + 4 * sub + q];
+          }
+        *reinterpret_cast<f32x4*>(p.dv + row[s] * p.lddf + e * D + 4 * sub) = o;
+      }
+      // d c_hat_k += dcos * f_hat_n
+      const float inv_nf = 1.f / fn[s];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (k == m) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dch[m * 4 + q] += dc * f[s][q] * inv_nf;
+        }
+    }
+    reduce_md(dch, sm + SM_PART, sm + SM_T2, 1.f, tid, T);
+  }
+  // dc_m = (dch_m - chat_m (chat_m . dch_m)) / max(|c_m|, eps)   [no projection when |c_m| < eps]
+  float dcen[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    float dh[4], dot = 0.f;
+    const float inv_cn = 1.f / cnorm[m];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dh[q] = sm[SM_T2 + m * 32 + 4 * sub + q];
+      dot += cl[m][q] * inv_cn * dh[q];
+    }
+    dot = group8_sum(dot);
+    const bool clamped = cnorm[m] <= 1e-12f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      dcen[m][q] = clamped ? dh[q] * inv_cn : (dh[q] - cl[m][q] * inv_cn * dot) * inv_cn;
+  }
+#pragma unroll
+  for (int s = 0; s < NPT; ++s) {
+    if (!ok[s] || !dim_ok) continue;
+    const int k = kk[s];
+    const float inv_nf = 1.f / fn[s];
+    const bool clamped = fn[s] <= 1e-12f;
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float ck = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (k == m) ck = cl[m][q] / cnorm[m];
+      const float fh = f[s][q] * inv_nf;
+      o[q] = clamped ? dcs[s] * ck * inv_nf : dcs[s] * (ck - fh * cosk[s]) * inv_nf;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (inq[s] & (1u << m)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] += invq * dcen[m][q];
+      }
+    *reinterpret_cast<f32x4*>(p.df + row[s] * p.lddf + e * D + 4 * sub) = o;
+  }
+  // d alpha, d beta partials of this workgroup
+  {
+    float ab[4] = {dal, dbe, 0.f, 0.f};
+    reduce4(ab, sm + SM_PART, sm + SM_MISC + 8, tid, T);
+    if (tid == 0) {
+      p.ab_partial[2 * (long)blockIdx.x] = sm[SM_MISC + 8];
+      p.ab_partial[2 * (long)blockIdx.x + 1] = sm[SM_MISC + 9];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cluster_ab_reduce_kernel(const float* partial, long blocks, float* dalpha,
+                                                                float* dbeta, int accumulate) {
+  __shared__ double red[8];
+  double a = 0, b = 0;
+  for (long i = threadIdx.x; i < blocks; i += 256) {
+    a += partial[2 * i];
+    b += partial[2 * i + 1];
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = a;
+    red[4 + (threadIdx.x >> 6)] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double sa = red[0] + red[1] + red[2] + red[3], sb = red[4] + red[5] + red[6] + red[7];
+    dalpha[0] = (accumulate ? dalpha[0] : 0.f) + (float)sa;
+    dbeta[0] = (accumulate ? dbeta[0] : 0.f) + (float)sb;
+  }
+}
+
+int cluster_plan(int N, int* T, int* npt) {
+  int t = ((N + 63) / 64) * 64;
+  if (t < 64) t = 64;
+  if (t > 1024) t = 1024;
+  const int pp = t / 8;
+  const int np = (N + pp - 1) / pp;
+  if (np > 8) return -1;
+  *T = t;
+  *npt = np <= 1 ? 1 : (np <= 2 ? 2 : (np <= 4 ? 4 : 8));
+  return 0;
+}
+
+template <bool BWD>
+int cluster_launch(const ClusterArgs& p, int T, int npt, long blocks, hipStream_t st) {
+  dim3 grid(blocks), block(T);
+  if (T <= 256) {   // registers: up to 512 / (T/256) per lane; the 1024-thread variant is capped at 128
+    switch (npt) {
+      case 1: hipLaunchKernelGGL((cluster_kernel<1, BWD, 256>), grid, block, 0, st, p); break;
+      case 2: hipLaunchKernelGGL((cluster_kernel<2, BWD, 256>), grid, block, 0, st, p); break;
+      case 4: hipLaunchKernelGGL((cluster_kernel<4, BWD, 256>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((cluster_kernel<8, BWD, 256>), grid, block, 0, st, p); break;
+    }
+  } else {
+    hipLaunchKernelGGL((cluster_kernel<8, BWD, 1024>), grid, block, 0, st, p);
+  }
+  return 0;
+}
+
+int cluster_check(const char* name, const void* f, const void* v, long ld, int B, int H, int W, int E, int D, int fold,
+                  int* T, int* npt) {
+  VR_CHECK_ARG(f && v, "%s: null tensor", name);
+  VR_CHECK_ARG(B > 0 && H > 0 && W > 0 && E > 0 && fold >= 1, "%s: bad shape", name);
+  VR_CHECK_ARG(D > 0 && D <= 32 && D % 4 == 0, "%s: head_dim %d unsupported (multiple of 4, <= 32)", name, D);
+  VR_CHECK_ARG(H % fold == 0 && W % fold == 0,
+               "Ensure the feature map size (%d*%d) can be divided by fold %d*%d", H, W, fold, fold);
+  VR_CHECK_ARG(ld % 4 == 0 && vr_aligned16(f) && vr_aligned16(v), "%s: rows must be 16-byte aligned", name);
+  const int N = (H / fold) * (W / fold);
+  VR_CHECK_ARG(cluster_plan(N, T, npt) == 0, "%s: region of %d points exceeds the 1024-point kernel limit", name, N);
+  return VR_OK;
+}
+
+}  // namespace
+
+extern "C" int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
+                                     float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E,
+                                     int D, int fold, void* stream) {
+  int T, npt;
+  int rc = cluster_check("cluster_fwd", f, v, ld, B, H, W, E, D, fold, &T, &npt);
+  if (rc) return rc;
+  VR_CHECK_ARG(out && idx && alpha && beta && ldo % 4 == 0 && vr_aligned16(out), "cluster_fwd: bad output");
+  ClusterArgs p{};
+  p.f = f; p.v = v; p.ld = ld; p.alpha = alpha; p.beta = beta; p.out = out; p.ldo = ldo; p.idx = idx; p.wgt = wgt;
+  p.B = B; p.H = H; p.W = W; p.E = E; p.D = D; p.fold = fold;
+  cluster_launch<false>(p, T, npt, (long)B * E * fold * fold, vr_stream(stream));
+  VR_LAUNCH_CHECK("cluster_fwd");
+  return VR_OK;
+}
+
+extern "C" long vrnet_cluster_bwd_workspace(int B, int E, int fold) { return (long)B * E * fold * fold * 2 * 4 + 256; }
+
+extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
+                                     const unsigned char* idx, const float* dout, long lddo, float* df, float* dv,
+                                     long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
+                                     int E, int D, int fold, void* workspace, long workspace_bytes, void* stream) {
+  int T, npt;
+  int rc = cluster_check("cluster_bwd", f, v, ld, B, H, W, E, D, fold, &T, &npt);
+  if (rc) return rc;
+  VR_CHECK_ARG(idx && dout && df && dv && dalpha && dbeta && workspace, "cluster_bwd: null tensor");
+  VR_CHECK_ARG(lddo % 4 == 0 && lddf % 4 == 0 && vr_aligned16(dout) && vr_aligned16(df) && vr_aligned16(dv),
+               "cluster_bwd: rows must be 16-byte aligned");
+  const long blocks = (long)B * E * fold * fold;
+  if (workspace_bytes < vrnet_cluster_bwd_workspace(B, E, fold)) {
+    vr_set_error("cluster_bwd: workspace too small");
+    return VR_ERR_WORKSPACE;
+  }
+  ClusterArgs p{};
+  p.f = f; p.v = v; p.ld = ld; p.alpha = alpha; p.beta = beta; p.idx = const_cast<unsigned char*>(idx);
+  p.g = dout; p.ldg = lddo; p.df = df; p.dv = dv; p.lddf = lddf;
+  p.ab_partial = reinterpret_cast<float*>(workspace);
+  p.B = B; p.H = H; p.W = W; p.E = E; p.D = D; p.fold = fold;
+  hipStream_t st = vr_stream(stream);
+  cluster_launch<true>(p, T, npt, blocks, st);
+  VR_LAUNCH_CHECK("cluster_bwd");
+  hipLaunchKernelGGL(cluster_ab_reduce_kernel, dim3(1), dim3(256), 0, st, p.ab_partial, blocks, dalpha, dbeta,
+                     accumulate_ab);
+  VR_LAUNCH_CHECK("cluster_ab_reduce");
+  return VR_OK;
+}

@@ -1,0 +1,529 @@
+// Implicit-GEMM NHWC convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// One kernel family covers every dense convolution of the hot path (reference call sites:
+// 1x1 fc1/fc_v/fc2 and Mlp fc1/fc2 -- backbone/fusion/vr_coc.py:145-147,205-207; 3x3 radar_projection
+// :308; 3x3/s2 and 4x4/s4 PointRecuder :99-102; dilated ASPP -- neck/coc_fpn_dual.py:50-74; heads --
+// head/decouplehead.py:21-40) in both directions:
+//   mode 0 (forward)       y[m, n]  = sum_{t, c} x[src(m, t), c] * w[t][n][c]      m over output pixels
+//   mode 1 (data gradient) dx[m, c] = sum_{t, n} dy[src'(m, t), n] * w[t][n][c]    m over input pixels
+// Block tile 128 x BN x 16, 4 waves, each wave a TM x TN grid of 32x32 MFMA tiles.  Operand tiles
+// are staged global -> registers -> LDS (k-major images, so every MFMA fragment read is a
+// conflict-free ds_read_b32); the next tile's global loads are in flight during the MFMAs.
+// Exact fp32: the MFMA is an fmaf chain in k order (guide: cdna_hip_programming.md section 3).
+#include "common.h"
+
+namespace {
+
+struct IgemmArgs {
+  const float* a; long lda;
+  const float* w;
+  const float* bias;
+  float* y; long ldy;
+  float* ypre; long ldypre;
+  const float* res; long ldres; const float* res_scale;
+  const float* kscale;
+  const float* aux; long ldaux;
+  int M, MH, MW, SH, SW, CK, CN;
+  int kh, kw, stride, pad, dil;
+  int mode, act, a_vec, b_vec;
+  int out_nchw, out_ctot, out_coff, accumulate;
+  long wtap;   // Cout*Cin
+  int Cin;
+};
+
+constexpr int BM = 128, BK = 16;
+
+template <int BN, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+  static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
+  __shared__ float As[BK][BM + 4];
+  __shared__ float Bs[BK][BN + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int nkb = (p.CK + BK - 1) / BK;
+  const int nsteps = p.kh * p.kw * nkb;
+
+  // ---- A-side: each thread owns rows (tid>>2) and (tid>>2)+64, k-quad tid&3
+  const int kq = tid & 3;
+  int a_b[2], a_y[2], a_x[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + (tid >> 2) + 64 * i;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    a_x[i] = mm % p.MW;
+    const int q = mm / p.MW;
+    a_y[i] = q % p.MH;
+    a_b[i] = q / p.MH;
+  }
+  constexpr int BROWS = (BN >= 64) ? BN / 64 : 1;     // NK loader: rows per thread
+  constexpr int BVEC = (BN * BK / 4 + 255) / 256;     // KN loader: float4 per thread
+
+  f32x4 areg[2], breg[2];
+
+  auto load_tiles = [&](int s) {
+    const int t = s / nkb, c0 = (s - t * nkb) * BK;
+    const int ky = t / p.kw, kx = t - ky * p.kw;
+    const int kc = c0 + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int sy, sx;
+      bool ok = a_ok[i];
+      if (p.mode == 0) {
+        sy = a_y[i] * p.stride - p.pad + ky * p.dil;
+        sx = a_x[i] * p.stride - p.pad + kx * p.dil;
+      } else {
+        const int ty = a_y[i] + p.pad - ky * p.dil, tx = a_x[i] + p.pad - kx * p.dil;
+        ok = ok && ty >= 0 && tx >= 0 && (ty % p.stride) == 0 && (tx % p.stride) == 0;
+        sy = ty / p.stride;
+        sx = tx / p.stride;
+      }
+      ok = ok && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const float* src = p.a + ((long)(a_b[i] * p.SH + sy) * p.SW + sx) * p.lda + kc;
+        if (p.a_vec) {
+          if (kc < p.CK) v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kc + j < p.CK) v[j] = src[j];
+        }
+        if (p.kscale) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kc + j < p.CK) v[j] *= p.kscale[kc + j];
+        }
+      }
+      areg[i] = v;
+    }
+    const float* wt = p.w + (long)t * p.wtap;
+    if (p.mode == 0) {            // B[k = c][n] = w[t][n][c]: rows n, contiguous contraction
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i) {
+        const int n = (tid >> 2) + 64 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < BN && n0 + n < p.CN) {
+          const float* src = wt + (long)(n0 + n) * p.Cin + kc;
+          if (p.b_vec) {
+            if (kc < p.CK) v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (kc + j < p.CK) v[j] = src[j];
+          }
+        }
+        breg[i] = v;
+      }
+    } else {                      // B[k = n'][j = c] = w[t][n'][c]: rows = contraction, contiguous output col
+#pragma unroll
+      for (int i = 0; i < BVEC; ++i) {
+        const int idx = tid + 256 * i;
+        const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kr < BK && c0 + kr < p.CK) {
+          const int col = n0 + 4 * cq;
+          const float* src = wt + (long)(c0 + kr) * p.Cin + col;
+          if (p.b_vec) {
+            if (col < p.CN) v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (col + j < p.CN) v[j] = src[j];
+          }
+        }
+        breg[i] = v;
+      }
+    }
+  };
+
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 2) + 64 * i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) As[4 * kq + j][r] = areg[i][j];
+    }
+    if (p.mode == 0) {
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i) {
+        const int n = (tid >> 2) + 64 * i;
+        if (n < BN) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Bs[4 * kq + j][n] = breg[i][j];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BVEC; ++i) {
+        const int idx = tid + 256 * i;
+        const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
+        if (kr < BK) *reinterpret_cast<f32x4*>(&Bs[kr][4 * cq]) = breg[i];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int arow = wm * TM * 32 + (lane & 31);
+  const int bcol = wn * TN * 32 + (lane & 31);
+  const int khalf = lane >> 5;
+
+  load_tiles(0);
+  for (int s = 0; s < nsteps; ++s) {
+    store_tiles();
+    __syncthreads();
+    if (s + 1 < nsteps) load_tiles(s + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[2 * kk + khalf][arow + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[2 * kk + khalf][bcol + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const long hw = (long)p.MH * p.MW;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+    if (n >= p.CN) continue;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const float rsc = (p.res && p.res_scale) ? p.res_scale[n] : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bias;
+        if (p.aux) v *= vr_gelu_grad(p.aux[(long)m * p.ldaux + n]);
+        if (p.ypre) p.ypre[(long)m * p.ldypre + n] = v;
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        else if (p.act == 2) v = vr_gelu(v);
+        if (p.res) v = p.res[(long)m * p.ldres + n] + rsc * v;
+        float* dst;
+        if (p.out_nchw) {
+          const long b = m / hw, pix = m - b * hw;
+          dst = p.y + ((b * p.out_ctot + p.out_coff + n) * hw + pix);
+        } else {
+          dst = p.y + (long)m * p.ldy + n;
+        }
+        if (p.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient: dW[t][n][c] = sum_m dy[m, n] * x[src(m, t), c], contraction over output pixels,
+// split over `S` row ranges into fp32 slabs (deterministic; reduced by wgrad_reduce_kernel).
+struct WgradArgs {
+  const float* x; long ldx;
+  const float* dy; long lddy;
+  float* slab; float* bslab;
+  int M, OH, OW, H, W, Cin, Cout;
+  int kh, kw, stride, pad, dil;
+  int rows_per_split, n_tiles, c_tiles;
+  int x_vec, dy_vec;
+};
+
+template <int BN, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+  static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
+  __shared__ float As[BK][BM + 4];   // dy tile, [m][n]
+  __shared__ float Bs[BK][BN + 4];   // gathered x tile, [m][c]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int bid = blockIdx.x;
+  const int ct = bid % p.c_tiles; bid /= p.c_tiles;
+  const int nt = bid % p.n_tiles; bid /= p.n_tiles;
+  const int t = bid;
+  const int ky = t / p.kw, kx = t - ky * p.kw;
+  const int n0 = nt * BM, c0 = ct * BN;
+  const int split = blockIdx.y;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  constexpr int BVEC = (BN * BK / 4 + 255) / 256;
+  f32x4 areg[2], breg[BVEC];
+  const bool do_bias = p.bslab != nullptr && ct == 0 && t == 0;
+  float bsum = 0.f;
+
+  auto load_tiles = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      const int kr = idx >> 5, cq = idx & 31;
+      const int m = mb + kr, col = n0 + 4 * cq;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) {
+        const float* src = p.dy + (long)m * p.lddy + col;
+        if (p.dy_vec) {
+          if (col < p.Cout) v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (col + j < p.Cout) v[j] = src[j];
+        }
+      }
+      areg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BVEC; ++i) {
+      const int idx = tid + 256 * i;
+      const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int m = mb + kr, col = c0 + 4 * cq;
+      if (kr < BK && m < m_end) {
+        const int ox = m % p.OW;
+        const int q = m / p.OW;
+        const int oy = q % p.OH, b = q / p.OH;
+        const int sy = oy * p.stride - p.pad + ky * p.dil, sx = ox * p.stride - p.pad + kx * p.dil;
+        if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) {
+          const float* src = p.x + ((long)(b * p.H + sy) * p.W + sx) * p.ldx + col;
+          if (p.x_vec) {
+            if (col < p.Cin) v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (col + j < p.Cin) v[j] = src[j];
+          }
+        }
+      }
+      breg[i] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(&As[idx >> 5][4 * (idx & 31)]) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BVEC; ++i) {
+      const int idx = tid + 256 * i;
+      const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
+      if (kr < BK) *reinterpret_cast<f32x4*>(&Bs[kr][4 * cq]) = breg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int arow = wm * TM * 32 + (lane & 31);
+  const int bcol = wn * TN * 32 + (lane & 31);
+  const int khalf = lane >> 5;
+
+  if (m_begin < m_end) load_tiles(m_begin);
+  for (int mb = m_begin; mb < m_end; mb += BK) {
+    store_tiles();
+    __syncthreads();
+    if (mb + BK < m_end) load_tiles(mb + BK);
+    if (do_bias && tid < BM) {
+#pragma unroll
+      for (int k = 0; k < BK; ++k) bsum += As[k][tid];
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[2 * kk + khalf][arow + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[2 * kk + khalf][bcol + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const long T = (long)p.kh * p.kw;
+  float* slab = p.slab + ((long)split * T + t) * p.Cout * p.Cin;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int c = c0 + wn * TN * 32 + j * 32 + (lane & 31);
+    if (c >= p.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (n < p.Cout) slab[(long)n * p.Cin + c] = acc[i][j][r];
+      }
+  }
+  if (do_bias && tid < BM && n0 + tid < p.Cout) p.bslab[(long)split * p.Cout + n0 + tid] = bsum;
+}
+
+// dw (OIHW) = row_scale[n] * sum_s slab[s][t][n][c] (+ dw);  db[n] = row_scale[n] * sum_s bslab[s][n] (+ db)
+__global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, const float* row_scale, float* dw,
+                                    float* db, int S, int T, int Cout, int Cin, int accumulate) {
+  const long per = (long)T * Cout * Cin;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < per) {
+    const int c = e % Cin;
+    const long q = e / Cin;
+    const int n = q % Cout;
+    const int t = q / Cout;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += slab[(long)k * per + e];
+    if (row_scale) s *= row_scale[n];
+    float* d = dw + ((long)n * Cin + c) * T + t;
+    *d = accumulate ? *d + s : s;
+  } else if (db && e < per + Cout) {
+    const int n = e - per;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += bslab[(long)k * Cout + n];
+    if (row_scale) s *= row_scale[n];
+    db[n] = accumulate ? db[n] + s : s;
+  }
+}
+
+// OIHW -> [T][Cout][Cin]
+__global__ void pack_weight_kernel(const float* w, float* out, int Cout, int Cin, int T) {
+  const long total = (long)T * Cout * Cin;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = e % Cin;
+  const long q = e / Cin;
+  const int n = q % Cout;
+  const int t = q / Cout;
+  out[e] = w[((long)n * Cin + c) * T + t];
+}
+
+}  // namespace
+
+extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias, float* y, long ldy,
+                                int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride,
+                                int pad, int dil, int mode, int act, float* ypre, long ldypre, const float* res,
+                                long ldres, const float* res_scale, const float* kscale, const float* aux,
+                                long ldaux, int out_nchw, int out_ctot, int out_coff, int accumulate,
+                                void* stream) {
+  VR_CHECK_ARG(a && w && y, "conv2d: null tensor");
+  VR_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0, "conv2d: bad shape");
+  VR_CHECK_ARG(kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d: bad geometry");
+  VR_CHECK_ARG((H + 2 * pad - dil * (kh - 1) - 1) / stride + 1 == OH &&
+                   (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1 == OW,
+               "conv2d: output size %dx%d inconsistent with input %dx%d k%d s%d p%d d%d", OH, OW, H, W, kh,
+               stride, pad, dil);
+  IgemmArgs p{};
+  p.a = a; p.lda = lda; p.w = w; p.bias = bias; p.y = y; p.ldy = ldy;
+  p.ypre = ypre; p.ldypre = ldypre; p.res = res; p.ldres = ldres; p.res_scale = res_scale;
+  p.kscale = kscale; p.aux = aux; p.ldaux = ldaux;
+  p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.mode = mode; p.act = act; p.out_nchw = out_nchw; p.out_ctot = out_ctot; p.out_coff = out_coff;
+  p.accumulate = accumulate; p.wtap = (long)Cout * Cin; p.Cin = Cin;
+  if (mode == 0) {
+    p.MH = OH; p.MW = OW; p.SH = H; p.SW = W; p.CK = Cin; p.CN = Cout;
+  } else {
+    p.MH = H; p.MW = W; p.SH = OH; p.SW = OW; p.CK = Cout; p.CN = Cin;
+  }
+  const long M = (long)B * p.MH * p.MW;
+  VR_CHECK_ARG(M < (1L << 31) && (long)B * p.SH * p.SW < (1L << 31), "conv2d: too many pixels");
+  p.M = (int)M;
+  VR_CHECK_ARG(lda >= p.CK && (out_nchw || ldy >= p.CN), "conv2d: row stride smaller than channel count");
+  p.a_vec = (p.CK % 4 == 0) && (lda % 4 == 0) && vr_aligned16(a) && (!kscale || true);
+  p.b_vec = (Cin % 4 == 0) && vr_aligned16(w);
+  dim3 block(256);
+  hipStream_t st = vr_stream(stream);
+  if (p.CN > 64) {
+    dim3 grid(vr_cdiv(M, BM), vr_cdiv(p.CN, 128));
+    hipLaunchKernelGGL((igemm_kernel<128, 2, 2, 2, 2>), grid, block, 0, st, p);
+  } else if (p.CN > 32) {
+    dim3 grid(vr_cdiv(M, BM), 1);
+    hipLaunchKernelGGL((igemm_kernel<64, 2, 1, 2, 2>), grid, block, 0, st, p);
+  } else {
+    dim3 grid(vr_cdiv(M, BM), 1);
+    hipLaunchKernelGGL((igemm_kernel<32, 1, 1, 4, 1>), grid, block, 0, st, p);
+  }
+  VR_LAUNCH_CHECK("conv2d");
+  return VR_OK;
+}
+
+static void wgrad_plan(long M, int Cin, int Cout, int T, int* bn, int* n_tiles, int* c_tiles, int* S, int* rows) {
+  *bn = Cin > 64 ? 128 : (Cin > 32 ? 64 : 32);
+  *n_tiles = (int)vr_cdiv(Cout, BM);
+  *c_tiles = (int)vr_cdiv(Cin, *bn);
+  const long tiles = (long)(*n_tiles) * (*c_tiles) * T;
+  long s = vr_cdiv(1024, tiles);
+  const long smax = vr_cdiv(M, 64);
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  long r = vr_cdiv(vr_cdiv(M, s), BK) * BK;
+  *rows = (int)r;
+  *S = (int)vr_cdiv(M, r);
+}
+
+extern "C" long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int Cout, int kh, int kw) {
+  int bn, nt, ct, S, rows;
+  wgrad_plan((long)B * OH * OW, Cin, Cout, kh * kw, &bn, &nt, &ct, &S, &rows);
+  return ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
+}
+
+extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, float* dbias,
+                                      const float* row_scale, int B, int H, int W, int Cin, int OH, int OW,
+                                      int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                                      void* workspace, long workspace_bytes, void* stream) {
+  VR_CHECK_ARG(x && dy && dw && workspace, "conv2d_wgrad: null tensor");
+  const long M = (long)B * OH * OW;
+  VR_CHECK_ARG(M < (1L << 31) && (long)B * H * W < (1L << 31), "conv2d_wgrad: too many pixels");
+  const int T = kh * kw;
+  int bn, nt, ct, S, rows;
+  wgrad_plan(M, Cin, Cout, T, &bn, &nt, &ct, &S, &rows);
+  const long need = vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw);
+  if (workspace_bytes < need) {
+    vr_set_error("conv2d_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
+    return VR_ERR_WORKSPACE;
+  }
+  WgradArgs p{};
+  p.x = x; p.ldx = ldx; p.dy = dy; p.lddy = lddy;
+  p.slab = reinterpret_cast<float*>(workspace);
+  p.bslab = dbias ? p.slab + (long)S * T * Cout * Cin : nullptr;
+  p.M = (int)M; p.OH = OH; p.OW = OW; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.rows_per_split = rows; p.n_tiles = nt; p.c_tiles = ct;
+  p.x_vec = (Cin % 4 == 0) && (ldx % 4 == 0) && vr_aligned16(x);
+  p.dy_vec = (Cout % 4 == 0) && (lddy % 4 == 0) && vr_aligned16(dy);
+  hipStream_t st = vr_stream(stream);
+  dim3 grid(nt * ct * T, S), block(256);
+  if (bn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 2, 2, 2, 2>), grid, block, 0, st, p);
+  else if (bn == 64) hipLaunchKernelGGL((wgrad_kernel<64, 2, 1, 2, 2>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((wgrad_kernel<32, 1, 1, 4, 1>), grid, block, 0, st, p);
+  VR_LAUNCH_CHECK("conv2d_wgrad");
+  const long total = (long)T * Cout * Cin + (dbias ? Cout : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(vr_cdiv(total, 256)), dim3(256), 0, st, p.slab, p.bslab, row_scale, dw,
+                     dbias, S, T, Cout, Cin, accumulate);
+  VR_LAUNCH_CHECK("conv2d_wgrad_reduce");
+  return VR_OK;
+}
+
+extern "C" int vrnet_pack_weight_f32(const float* w_oihw, float* w_tnc, int Cout, int Cin, int kh, int kw,
+                                     void* stream) {
+  VR_CHECK_ARG(w_oihw && w_tnc, "pack_weight: null tensor");
+  const long total = (long)kh * kw * Cout * Cin;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(vr_cdiv(total, 256)), dim3(256), 0, vr_stream(stream), w_oihw, w_tnc,
+                     Cout, Cin, kh * kw);
+  VR_LAUNCH_CHECK("pack_weight");
+  return VR_OK;
+}

@@ -1,0 +1,622 @@
+// Spatial / attention streaming kernels of the fusion hot path (NHWC fp32):
+//   depthwise 3x3 (head towers, backbone/conv_utils/normal_conv.py:23-33), bilinear x2/x4 upsampling with
+//   align_corners=True (neck/coc_fpn_dual.py:19-22), the radar-guided image gain of ImageEnhanceByRadar with
+//   its batch-global min/max normalisation (backbone/fusion/vr_coc.py:59-67,312-316) and ShuffleAttention
+//   (backbone/attention_modules/shuffle_attention.py:48-72), each with its backward.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ depthwise 3x3
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* x, long ldx, const float* w, float* y, long ldy,
+                                                        int B, int H, int W, int C, int flip, int accumulate) {
+  const long total = (long)B * H * W * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = e % C;
+    const long pix = e / C;
+    const int xx = pix % W;
+    const long q = pix / W;
+    const int yy = q % H;
+    const long b = q / H;
+    float s = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int sy = yy + ky - 1;
+      if (sy < 0 || sy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int sx = xx + kx - 1;
+        if (sx < 0 || sx >= W) continue;
+        const int t = ky * 3 + kx;
+        s += x[((b * H + sy) * W + sx) * ldx + c] * w[c * 9 + (flip ? 8 - t : t)];
+      }
+    }
+    float* d = y + pix * ldy + c;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+// partial[chunk][c][9]: dw[c][t] = sum_pix dy[pix, c] * x[pix + tap t, c]
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* x, long ldx, const float* dy, long lddy,
+                                                              int B, int H, int W, int C, long pix_per_chunk,
+                                                              float* partial) {
+  __shared__ float sm[256 * 9];
+  const int TPR = min(256, C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256)));
+  const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR, RP = 256 / TPR;
+  const int c = blockIdx.y * TPR + tx;
+  const long npix = (long)B * H * W;
+  const long p0 = blockIdx.x * pix_per_chunk, p1 = min(npix, p0 + pix_per_chunk);
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  if (c < C) {
+    for (long pix = p0 + ty; pix < p1; pix += RP) {
+      const int xx = pix % W;
+      const long q = pix / W;
+      const int yy = q % H;
+      const long b = q / H;
+      const float g = dy[pix * lddy + c];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int sy = yy + ky - 1;
+        if (sy < 0 || sy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int sx = xx + kx - 1;
+          if (sx < 0 || sx >= W) continue;
+          acc[ky * 3 + kx] += g * x[((b * H + sy) * W + sx) * ldx + c];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) sm[threadIdx.x * 9 + t] = acc[t];
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    for (int r = 1; r < RP; ++r)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] += sm[(r * TPR + tx) * 9 + t];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) partial[((long)blockIdx.x * C + c) * 9 + t] = acc[t];
+  }
+}
+__global__ void dwconv3x3_wgrad_reduce_kernel(const float* partial, int nchunks, int C, float* dw, int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= C * 9) return;
+  double s = 0;
+  for (int k = 0; k < nchunks; ++k) s += partial[(long)k * C * 9 + e];
+  dw[e] = (accumulate ? dw[e] : 0.f) + (float)s;
+}
+
+// ------------------------------------------------------------------------------------------ bilinear upsample
+__device__ __forceinline__ void src_index(float scale, int o, int in_size, int* i0, int* i1, float* l1) {
+  const float r = scale * (float)o;
+  int a = (int)r;
+  if (a > in_size - 1) a = in_size - 1;
+  *i0 = a;
+  *i1 = a + ((a < in_size - 1) ? 1 : 0);
+  *l1 = r - (float)a;
+}
+
+__global__ __launch_bounds__(256) void upsample_kernel(const float* x, long ldx, float* y, long ldy, int B, int H,
+                                                       int W, int C, int OH, int OW, int out_nchw) {
+  const float ry = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float rx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const long total = (long)B * OH * OW * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    int c, ox, oy;
+    long b;
+    if (out_nchw) {   // e runs over [b][c][oy][ox] so that stores coalesce
+      ox = e % OW; long q = e / OW; oy = q % OH; q /= OH; c = q % C; b = q / C;
+    } else {
+      c = e % C; long q = e / C; ox = q % OW; q /= OW; oy = q % OH; b = q / OH;
+    }
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(ry, oy, H, &y0, &y1, &ly);
+    src_index(rx, ox, W, &x0, &x1, &lx);
+    const float* base = x + (b * H * W) * ldx + c;
+    const float v00 = base[((long)y0 * W + x0) * ldx], v01 = base[((long)y0 * W + x1) * ldx];
+    const float v10 = base[((long)y1 * W + x0) * ldx], v11 = base[((long)y1 * W + x1) * ldx];
+    const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    if (out_nchw) y[e] = v;
+    else y[((b * OH + oy) * OW + ox) * ldy + c] = v;
+  }
+}
+
+// gather form of the adjoint: deterministic, no atomics
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* dy, long lddy, int dy_nchw, float* dx, long lddx,
+                                                           int B, int H, int W, int C, int OH, int OW, int accumulate) {
+  const float ry = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float rx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const long total = (long)B * H * W * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = e % C;
+    long q = e / C;
+    const int ix = q % W; q /= W;
+    const int iy = q % H;
+    const long b = q / H;
+    int oy_lo = 0, oy_hi = OH - 1, ox_lo = 0, ox_hi = OW - 1;
+    if (ry > 0.f) {
+      oy_lo = max(0, (int)floorf((float)(iy - 1) / ry) - 1);
+      oy_hi = min(OH - 1, (int)ceilf((float)(iy + 1) / ry) + 1);
+    }
+    if (rx > 0.f) {
+      ox_lo = max(0, (int)floorf((float)(ix - 1) / rx) - 1);
+      ox_hi = min(OW - 1, (int)ceilf((float)(ix + 1) / rx) + 1);
+    }
+    float s = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly;
+      src_index(ry, oy, H, &y0, &y1, &ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx;
+        src_index(rx, ox, W, &x0, &x1, &lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx == 0.f) continue;
+        const float g = dy_nchw ? dy[((b * C + c) * OH + oy) * (long)OW + ox]
+                                : dy[((b * OH + oy) * (long)OW + ox) * lddy + c];
+        s += wy * wx * g;
+      }
+    }
+    float* d = dx + ((b * H + iy) * (long)W + ix) * lddx + c;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ min / max, image gain
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const float* p, long n, float* partial) {
+  __shared__ float smn[4], smx[4];
+  float mn = INFINITY, mx = -INFINITY;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const float v = p[e];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    partial[2 * blockIdx.x + 1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  }
+}
+__global__ __launch_bounds__(256) void minmax_final_kernel(const float* partial, int nblocks, float* mm) {
+  __shared__ float smn[4], smx[4];
+  float mn = INFINITY, mx = -INFINITY;
+  for (int e = threadIdx.x; e < nblocks; e += 256) {
+    mn = fminf(mn, partial[2 * e]);
+    mx = fmaxf(mx, partial[2 * e + 1]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mm[0] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    mm[1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  }
+}
+
+// out = (1 + (p - mn) / (mx - mn)) * x     (contiguous tensors of n elements)
+__global__ void enhance_mul_kernel(const float* p, const float* x, const float* mm, float* out, long n) {
+  const float mn = mm[0], dst = mm[1] - mm[0];
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    out[e] = (1.f + (p[e] - mn) / dst) * x[e];
+}
+
+// sums: [0] sum dn, [1] sum dn*(p-mn), [2] #(p == mn), [3] #(p == mx)   with dn = dt * x
+__global__ __launch_bounds__(256) void enhance_bwd_partial_kernel(const float* dt, const float* x, const float* p,
+                                                                  const float* mm, long n, double* partial) {
+  __shared__ double red[4][4];
+  const float mn = mm[0], mx = mm[1];
+  double s[4] = {0, 0, 0, 0};
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const float pv = p[e];
+    const double dn = (double)dt[e] * (double)x[e];
+    s[0] += dn;
+    s[1] += dn * (double)(pv - mn);
+    s[2] += (pv == mn) ? 1.0 : 0.0;
+    s[3] += (pv == mx) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[threadIdx.x >> 6][i] = s[i];
+  __syncthreads();
+  if (threadIdx.x < 4) partial[4 * (long)blockIdx.x + threadIdx.x] =
+      red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void enhance_bwd_final_kernel(const double* partial, int nblocks, double* sums) {
+  __shared__ double red[4][4];
+  double s[4] = {0, 0, 0, 0};
+  for (int e = threadIdx.x; e < nblocks; e += 256)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] += partial[4 * (long)e + i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[threadIdx.x >> 6][i] = s[i];
+  __syncthreads();
+  if (threadIdx.x < 4) sums[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+// dx (+)= dt * (1 + n);  dp = dn/dst + [p==mn] g_mn/cnt_mn + [p==mx] g_mx/cnt_mx
+__global__ void enhance_bwd_apply_kernel(const float* dt, const float* x, const float* p, const float* mm,
+                                         const double* sums, float* dx, float* dp, long n, int accumulate_dx) {
+  const float mn = mm[0], mx = mm[1];
+  const double dst = (double)mx - (double)mn;
+  const float gmn = (float)((-sums[0] / dst + sums[1] / (dst * dst)) / sums[2]);
+  const float gmx = (float)((-sums[1] / (dst * dst)) / sums[3]);
+  const float fd = (float)dst;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const float pv = p[e], g = dt[e];
+    const float gain = 1.f + (pv - mn) / fd;
+    const float vx = g * gain;
+    dx[e] = accumulate_dx ? dx[e] + vx : vx;
+    float v = g * x[e] / fd;
+    if (pv == mn) v += gmn;
+    if (pv == mx) v += gmx;
+    dp[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ ShuffleAttention
+struct SaParams {
+  const float *cw, *cb, *sw, *sb, *gnw, *gnb;
+};
+__device__ __forceinline__ int sa_dst(int q, int C) { return q < C / 2 ? 2 * q : 2 * (q - C / 2) + 1; }
+
+__global__ void sa_coef_fwd_kernel(const double* mom, SaParams sp, int B, long HW, int C, int G, float* P, float* Q) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)B * C) return;
+  const int q = e % C, cp = C / (2 * G);
+  const int rem = q % (2 * cp), half = rem / cp, i = rem % cp;
+  const double mean = mom[2 * e] / (double)HW;
+  if (half == 0) {
+    P[e] = 0.f;
+    Q[e] = (float)((double)sp.cw[i] * mean + (double)sp.cb[i]);
+  } else {
+    double var = mom[2 * e + 1] / (double)HW - mean * mean;
+    if (var < 0) var = 0;
+    const double r = 1.0 / sqrt(var + 1e-5);
+    P[e] = (float)((double)sp.sw[i] * sp.gnw[i] * r);
+    Q[e] = (float)((double)sp.sw[i] * ((double)sp.gnb[i] - (double)sp.gnw[i] * mean * r) + (double)sp.sb[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void sa_apply_kernel(const float* x, long ldx, const float* P, const float* Q, float* y,
+                                                       long ldy, long HW, int C) {
+  const long b = blockIdx.y;
+  const long total = HW * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / C;
+    const int q = e - r * C;
+    const float xv = x[(b * HW + r) * ldx + q];
+    const float z = P[b * C + q] * xv + Q[b * C + q];
+    y[(b * HW + r) * ldy + sa_dst(q, C)] = xv * vr_sigmoid(z);
+  }
+}
+
+// per (b,q): T1 = sum dz, T2 = sum dz*x with dz = dy[dst(q)] * x * sig'(z); one workgroup per (row chunk, b)
+__global__ __launch_bounds__(256) void sa_bwd_reduce_kernel(const float* dy, long lddy, const float* x, long ldx,
+                                                            const float* P, const float* Q, long HW, int C, int TPR,
+                                                            long rows_per_chunk, int nchunks, double* partial) {
+  extern __shared__ double smd[];   // [256][2]
+  const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR, RP = 256 / TPR;
+  const int chunk = blockIdx.x;
+  const long b = blockIdx.y;
+  const int q = blockIdx.z * TPR + tx;
+  const long r0 = chunk * rows_per_chunk, r1 = min(HW, r0 + rows_per_chunk);
+  double t1 = 0, t2 = 0;
+  if (q < C) {
+    const float pq = P[b * C + q], qq = Q[b * C + q];
+    const int dq = sa_dst(q, C);
+    for (long r = r0 + ty; r < r1; r += RP) {
+      const float xv = x[(b * HW + r) * ldx + q];
+      const float sg = vr_sigmoid(pq * xv + qq);
+      const double dz = (double)(dy[(b * HW + r) * lddy + dq] * xv * sg * (1.f - sg));
+      t1 += dz;
+      t2 += dz * (double)xv;
+    }
+  }
+  smd[threadIdx.x * 2] = t1;
+  smd[threadIdx.x * 2 + 1] = t2;
+  __syncthreads();
+  if (ty == 0 && q < C) {
+    for (int r = 1; r < RP; ++r) {
+      t1 += smd[(r * TPR + tx) * 2];
+      t2 += smd[(r * TPR + tx) * 2 + 1];
+    }
+    partial[((b * nchunks + chunk) * C + q) * 2] = t1;
+    partial[((b * nchunks + chunk) * C + q) * 2 + 1] = t2;
+  }
+}
+__global__ void sa_reduce_chunks_kernel(const double* partial, double* out, int B, int nchunks, int C) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)B * C * 2) return;
+  const long b = e / (2L * C), rem = e - b * 2L * C;
+  double s = 0.0;
+  for (int k = 0; k < nchunks; ++k) s += partial[((long)b * nchunks + k) * C * 2 + rem];
+  out[e] = s;
+}
+
+// blocks [0, nb1): E,F per (b,q);  block nb1: parameter gradients (one thread per (half, i))
+__global__ __launch_bounds__(256) void sa_coef_bwd_kernel(const double* T, const double* mom, SaParams sp, int B, long HW,
+                                                          int C, int G, int nb1, float* E, float* F, float* dcw,
+                                                          float* dcb, float* dsw, float* dsb, float* dgnw, float* dgnb,
+                                                          int accumulate) {
+  const int cp = C / (2 * G);
+  if ((int)blockIdx.x < nb1) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)B * C) return;
+    const int q = e % C;
+    const int rem = q % (2 * cp), half = rem / cp, i = rem % cp;
+    const double t1 = T[2 * e], t2 = T[2 * e + 1];
+    const double mean = mom[2 * e] / (double)HW;
+    if (half == 0) {
+      E[e] = 0.f;
+      F[e] = (float)((double)sp.cw[i] * t1 / (double)HW);
+    } else {
+      double var = mom[2 * e + 1] / (double)HW - mean * mean;
+      if (var < 0) var = 0;
+      const double r = 1.0 / sqrt(var + 1e-5);
+      const double k = (double)sp.sw[i] * sp.gnw[i];
+      const double m1 = k * t1 / (double)HW, m2 = k * r * (t2 - mean * t1) / (double)HW;
+      E[e] = (float)(-r * r * m2);
+      F[e] = (float)(-r * m1 + r * r * m2 * mean);
+    }
+  } else {
+    for (int i = threadIdx.x; i < cp; i += 256) {
+      double gcw = 0, gcb = 0, gsw = 0, gsb = 0, ggw = 0, ggb = 0;
+      for (int b = 0; b < B; ++b)
+        for (int g = 0; g < G; ++g) {
+          {
+            const long e = (long)b * C + g * 2 * cp + i;
+            const double mean = mom[2 * e] / (double)HW;
+            gcw += mean * T[2 * e];
+            gcb += T[2 * e];
+          }
+          {
+            const long e = (long)b * C + g * 2 * cp + cp + i;
+            const double t1 = T[2 * e], t2 = T[2 * e + 1];
+            const double mean = mom[2 * e] / (double)HW;
+            double var = mom[2 * e + 1] / (double)HW - mean * mean;
+            if (var < 0) var = 0;
+            const double r = 1.0 / sqrt(var + 1e-5);
+            const double xh = r * (t2 - mean * t1);   // sum dz * xhat
+            gsw += (double)sp.gnw[i] * xh + (double)sp.gnb[i] * t1;
+            gsb += t1;
+            ggw += (double)sp.sw[i] * xh;
+            ggb += (double)sp.sw[i] * t1;
+          }
+        }
+      dcw[i] = (accumulate ? dcw[i] : 0.f) + (float)gcw;
+      dcb[i] = (accumulate ? dcb[i] : 0.f) + (float)gcb;
+      dsw[i] = (accumulate ? dsw[i] : 0.f) + (float)gsw;
+      dsb[i] = (accumulate ? dsb[i] : 0.f) + (float)gsb;
+      dgnw[i] = (accumulate ? dgnw[i] : 0.f) + (float)ggw;
+      dgnb[i] = (accumulate ? dgnb[i] : 0.f) + (float)ggb;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sa_bwd_apply_kernel(const float* dy, long lddy, const float* x, long ldx,
+                                                           const float* P, const float* Q, const float* E, const float* F,
+                                                           float* dx, long lddx, long HW, int C, int accumulate) {
+  const long b = blockIdx.y;
+  const long total = HW * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / C;
+    const int q = e - r * C;
+    const float xv = x[(b * HW + r) * ldx + q];
+    const float pq = P[b * C + q];
+    const float sg = vr_sigmoid(pq * xv + Q[b * C + q]);
+    const float g = dy[(b * HW + r) * lddy + sa_dst(q, C)];
+    const float v = g * (sg + xv * sg * (1.f - sg) * pq) + E[b * C + q] * xv + F[b * C + q];
+    float* d = dx + (b * HW + r) * lddx + q;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+inline long grid_for(long n, long per_block = 1024, long cap = 8192) {
+  long g = vr_cdiv(n, per_block);
+  return g < 1 ? 1 : (g > cap ? cap : g);
+}
+
+void sa_plan(long HW, int C, int* TPR, int* ncb, int* nchunks, long* rows) {
+  int t = 1;
+  while (t < C && t < 256) t <<= 1;
+  *TPR = t;
+  *ncb = (int)vr_cdiv(C, t);
+  long nc = vr_cdiv(HW * C, 8192);
+  if (nc < 1) nc = 1;
+  if (nc > 1024) nc = 1024;
+  if (nc > HW) nc = HW;
+  *rows = vr_cdiv(HW, nc);
+  *nchunks = (int)vr_cdiv(HW, *rows);
+}
+
+}  // namespace
+
+extern "C" int vrnet_dwconv3x3_f32(const float* x, long ldx, const float* w, float* y, long ldy, int B, int H, int W,
+                                   int C, int flip, int accumulate, void* stream) {
+  VR_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && C > 0, "dwconv3x3: bad arguments");
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, vr_stream(stream), x, ldx, w, y,
+                     ldy, B, H, W, C, flip, accumulate);
+  VR_LAUNCH_CHECK("dwconv3x3");
+  return VR_OK;
+}
+
+static void dw_wgrad_plan(long npix, int C, int* nchunks, long* ppc) {
+  long nc = vr_cdiv(npix * C, 16384);
+  if (nc < 1) nc = 1;
+  if (nc > 512) nc = 512;
+  *ppc = vr_cdiv(npix, nc);
+  *nchunks = (int)vr_cdiv(npix, *ppc);
+}
+extern "C" long vrnet_dwconv3x3_wgrad_workspace(int B, int H, int W, int C) {
+  int nchunks;
+  long ppc;
+  dw_wgrad_plan((long)B * H * W, C, &nchunks, &ppc);
+  return (long)nchunks * C * 9 * 4 + 256;
+}
+extern "C" int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, int B, int H,
+                                         int W, int C, int accumulate, void* workspace, long workspace_bytes,
+                                         void* stream) {
+  VR_CHECK_ARG(x && dy && dw && workspace, "dwconv3x3_wgrad: null tensor");
+  int nchunks;
+  long ppc;
+  dw_wgrad_plan((long)B * H * W, C, &nchunks, &ppc);
+  if (workspace_bytes < vrnet_dwconv3x3_wgrad_workspace(B, H, W, C)) {
+    vr_set_error("dwconv3x3_wgrad: workspace too small");
+    return VR_ERR_WORKSPACE;
+  }
+  const int TPR = C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256));
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipStream_t st = vr_stream(stream);
+  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(nchunks, vr_cdiv(C, TPR)), dim3(256), 0, st, x, ldx, dy, lddy, B, H, W,
+                     C, ppc, partial);
+  VR_LAUNCH_CHECK("dwconv3x3_wgrad");
+  hipLaunchKernelGGL(dwconv3x3_wgrad_reduce_kernel, dim3(vr_cdiv(C * 9, 256)), dim3(256), 0, st, partial, nchunks, C, dw,
+                     accumulate);
+  VR_LAUNCH_CHECK("dwconv3x3_wgrad_reduce");
+  return VR_OK;
+}
+
+extern "C" int vrnet_upsample_bilinear_f32(const float* x, long ldx, float* y, long ldy, int B, int H, int W, int C,
+                                           int scale, int out_nchw, void* stream) {
+  VR_CHECK_ARG(x && y && scale >= 1 && B > 0 && H > 0 && W > 0 && C > 0, "upsample: bad arguments");
+  hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long)B * H * W * scale * scale * C)), dim3(256), 0,
+                     vr_stream(stream), x, ldx, y, ldy, B, H, W, C, H * scale, W * scale, out_nchw);
+  VR_LAUNCH_CHECK("upsample");
+  return VR_OK;
+}
+
+extern "C" int vrnet_upsample_bilinear_bwd_f32(const float* dy, long lddy, int dy_nchw, float* dx, long lddx, int B,
+                                               int H, int W, int C, int scale, int accumulate, void* stream) {
+  VR_CHECK_ARG(dy && dx && scale >= 1, "upsample_bwd: bad arguments");
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((long)B * H * W * C, 256)), dim3(256), 0, vr_stream(stream), dy,
+                     lddy, dy_nchw, dx, lddx, B, H, W, C, H * scale, W * scale, accumulate);
+  VR_LAUNCH_CHECK("upsample_bwd");
+  return VR_OK;
+}
+
+extern "C" long vrnet_reduce_workspace(void) { return 8192L * 4 * 8 + 256; }
+
+extern "C" int vrnet_minmax_f32(const float* p, long n, float* mm, void* workspace, long workspace_bytes, void* stream) {
+  VR_CHECK_ARG(p && mm && workspace && n > 0, "minmax: bad arguments");
+  VR_CHECK_ARG(workspace_bytes >= vrnet_reduce_workspace(), "minmax: workspace too small");
+  const int nb = (int)grid_for(n, 2048, 2048);
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(256), 0, vr_stream(stream), p, n, partial);
+  VR_LAUNCH_CHECK("minmax_partial");
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, vr_stream(stream), partial, nb, mm);
+  VR_LAUNCH_CHECK("minmax_final");
+  return VR_OK;
+}
+
+extern "C" int vrnet_enhance_mul_f32(const float* p, const float* x, const float* mm, float* out, long n, void* stream) {
+  VR_CHECK_ARG(p && x && mm && out && n > 0, "enhance_mul: bad arguments");
+  hipLaunchKernelGGL(enhance_mul_kernel, dim3(grid_for(n)), dim3(256), 0, vr_stream(stream), p, x, mm, out, n);
+  VR_LAUNCH_CHECK("enhance_mul");
+  return VR_OK;
+}
+
+extern "C" int vrnet_enhance_bwd_f32(const float* dt, const float* x, const float* p, const float* mm, float* dx,
+                                     float* dp, long n, int accumulate_dx, void* workspace, long workspace_bytes,
+                                     void* stream) {
+  VR_CHECK_ARG(dt && x && p && mm && dx && dp && workspace && n > 0, "enhance_bwd: bad arguments");
+  VR_CHECK_ARG(workspace_bytes >= vrnet_reduce_workspace(), "enhance_bwd: workspace too small");
+  const int nb = (int)grid_for(n, 2048, 2048);
+  double* partial = reinterpret_cast<double*>(workspace);
+  double* sums = partial + 4L * nb;
+  hipStream_t st = vr_stream(stream);
+  hipLaunchKernelGGL(enhance_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, dt, x, p, mm, n, partial);
+  VR_LAUNCH_CHECK("enhance_bwd_partial");
+  hipLaunchKernelGGL(enhance_bwd_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, sums);
+  VR_LAUNCH_CHECK("enhance_bwd_final");
+  hipLaunchKernelGGL(enhance_bwd_apply_kernel, dim3(grid_for(n)), dim3(256), 0, st, dt, x, p, mm, sums, dx, dp, n,
+                     accumulate_dx);
+  VR_LAUNCH_CHECK("enhance_bwd_apply");
+  return VR_OK;
+}
+
+extern "C" int vrnet_sa_coef_fwd(const double* mom, const float* cw, const float* cb, const float* sw, const float* sb,
+                                 const float* gnw, const float* gnb, int B, long HW, int C, int G, float* P, float* Q,
+                                 void* stream) {
+  VR_CHECK_ARG(mom && cw && cb && sw && sb && gnw && gnb && P && Q, "sa_coef_fwd: null tensor");
+  VR_CHECK_ARG(G > 0 && C % (2 * G) == 0 && C / (2 * G) > 0, "sa_coef_fwd: channels %d not divisible by 2*G=%d", C, 2 * G);
+  SaParams sp{cw, cb, sw, sb, gnw, gnb};
+  hipLaunchKernelGGL(sa_coef_fwd_kernel, dim3(vr_cdiv((long)B * C, 256)), dim3(256), 0, vr_stream(stream), mom, sp, B, HW,
+                     C, G, P, Q);
+  VR_LAUNCH_CHECK("sa_coef_fwd");
+  return VR_OK;
+}
+
+extern "C" int vrnet_sa_apply_f32(const float* x, long ldx, const float* P, const float* Q, float* y, long ldy, int B,
+                                  long HW, int C, void* stream) {
+  VR_CHECK_ARG(x && P && Q && y && C % 2 == 0, "sa_apply: bad arguments");
+  hipLaunchKernelGGL(sa_apply_kernel, dim3(grid_for(HW * C), B), dim3(256), 0, vr_stream(stream), x, ldx, P, Q, y, ldy, HW,
+                     C);
+  VR_LAUNCH_CHECK("sa_apply");
+  return VR_OK;
+}
+
+extern "C" long vrnet_sa_bwd_workspace(int B, long HW, int C) {
+  int TPR, ncb, nchunks;
+  long rows;
+  sa_plan(HW, C, &TPR, &ncb, &nchunks, &rows);
+  return ((long)B * nchunks * C * 2 + (long)B * C * 2) * 8 + 256;
+}
+
+extern "C" int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long ldx, const float* P, const float* Q,
+                                const double* mom, const float* cw, const float* cb, const float* sw, const float* sb,
+                                const float* gnw, const float* gnb, float* dx, long lddx, float* dcw, float* dcb,
+                                float* dsw, float* dsb, float* dgnw, float* dgnb, float* EF /*[2][B][C] scratch*/, int B,
+                                long HW, int C, int G, int accumulate_dx, int accumulate_params, void* workspace,
+                                long workspace_bytes, void* stream) {
+  VR_CHECK_ARG(dy && x && P && Q && mom && dx && EF && workspace, "sa_bwd: null tensor");
+  VR_CHECK_ARG(workspace_bytes >= vrnet_sa_bwd_workspace(B, HW, C), "sa_bwd: workspace too small");
+  int TPR, ncb, nchunks;
+  long rows;
+  sa_plan(HW, C, &TPR, &ncb, &nchunks, &rows);
+  double* partial = reinterpret_cast<double*>(workspace);
+  double* T = partial + (long)B * nchunks * C * 2;
+  hipStream_t st = vr_stream(stream);
+  hipLaunchKernelGGL(sa_bwd_reduce_kernel, dim3(nchunks, B, ncb), dim3(256), 256 * 2 * sizeof(double), st, dy, lddy, x,
+                     ldx, P, Q, HW, C, TPR, rows, nchunks, partial);
+  VR_LAUNCH_CHECK("sa_bwd_reduce");
+  hipLaunchKernelGGL(sa_reduce_chunks_kernel, dim3(vr_cdiv((long)B * C * 2, 256)), dim3(256), 0, st, partial, T, B,
+                     nchunks, C);
+  VR_LAUNCH_CHECK("sa_reduce_chunks");
+  SaParams sp{cw, cb, sw, sb, gnw, gnb};
+  const int nb1 = (int)vr_cdiv((long)B * C, 256);
+  float* E = EF;
+  float* F = EF + (long)B * C;
+  hipLaunchKernelGGL(sa_coef_bwd_kernel, dim3(nb1 + 1), dim3(256), 0, st, T, mom, sp, B, HW, C, G, nb1, E, F, dcw, dcb,
+                     dsw, dsb, dgnw, dgnb, accumulate_params);
+  VR_LAUNCH_CHECK("sa_coef_bwd");
+  hipLaunchKernelGGL(sa_bwd_apply_kernel, dim3(grid_for(HW * C), B), dim3(256), 0, st, dy, lddy, x, ldx, P, Q, E, F, dx,
+                     lddx, HW, C, accumulate_dx);
+  VR_LAUNCH_CHECK("sa_bwd_apply");
+  return VR_OK;
+}

@@ -1,0 +1,625 @@
+// HBM-bound streaming kernels over NHWC fp32 tensors viewed as [B][HW][C] rows with a row stride:
+//   * moments: per-(sample, channel) sums in fp64 (feeds GroupNorm, BatchNorm, ShuffleAttention, ECA,
+//     layer-scale and bias gradients);
+//   * affine: out = pre(A*x1 + D1) + E*x2 + D2 with per-channel or per-(sample, channel) coefficients
+//     (normalisation apply forward AND backward, ECA gating, ReLU masks, broadcasts);
+//   * the tiny coefficient kernels that turn moments into those coefficients and parameter gradients;
+//   * layout copies (channel-strided cat / shuffle, NCHW <-> NHWC), add, fill.
+// Reference semantics: GroupNorm(1,C) backbone/fusion/vr_coc.py:105-111; BatchNorm2d in BaseConv
+// backbone/conv_utils/normal_conv.py:45; eca backbone/attention_modules/eca.py:16-22; layer scale
+// vr_coc.py:264-271.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ moments
+template <int VEC>
+__global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, const float* x2, long ldx2,
+                                                      const float* mask, long ldm, long HW, int C, int TPR,
+                                                      long rows_per_chunk, int nchunks, double* partial) {
+  extern __shared__ double sm[];   // [256][2*VEC]
+  const int tid = threadIdx.x;
+  const int tx = tid % TPR, ty = tid / TPR, RP = 256 / TPR;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int CV = C / VEC;
+  const int cv = blockIdx.z * TPR + tx;
+  const long r0 = chunk * rows_per_chunk;
+  const long r1 = min(HW, r0 + rows_per_chunk);
+  double s1[VEC], s2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0;
+  if (cv < CV) {
+    const long base = (long)b * HW;
+    for (long r = r0 + ty; r < r1; r += RP) {
+      float a[VEC], c2[VEC], mk[VEC];
+      if (VEC == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (base + r) * ldx + cv * 4);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a[j] = v[j];
+        if (x2) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(x2 + (base + r) * ldx2 + cv * 4);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) c2[j] = w[j];
+        }
+        if (mask) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(mask + (base + r) * ldm + cv * 4);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) mk[j] = w[j];
+        }
+      } else {
+        a[0] = x[(base + r) * ldx + cv];
+        if (x2) c2[0] = x2[(base + r) * ldx2 + cv];
+        if (mask) mk[0] = mask[(base + r) * ldm + cv];
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float v = a[j];
+        if (mask && !(mk[j] > 0.f)) v = 0.f;
+        s1[j] += (double)v;
+        s2[j] += (double)v * (double)(x2 ? c2[j] : v);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sm[(long)tid * 2 * VEC + j] = s1[j];
+    sm[(long)tid * 2 * VEC + VEC + j] = s2[j];
+  }
+  __syncthreads();
+  if (ty == 0 && cv < CV) {
+    for (int q = 1; q < RP; ++q) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        s1[j] += sm[(long)(q * TPR + tx) * 2 * VEC + j];
+        s2[j] += sm[(long)(q * TPR + tx) * 2 * VEC + VEC + j];
+      }
+    }
+    double* out = partial + (((long)b * nchunks + chunk) * C + (long)cv * VEC) * 2;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      out[2 * j] = s1[j];
+      out[2 * j + 1] = s2[j];
+    }
+  }
+}
+
+__global__ void moments_reduce_kernel(const double* partial, double* out, int B, int nchunks, int C) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*C*2
+  if (e >= (long)B * C * 2) return;
+  const long b = e / (2L * C), rem = e - b * 2L * C;
+  double s = 0.0;
+  for (int k = 0; k < nchunks; ++k) s += partial[((long)b * nchunks + k) * C * 2 + rem];
+  out[e] = s;
+}
+
+// ------------------------------------------------------------------------------------------ affine
+struct AffineArgs {
+  const float* x1; long ld1; const float* A; const float* D1;
+  const float* masky; long ldm;
+  const float* x2; long ld2; const float* E; const float* D2;
+  float* out; long ldo;
+  long HW; int C; long bstride; int pre; int accumulate;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void affine_kernel(const AffineArgs p) {
+  const int CV = p.C / VEC;
+  const long total = p.HW * CV;
+  const long b = blockIdx.y;
+  const long cb = b * p.bstride;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / CV;
+    const int c = (int)(e - r * CV) * VEC;
+    const long row = b * p.HW + r;
+    float v[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = p.D1 ? p.D1[cb + c + j] : 0.f;
+    if (p.x1) {
+      float a[VEC];
+      if (VEC == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.x1 + row * p.ld1 + c);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a[j] = t[j];
+      } else {
+        a[0] = p.x1[row * p.ld1 + c];
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] += (p.A ? p.A[cb + c + j] : 1.f) * a[j];
+    }
+    if (p.pre == 1) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = fmaxf(v[j], 0.f);
+    } else if (p.pre == 2) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if (!(p.masky[row * p.ldm + c + j] > 0.f)) v[j] = 0.f;
+    }
+    if (p.x2) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] += (p.E ? p.E[cb + c + j] : 1.f) * p.x2[row * p.ld2 + c + j];
+    }
+    if (p.D2) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] += p.D2[cb + c + j];
+    }
+    float* o = p.out + row * p.ldo + c;
+    if (p.accumulate) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] += o[j];
+    }
+    if (VEC == 4) {
+      f32x4 t = {v[0], v[VEC > 1 ? 1 : 0], v[VEC > 2 ? 2 : 0], v[VEC > 3 ? 3 : 0]};
+      *reinterpret_cast<f32x4*>(o) = t;
+    } else {
+      o[0] = v[0];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ coefficients
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void gn_coef_fwd_kernel(const double* mom, const float* gamma, const float* beta,
+                                                          float eps, long HW, int C, float* A, float* D,
+                                                          float* mean_rstd) {
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  double s1 = 0, s2 = 0;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    s1 += mom[((long)b * C + c) * 2];
+    s2 += mom[((long)b * C + c) * 2 + 1];
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  const double n = (double)HW * C;
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0) var = 0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double a = rstd * gamma[c];
+    A[(long)b * C + c] = (float)a;
+    D[(long)b * C + c] = (float)((double)beta[c] - mean * a);
+  }
+  if (threadIdx.x == 0) {
+    mean_rstd[2 * b] = (float)mean;
+    mean_rstd[2 * b + 1] = (float)rstd;
+  }
+}
+
+// blocks [0, B): per-sample dx coefficients; blocks [B, ...): per-channel dgamma / dbeta
+__global__ __launch_bounds__(256) void gn_coef_bwd_kernel(const double* mom2, const float* mean_rstd,
+                                                          const float* gamma, int B, long HW, int C, float* A,
+                                                          float* E, float* D, float* dgamma, float* dbeta,
+                                                          int accumulate) {
+  __shared__ double red[4];
+  if ((int)blockIdx.x < B) {
+    const int b = blockIdx.x;
+    const double mu = mean_rstd[2 * b], r = mean_rstd[2 * b + 1];
+    double t1 = 0, t2 = 0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const double g = gamma[c], s1 = mom2[((long)b * C + c) * 2], s2 = mom2[((long)b * C + c) * 2 + 1];
+      t1 += g * s1;
+      t2 += g * (s2 - mu * s1);
+    }
+    t1 = block_sum(t1, red);
+    t2 = block_sum(t2, red);
+    const double n = (double)HW * C;
+    const double m1 = t1 / n, m2 = r * t2 / n;
+    const float e = (float)(-r * r * m2), d = (float)(-r * m1 + r * r * m2 * mu);
+    for (int c = threadIdx.x; c < C; c += 256) {
+      A[(long)b * C + c] = (float)(r * gamma[c]);
+      E[(long)b * C + c] = e;
+      D[(long)b * C + c] = d;
+    }
+  } else {
+    const int c = (blockIdx.x - B) * 256 + threadIdx.x;
+    if (c >= C) return;
+    double dg = 0, db = 0;
+    for (int b = 0; b < B; ++b) {
+      const double mu = mean_rstd[2 * b], r = mean_rstd[2 * b + 1];
+      const double s1 = mom2[((long)b * C + c) * 2], s2 = mom2[((long)b * C + c) * 2 + 1];
+      dg += r * (s2 - mu * s1);
+      db += s1;
+    }
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dg;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)db;
+  }
+}
+
+__global__ void bn_coef_fwd_kernel(const double* mom, const float* gamma, const float* beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, long long* nbt,
+                                   int training, int B, long HW, int C, float* A, float* D, float* mean_rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && nbt) *nbt += 1;
+  if (c >= C) return;
+  double mean, var;
+  if (training) {
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < B; ++b) {
+      s1 += mom[((long)b * C + c) * 2];
+      s2 += mom[((long)b * C + c) * 2 + 1];
+    }
+    const double n = (double)B * HW;
+    mean = s1 / n;
+    var = s2 / n - mean * mean;
+    if (var < 0) var = 0;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (n / (n - 1.0)));
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double a = rstd * gamma[c];
+  A[c] = (float)a;
+  D[c] = (float)((double)beta[c] - mean * a);
+  mean_rstd[2 * c] = (float)mean;
+  mean_rstd[2 * c + 1] = (float)rstd;
+}
+
+__global__ void bn_coef_bwd_kernel(const double* mom2, const float* mean_rstd, const float* gamma, int training,
+                                   int B, long HW, int C, float* A, float* E, float* D, float* dgamma, float* dbeta,
+                                   int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int b = 0; b < B; ++b) {
+    s1 += mom2[((long)b * C + c) * 2];
+    s2 += mom2[((long)b * C + c) * 2 + 1];
+  }
+  const double mu = mean_rstd[2 * c], r = mean_rstd[2 * c + 1], g = gamma[c];
+  const double n = (double)B * HW;
+  const double dxh = r * (s2 - mu * s1);   // sum dy * xhat
+  A[c] = (float)(g * r);
+  if (training) {
+    const double m1 = s1 / n, m2 = dxh / n;
+    E[c] = (float)(-g * r * r * m2);
+    D[c] = (float)(-g * r * m1 + g * r * r * m2 * mu);
+  } else {
+    E[c] = 0.f;
+    D[c] = 0.f;
+  }
+  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dxh;
+  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+}
+
+// gate[b][c] = sigmoid(sum_j wk[j] * mean[b][c + j - pad]);  eca.py:16-22
+__global__ void eca_coef_fwd_kernel(const double* mom, const float* wk, int k, int B, long HW, int C, float* gate) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)B * C) return;
+  const int b = e / C, c = e % C, pad = (k - 1) / 2;
+  double z = 0;
+  for (int j = 0; j < k; ++j) {
+    const int cc = c + j - pad;
+    if (cc >= 0 && cc < C) z += (double)wk[j] * (mom[((long)b * C + cc) * 2] / (double)HW);
+  }
+  gate[e] = (float)(1.0 / (1.0 + exp(-z)));
+}
+
+// mom2 = (sum dy, sum dy*x) per (b,c); mom = x moments.  F[b][c] = dm[b][c] / HW (constant added to dx).
+// dwk (k taps) is reduced by block 0 only after the per-element pass (second kernel below).
+__global__ void eca_coef_bwd_kernel(const double* mom2, const float* gate, const float* wk, int k, int B, long HW,
+                                    int C, float* F) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)B * C) return;
+  const int b = e / C, c = e % C, pad = (k - 1) / 2;
+  double dm = 0;
+  for (int j = 0; j < k; ++j) {
+    const int cc = c - j + pad;   // z[b][cc] uses m[b][cc + j - pad] = m[b][c]
+    if (cc >= 0 && cc < C) {
+      const double g = gate[(long)b * C + cc];
+      dm += (double)wk[j] * mom2[((long)b * C + cc) * 2 + 1] * g * (1.0 - g);
+    }
+  }
+  F[e] = (float)(dm / (double)HW);
+}
+
+__global__ __launch_bounds__(256) void eca_dwk_kernel(const double* mom2, const double* mom, const float* gate,
+                                                      int k, int B, long HW, int C, float* dwk, int accumulate) {
+  __shared__ double red[4];
+  const int j = blockIdx.x, pad = (k - 1) / 2;
+  double s = 0;
+  for (long e = threadIdx.x; e < (long)B * C; e += 256) {
+    const int b = e / C, c = e % C, cc = c + j - pad;
+    if (cc >= 0 && cc < C) {
+      const double g = gate[e];
+      s += mom2[e * 2 + 1] * g * (1.0 - g) * (mom[((long)b * C + cc) * 2] / (double)HW);
+    }
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) dwk[j] = (accumulate ? dwk[j] : 0.f) + (float)s;
+}
+
+// layer scale: x_new = x + ls * o.  mom2 = (sum dx, sum dx*o).  dls = sum_b S2; dbias = ls * sum_b S1.
+__global__ void ls_coef_bwd_kernel(const double* mom2, const float* ls, int B, int C, float* dls, float* dbias,
+                                   int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int b = 0; b < B; ++b) {
+    s1 += mom2[((long)b * C + c) * 2];
+    s2 += mom2[((long)b * C + c) * 2 + 1];
+  }
+  if (dls) dls[c] = (accumulate ? dls[c] : 0.f) + (float)s2;
+  if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)((ls ? (double)ls[c] : 1.0) * s1);
+}
+
+// out[b][c] = mom[b][c][0] * scale   (global average pooling, per-sample column sums)
+__global__ void moments_to_float_kernel(const double* mom, float* out, long n, double scale, int which) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) out[e] = (float)(mom[2 * e + which] * scale);
+}
+
+// ------------------------------------------------------------------------------------------ copies
+// dst[r*ldd + c*dcs] (+)= src[r*lds + c*scs]
+__global__ void copy_channels_kernel(const float* src, long lds, int scs, float* dst, long ldd, int dcs, long rows,
+                                     int C, int accumulate) {
+  const long total = rows * C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / C;
+    const int c = e - r * C;
+    const float v = src[r * lds + (long)c * scs];
+    float* d = dst + r * ldd + (long)c * dcs;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+// 32x32 LDS-tiled transpose between [B][C][HW] and [B][HW][ld]
+__global__ void nchw_to_nhwc_kernel(const float* src, float* dst, long ldd, int C, long HW) {
+  __shared__ float tile[32][33];
+  const long b = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i;
+    const long pp = p0 + tx;
+    tile[i][tx] = (c < C && pp < HW) ? src[(b * C + c) * HW + pp] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const long pp = p0 + i;
+    const int c = c0 + tx;
+    if (c < C && pp < HW) dst[(b * HW + pp) * ldd + c] = tile[tx][i];
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* src, long lds, float* dst, int C, long HW, int accumulate) {
+  __shared__ float tile[32][33];
+  const long b = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  for (int i = ty; i < 32; i += 8) {
+    const long pp = p0 + i;
+    const int c = c0 + tx;
+    tile[i][tx] = (c < C && pp < HW) ? src[(b * HW + pp) * lds + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i;
+    const long pp = p0 + tx;
+    if (c < C && pp < HW) {
+      float* d = dst + (b * C + c) * HW + pp;
+      *d = accumulate ? *d + tile[tx][i] : tile[tx][i];
+    }
+  }
+}
+
+__global__ void add_kernel(float* dst, const float* src, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) dst[e] += src[e];
+}
+__global__ void fill_kernel(float* dst, float v, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) dst[e] = v;
+}
+
+static int moments_plan(long HW, int C, int vec, int* TPR, int* ncb, int* nchunks, long* rows) {
+  const int CV = C / vec;
+  int t = 1;
+  while (t < CV && t < 256) t <<= 1;
+  *TPR = t;
+  *ncb = (int)vr_cdiv(CV, t);
+  long nc = vr_cdiv(HW * C, 8192);
+  if (nc < 1) nc = 1;
+  if (nc > 1024) nc = 1024;
+  if (nc > HW) nc = HW;
+  *rows = vr_cdiv(HW, nc);
+  *nchunks = (int)vr_cdiv(HW, *rows);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" long vrnet_moments_workspace(int B, long HW, int C) {
+  int TPR, ncb, nchunks;
+  long rows;
+  moments_plan(HW, C, 1, &TPR, &ncb, &nchunks, &rows);
+  return (long)B * nchunks * C * 2 * 8 + 256;
+}
+
+extern "C" int vrnet_moments_f32(const float* x, long ldx, const float* x2, long ldx2, const float* mask, long ldm,
+                                 int B, long HW, int C, double* out, void* workspace, long workspace_bytes,
+                                 void* stream) {
+  VR_CHECK_ARG(x && out && workspace, "moments: null tensor");
+  VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && ldx >= C, "moments: bad shape");
+  bool vec = (C % 4 == 0) && (ldx % 4 == 0) && vr_aligned16(x);
+  if (x2) vec = vec && (ldx2 % 4 == 0) && vr_aligned16(x2);
+  if (mask) vec = vec && (ldm % 4 == 0) && vr_aligned16(mask);
+  int TPR, ncb, nchunks;
+  long rows;
+  moments_plan(HW, C, vec ? 4 : 1, &TPR, &ncb, &nchunks, &rows);
+  if (workspace_bytes < vrnet_moments_workspace(B, HW, C)) {
+    vr_set_error("moments: workspace too small");
+    return VR_ERR_WORKSPACE;
+  }
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipStream_t st = vr_stream(stream);
+  dim3 grid(nchunks, B, ncb), block(256);
+  if (vec)
+    hipLaunchKernelGGL((moments_kernel<4>), grid, block, 256 * 8 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
+                       TPR, rows, nchunks, partial);
+  else
+    hipLaunchKernelGGL((moments_kernel<1>), grid, block, 256 * 2 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
+                       TPR, rows, nchunks, partial);
+  VR_LAUNCH_CHECK("moments");
+  const long n = (long)B * C * 2;
+  hipLaunchKernelGGL(moments_reduce_kernel, dim3(vr_cdiv(n, 256)), dim3(256), 0, st, partial, out, B, nchunks, C);
+  VR_LAUNCH_CHECK("moments_reduce");
+  return VR_OK;
+}
+
+extern "C" int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1, int pre,
+                                const float* masky, long ldm, const float* x2, long ld2, const float* E,
+                                const float* D2, long coef_bstride, float* out, long ldo, int B, long HW, int C,
+                                int accumulate, void* stream) {
+  VR_CHECK_ARG(out && B > 0 && HW > 0 && C > 0, "affine: bad arguments");
+  VR_CHECK_ARG(pre != 2 || masky, "affine: mask mode without mask tensor");
+  AffineArgs p{x1, ld1, A, D1, masky, ldm, x2, ld2, E, D2, out, ldo, HW, C, coef_bstride, pre, accumulate};
+  bool vec = (C % 4 == 0) && (ldo % 4 == 0) && vr_aligned16(out) && (coef_bstride % 4 == 0);
+  if (x1) vec = vec && (ld1 % 4 == 0) && vr_aligned16(x1);
+  long blocks = vr_cdiv(HW * (C / (vec ? 4 : 1)), 256 * 4);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  dim3 grid(blocks, B), block(256);
+  if (vec) hipLaunchKernelGGL((affine_kernel<4>), grid, block, 0, vr_stream(stream), p);
+  else hipLaunchKernelGGL((affine_kernel<1>), grid, block, 0, vr_stream(stream), p);
+  VR_LAUNCH_CHECK("affine");
+  return VR_OK;
+}
+
+extern "C" int vrnet_gn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, int B, long HW,
+                                 int C, float* A, float* D, float* mean_rstd, void* stream) {
+  VR_CHECK_ARG(mom && gamma && beta && A && D && mean_rstd, "gn_coef_fwd: null tensor");
+  hipLaunchKernelGGL(gn_coef_fwd_kernel, dim3(B), dim3(256), 0, vr_stream(stream), mom, gamma, beta, eps, HW, C, A, D,
+                     mean_rstd);
+  VR_LAUNCH_CHECK("gn_coef_fwd");
+  return VR_OK;
+}
+
+extern "C" int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int B, long HW, int C,
+                                 float* A, float* E, float* D, float* dgamma, float* dbeta, int accumulate,
+                                 void* stream) {
+  VR_CHECK_ARG(mom2 && mean_rstd && gamma && A && E && D && dgamma && dbeta, "gn_coef_bwd: null tensor");
+  hipLaunchKernelGGL(gn_coef_bwd_kernel, dim3(B + vr_cdiv(C, 256)), dim3(256), 0, vr_stream(stream), mom2, mean_rstd,
+                     gamma, B, HW, C, A, E, D, dgamma, dbeta, accumulate);
+  VR_LAUNCH_CHECK("gn_coef_bwd");
+  return VR_OK;
+}
+
+extern "C" int vrnet_bn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, float momentum,
+                                 float* running_mean, float* running_var, long long* num_batches_tracked,
+                                 int training, int B, long HW, int C, float* A, float* D, float* mean_rstd,
+                                 void* stream) {
+  VR_CHECK_ARG(gamma && beta && running_mean && running_var && A && D && mean_rstd, "bn_coef_fwd: null tensor");
+  VR_CHECK_ARG(!training || mom, "bn_coef_fwd: training mode needs batch moments");
+  VR_CHECK_ARG(!training || (long)B * HW > 1, "Expected more than 1 value per channel when training");
+  hipLaunchKernelGGL(bn_coef_fwd_kernel, dim3(vr_cdiv(C, 128)), dim3(128), 0, vr_stream(stream), mom, gamma, beta, eps,
+                     momentum, running_mean, running_var, num_batches_tracked, training, B, HW, C, A, D, mean_rstd);
+  VR_LAUNCH_CHECK("bn_coef_fwd");
+  return VR_OK;
+}
+
+extern "C" int vrnet_bn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int training, int B,
+                                 long HW, int C, float* A, float* E, float* D, float* dgamma, float* dbeta,
+                                 int accumulate, void* stream) {
+  VR_CHECK_ARG(mom2 && mean_rstd && gamma && A && E && D && dgamma && dbeta, "bn_coef_bwd: null tensor");
+  hipLaunchKernelGGL(bn_coef_bwd_kernel, dim3(vr_cdiv(C, 128)), dim3(128), 0, vr_stream(stream), mom2, mean_rstd, gamma,
+                     training, B, HW, C, A, E, D, dgamma, dbeta, accumulate);
+  VR_LAUNCH_CHECK("bn_coef_bwd");
+  return VR_OK;
+}
+
+extern "C" int vrnet_eca_coef_fwd(const double* mom, const float* wk, int k, int B, long HW, int C, float* gate,
+                                  void* stream) {
+  VR_CHECK_ARG(mom && wk && gate && k >= 1 && (k & 1), "eca_coef_fwd: bad arguments");
+  hipLaunchKernelGGL(eca_coef_fwd_kernel, dim3(vr_cdiv((long)B * C, 256)), dim3(256), 0, vr_stream(stream), mom, wk, k,
+                     B, HW, C, gate);
+  VR_LAUNCH_CHECK("eca_coef_fwd");
+  return VR_OK;
+}
+
+extern "C" int vrnet_eca_coef_bwd(const double* mom2, const double* mom, const float* gate, const float* wk, int k,
+                                  int B, long HW, int C, float* F, float* dwk, int accumulate, void* stream) {
+  VR_CHECK_ARG(mom2 && mom && gate && wk && F && dwk, "eca_coef_bwd: null tensor");
+  hipLaunchKernelGGL(eca_coef_bwd_kernel, dim3(vr_cdiv((long)B * C, 256)), dim3(256), 0, vr_stream(stream), mom2, gate,
+                     wk, k, B, HW, C, F);
+  VR_LAUNCH_CHECK("eca_coef_bwd");
+  hipLaunchKernelGGL(eca_dwk_kernel, dim3(k), dim3(256), 0, vr_stream(stream), mom2, mom, gate, k, B, HW, C, dwk,
+                     accumulate);
+  VR_LAUNCH_CHECK("eca_dwk");
+  return VR_OK;
+}
+
+extern "C" int vrnet_ls_coef_bwd(const double* mom2, const float* ls, int B, int C, float* dls, float* dbias,
+                                 int accumulate, void* stream) {
+  VR_CHECK_ARG(mom2, "ls_coef_bwd: null tensor");
+  hipLaunchKernelGGL(ls_coef_bwd_kernel, dim3(vr_cdiv(C, 128)), dim3(128), 0, vr_stream(stream), mom2, ls, B, C, dls,
+                     dbias, accumulate);
+  VR_LAUNCH_CHECK("ls_coef_bwd");
+  return VR_OK;
+}
+
+extern "C" int vrnet_moments_to_float(const double* mom, float* out, long n, double scale, int which, void* stream) {
+  VR_CHECK_ARG(mom && out && (which == 0 || which == 1), "moments_to_float: bad arguments");
+  hipLaunchKernelGGL(moments_to_float_kernel, dim3(vr_cdiv(n, 256)), dim3(256), 0, vr_stream(stream), mom, out, n, scale,
+                     which);
+  VR_LAUNCH_CHECK("moments_to_float");
+  return VR_OK;
+}
+
+extern "C" int vrnet_copy_channels_f32(const float* src, long lds, int scs, float* dst, long ldd, int dcs, long rows,
+                                       int C, int accumulate, void* stream) {
+  VR_CHECK_ARG(src && dst && rows > 0 && C > 0, "copy_channels: bad arguments");
+  long blocks = vr_cdiv(rows * C, 1024);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(blocks), dim3(256), 0, vr_stream(stream), src, lds, scs, dst, ldd, dcs,
+                     rows, C, accumulate);
+  VR_LAUNCH_CHECK("copy_channels");
+  return VR_OK;
+}
+
+extern "C" int vrnet_nchw_to_nhwc_f32(const float* src, float* dst, long ldd, int B, int C, long HW, void* stream) {
+  VR_CHECK_ARG(src && dst && ldd >= C, "nchw_to_nhwc: bad arguments");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(vr_cdiv(HW, 32), vr_cdiv(C, 32), B), dim3(32, 8), 0, vr_stream(stream),
+                     src, dst, ldd, C, HW);
+  VR_LAUNCH_CHECK("nchw_to_nhwc");
+  return VR_OK;
+}
+
+extern "C" int vrnet_nhwc_to_nchw_f32(const float* src, long lds, float* dst, int B, int C, long HW, int accumulate,
+                                      void* stream) {
+  VR_CHECK_ARG(src && dst && lds >= C, "nhwc_to_nchw: bad arguments");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(vr_cdiv(HW, 32), vr_cdiv(C, 32), B), dim3(32, 8), 0, vr_stream(stream),
+                     src, lds, dst, C, HW, accumulate);
+  VR_LAUNCH_CHECK("nhwc_to_nchw");
+  return VR_OK;
+}
+
+extern "C" int vrnet_add_f32(float* dst, const float* src, long n, void* stream) {
+  VR_CHECK_ARG(dst && src && n >= 0, "add: bad arguments");
+  if (n == 0) return VR_OK;
+  long blocks = vr_cdiv(n, 1024);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(add_kernel, dim3(blocks), dim3(256), 0, vr_stream(stream), dst, src, n);
+  VR_LAUNCH_CHECK("add");
+  return VR_OK;
+}
+
+extern "C" int vrnet_fill_f32(float* dst, float value, long n, void* stream) {
+  VR_CHECK_ARG(dst && n >= 0, "fill: bad arguments");
+  if (n == 0) return VR_OK;
+  long blocks = vr_cdiv(n, 1024);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, vr_stream(stream), dst, value, n);
+  VR_LAUNCH_CHECK("fill");
+  return VR_OK;
+}

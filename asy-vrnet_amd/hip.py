@@ -1,0 +1,276 @@
+"""ctypes binding of the C-ABI in include/vrnet_hip.h (libvrnet_hip.so, gfx950).
+
+PyTorch is used for device memory and streams only: every function below passes raw device
+pointers, sizes and the current HIP stream to the library.  There is no fallback: a missing
+library raises at import of this module, a failing call raises RuntimeError with the
+library's message (mirroring the reference's assert at backbone/fusion/vr_coc.py:163-164).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvrnet_hip.so")
+ABI_VERSION = 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+        "or make -C asy-vrnet_amd/csrc). The hot path has no CPU/eager fallback.")
+_lib = ctypes.CDLL(LIB_PATH)
+
+P, L, I, F, D = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_double
+_SIGS = {
+    "vrnet_abi_version": ([], I),
+    "vrnet_last_error": ([], ctypes.c_char_p),
+    "vrnet_device_arch": ([ctypes.c_char_p, I], I),
+    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P], I),
+    "vrnet_conv2d_wgrad_workspace": ([I] * 7, L),
+    "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 13 + [P, L, P], I),
+    "vrnet_pack_weight_f32": ([P, P, I, I, I, I, P], I),
+    "vrnet_moments_workspace": ([I, L, I], L),
+    "vrnet_moments_f32": ([P, L, P, L, P, L, I, L, I, P, P, L, P], I),
+    "vrnet_affine_f32": ([P, L, P, P, I, P, L, P, L, P, P, L, P, L, I, L, I, I, P], I),
+    "vrnet_gn_coef_fwd": ([P, P, P, F, I, L, I, P, P, P, P], I),
+    "vrnet_gn_coef_bwd": ([P, P, P, I, L, I, P, P, P, P, P, I, P], I),
+    "vrnet_bn_coef_fwd": ([P, P, P, F, F, P, P, P, I, I, L, I, P, P, P, P], I),
+    "vrnet_bn_coef_bwd": ([P, P, P, I, I, L, I, P, P, P, P, P, I, P], I),
+    "vrnet_eca_coef_fwd": ([P, P, I, I, L, I, P, P], I),
+    "vrnet_eca_coef_bwd": ([P, P, P, P, I, I, L, I, P, P, I, P], I),
+    "vrnet_ls_coef_bwd": ([P, P, I, I, P, P, I, P], I),
+    "vrnet_moments_to_float": ([P, P, L, D, I, P], I),
+    "vrnet_copy_channels_f32": ([P, L, I, P, L, I, L, I, I, P], I),
+    "vrnet_nchw_to_nhwc_f32": ([P, P, L, I, I, L, P], I),
+    "vrnet_nhwc_to_nchw_f32": ([P, L, P, I, I, L, I, P], I),
+    "vrnet_add_f32": ([P, P, L, P], I),
+    "vrnet_fill_f32": ([P, F, L, P], I),
+    "vrnet_cluster_fwd_f32": ([P, P, L, P, P, P, L, P, P, I, I, I, I, I, I, P], I),
+    "vrnet_cluster_bwd_workspace": ([I, I, I], L),
+    "vrnet_cluster_bwd_f32": ([P, P, L, P, P, P, P, L, P, P, L, P, P, I, I, I, I, I, I, I, P, L, P], I),
+    "vrnet_dwconv3x3_f32": ([P, L, P, P, L, I, I, I, I, I, I, P], I),
+    "vrnet_dwconv3x3_wgrad_workspace": ([I, I, I, I], L),
+    "vrnet_dwconv3x3_wgrad_f32": ([P, L, P, L, P, I, I, I, I, I, P, L, P], I),
+    "vrnet_upsample_bilinear_f32": ([P, L, P, L, I, I, I, I, I, I, P], I),
+    "vrnet_upsample_bilinear_bwd_f32": ([P, L, I, P, L, I, I, I, I, I, I, P], I),
+    "vrnet_reduce_workspace": ([], L),
+    "vrnet_minmax_f32": ([P, L, P, P, L, P], I),
+    "vrnet_enhance_mul_f32": ([P, P, P, P, L, P], I),
+    "vrnet_enhance_bwd_f32": ([P, P, P, P, P, P, L, I, P, L, P], I),
+    "vrnet_sa_coef_fwd": ([P] * 7 + [I, L, I, I, P, P, P], I),
+    "vrnet_sa_apply_f32": ([P, L, P, P, P, L, I, L, I, P], I),
+    "vrnet_sa_bwd_workspace": ([I, L, I], L),
+    "vrnet_sa_bwd_f32": ([P, L, P, L, P, P, P] + [P] * 6 + [P, L] + [P] * 6 + [P, I, L, I, I, I, I, P, L, P], I),
+}
+for _name, (_args, _res) in _SIGS.items():
+    _fn = getattr(_lib, _name)          # AttributeError here = header/library mismatch
+    _fn.argtypes = _args
+    _fn.restype = _res
+
+if _lib.vrnet_abi_version() != ABI_VERSION:
+    raise ImportError(f"libvrnet_hip.so ABI {_lib.vrnet_abi_version()} != expected {ABI_VERSION}")
+
+EXPORTED = tuple(_SIGS)
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name}: {_lib.vrnet_last_error().decode()}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vrnet HIP path needs tensors on a HIP device (there is no CPU fallback)")
+        if t is not None and t.dtype not in (torch.float32, torch.float64, torch.uint8, torch.int64):
+            raise RuntimeError(f"unsupported dtype {t.dtype}")
+
+
+def empty(*shape, dtype=torch.float32, like=None, device=None):
+    return torch.empty(shape, dtype=dtype, device=device if device is not None else like.device)
+
+
+class Workspace:
+    """Grow-only scratch arena (bytes) per device; the caching allocator keeps it alive."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        b = self.buf.get(device)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[device] = b
+        return b
+
+
+_ws = Workspace()
+
+
+# --------------------------------------------------------------------------------------- wrappers
+def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, mode=0, act=0,
+           ypre=None, ldypre=0, res=None, ldres=0, res_scale=None, kscale=None, aux=None, ldaux=0,
+           out_nchw=0, out_ctot=0, out_coff=0, accumulate=0):
+    _check(_lib.vrnet_conv2d_f32(ptr(a), lda, ptr(w), ptr(bias), ptr(y), ldy, B, H, W, Cin, OH, OW, Cout, kh, kw,
+                                 stride, pad, dil, mode, act, ptr(ypre), ldypre, ptr(res), ldres, ptr(res_scale),
+                                 ptr(kscale), ptr(aux), ldaux, out_nchw, out_ctot, out_coff, accumulate, stream()),
+           "conv2d")
+
+
+def conv2d_wgrad(x, ldx, dy, lddy, dw, dbias, row_scale, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil,
+                 accumulate=0):
+    nbytes = _lib.vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw)
+    ws = _ws.get(nbytes, x.device)
+    _check(_lib.vrnet_conv2d_wgrad_f32(ptr(x), ldx, ptr(dy), lddy, ptr(dw), ptr(dbias), ptr(row_scale), B, H, W, Cin,
+                                       OH, OW, Cout, kh, kw, stride, pad, dil, accumulate, ptr(ws), ws.numel(),
+                                       stream()), "conv2d_wgrad")
+
+
+def pack_weight(w_oihw, out, Cout, Cin, kh, kw):
+    _check(_lib.vrnet_pack_weight_f32(ptr(w_oihw), ptr(out), Cout, Cin, kh, kw, stream()), "pack_weight")
+
+
+def moments(x, ldx, B, HW, C, x2=None, ldx2=0, mask=None, ldm=0, out=None):
+    if out is None:
+        out = torch.empty((B, C, 2), dtype=torch.float64, device=x.device)
+    ws = _ws.get(_lib.vrnet_moments_workspace(B, HW, C), x.device)
+    _check(_lib.vrnet_moments_f32(ptr(x), ldx, ptr(x2), ldx2, ptr(mask), ldm, B, HW, C, ptr(out), ptr(ws), ws.numel(),
+                                  stream()), "moments")
+    return out
+
+
+def affine(out, ldo, B, HW, C, x1=None, ld1=0, A=None, D1=None, pre=0, masky=None, ldm=0, x2=None, ld2=0, E=None,
+           D2=None, bstride=0, accumulate=0):
+    _check(_lib.vrnet_affine_f32(ptr(x1), ld1, ptr(A), ptr(D1), pre, ptr(masky), ldm, ptr(x2), ld2, ptr(E), ptr(D2),
+                                 bstride, ptr(out), ldo, B, HW, C, accumulate, stream()), "affine")
+
+
+def gn_coef_fwd(mom, gamma, beta, eps, B, HW, C, A, Dc, mean_rstd):
+    _check(_lib.vrnet_gn_coef_fwd(ptr(mom), ptr(gamma), ptr(beta), eps, B, HW, C, ptr(A), ptr(Dc), ptr(mean_rstd),
+                                  stream()), "gn_coef_fwd")
+
+
+def gn_coef_bwd(mom2, mean_rstd, gamma, B, HW, C, A, E, Dc, dgamma, dbeta, accumulate):
+    _check(_lib.vrnet_gn_coef_bwd(ptr(mom2), ptr(mean_rstd), ptr(gamma), B, HW, C, ptr(A), ptr(E), ptr(Dc),
+                                  ptr(dgamma), ptr(dbeta), accumulate, stream()), "gn_coef_bwd")
+
+
+def bn_coef_fwd(mom, gamma, beta, eps, momentum, rm, rv, nbt, training, B, HW, C, A, Dc, mean_rstd):
+    _check(_lib.vrnet_bn_coef_fwd(ptr(mom), ptr(gamma), ptr(beta), eps, momentum, ptr(rm), ptr(rv), ptr(nbt),
+                                  int(training), B, HW, C, ptr(A), ptr(Dc), ptr(mean_rstd), stream()), "bn_coef_fwd")
+
+
+def bn_coef_bwd(mom2, mean_rstd, gamma, training, B, HW, C, A, E, Dc, dgamma, dbeta, accumulate):
+    _check(_lib.vrnet_bn_coef_bwd(ptr(mom2), ptr(mean_rstd), ptr(gamma), int(training), B, HW, C, ptr(A), ptr(E),
+                                  ptr(Dc), ptr(dgamma), ptr(dbeta), accumulate, stream()), "bn_coef_bwd")
+
+
+def eca_coef_fwd(mom, wk, k, B, HW, C, gate):
+    _check(_lib.vrnet_eca_coef_fwd(ptr(mom), ptr(wk), k, B, HW, C, ptr(gate), stream()), "eca_coef_fwd")
+
+
+def eca_coef_bwd(mom2, mom, gate, wk, k, B, HW, C, Fc, dwk, accumulate):
+    _check(_lib.vrnet_eca_coef_bwd(ptr(mom2), ptr(mom), ptr(gate), ptr(wk), k, B, HW, C, ptr(Fc), ptr(dwk), accumulate,
+                                   stream()), "eca_coef_bwd")
+
+
+def ls_coef_bwd(mom2, ls, B, C, dls, dbias, accumulate):
+    _check(_lib.vrnet_ls_coef_bwd(ptr(mom2), ptr(ls), B, C, ptr(dls), ptr(dbias), accumulate, stream()), "ls_coef_bwd")
+
+
+def moments_to_float(mom, out, n, scale, which=0):
+    _check(_lib.vrnet_moments_to_float(ptr(mom), ptr(out), n, scale, which, stream()), "moments_to_float")
+
+
+def copy_channels(src, lds, scs, dst, ldd, dcs, rows, C, accumulate=0):
+    _check(_lib.vrnet_copy_channels_f32(ptr(src), lds, scs, ptr(dst), ldd, dcs, rows, C, accumulate, stream()),
+           "copy_channels")
+
+
+def nchw_to_nhwc(src, dst, ldd, B, C, HW):
+    _check(_lib.vrnet_nchw_to_nhwc_f32(ptr(src), ptr(dst), ldd, B, C, HW, stream()), "nchw_to_nhwc")
+
+
+def nhwc_to_nchw(src, lds, dst, B, C, HW, accumulate=0):
+    _check(_lib.vrnet_nhwc_to_nchw_f32(ptr(src), lds, ptr(dst), B, C, HW, accumulate, stream()), "nhwc_to_nchw")
+
+
+def add_(dst, src):
+    _check(_lib.vrnet_add_f32(ptr(dst), ptr(src), dst.numel(), stream()), "add")
+
+
+def fill_(dst, value):
+    _check(_lib.vrnet_fill_f32(ptr(dst), float(value), dst.numel(), stream()), "fill")
+
+
+def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold):
+    _check(_lib.vrnet_cluster_fwd_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(out), ldo, ptr(idx), ptr(wgt), B, H,
+                                      W, E, Dh, fold, stream()), "cluster_fwd")
+
+
+def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, dbeta, accumulate_ab, B, H, W, E, Dh,
+                fold):
+    ws = _ws.get(_lib.vrnet_cluster_bwd_workspace(B, E, fold), f.device)
+    _check(_lib.vrnet_cluster_bwd_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(idx), ptr(dout), lddo, ptr(df),
+                                      ptr(dv), lddf, ptr(dalpha), ptr(dbeta), accumulate_ab, B, H, W, E, Dh, fold,
+                                      ptr(ws), ws.numel(), stream()), "cluster_bwd")
+
+
+def dwconv3x3(x, ldx, w, y, ldy, B, H, W, C, flip=0, accumulate=0):
+    _check(_lib.vrnet_dwconv3x3_f32(ptr(x), ldx, ptr(w), ptr(y), ldy, B, H, W, C, flip, accumulate, stream()),
+           "dwconv3x3")
+
+
+def dwconv3x3_wgrad(x, ldx, dy, lddy, dw, B, H, W, C, accumulate=0):
+    ws = _ws.get(_lib.vrnet_dwconv3x3_wgrad_workspace(B, H, W, C), x.device)
+    _check(_lib.vrnet_dwconv3x3_wgrad_f32(ptr(x), ldx, ptr(dy), lddy, ptr(dw), B, H, W, C, accumulate, ptr(ws),
+                                          ws.numel(), stream()), "dwconv3x3_wgrad")
+
+
+def upsample(x, ldx, y, ldy, B, H, W, C, scale, out_nchw=0):
+    _check(_lib.vrnet_upsample_bilinear_f32(ptr(x), ldx, ptr(y), ldy, B, H, W, C, scale, out_nchw, stream()),
+           "upsample")
+
+
+def upsample_bwd(dy, lddy, dy_nchw, dx, lddx, B, H, W, C, scale, accumulate=0):
+    _check(_lib.vrnet_upsample_bilinear_bwd_f32(ptr(dy), lddy, dy_nchw, ptr(dx), lddx, B, H, W, C, scale, accumulate,
+                                                stream()), "upsample_bwd")
+
+
+def minmax(p, n, mm):
+    ws = _ws.get(_lib.vrnet_reduce_workspace(), p.device)
+    _check(_lib.vrnet_minmax_f32(ptr(p), n, ptr(mm), ptr(ws), ws.numel(), stream()), "minmax")
+
+
+def enhance_mul(p, x, mm, out, n):
+    _check(_lib.vrnet_enhance_mul_f32(ptr(p), ptr(x), ptr(mm), ptr(out), n, stream()), "enhance_mul")
+
+
+def enhance_bwd(dt, x, p, mm, dx, dp, n, accumulate_dx=0):
+    ws = _ws.get(_lib.vrnet_reduce_workspace(), p.device)
+    _check(_lib.vrnet_enhance_bwd_f32(ptr(dt), ptr(x), ptr(p), ptr(mm), ptr(dx), ptr(dp), n, accumulate_dx, ptr(ws),
+                                      ws.numel(), stream()), "enhance_bwd")
+
+
+def sa_coef_fwd(mom, cw, cb, sw, sb, gnw, gnb, B, HW, C, G, Pq, Qq):
+    _check(_lib.vrnet_sa_coef_fwd(ptr(mom), ptr(cw), ptr(cb), ptr(sw), ptr(sb), ptr(gnw), ptr(gnb), B, HW, C, G, ptr(Pq),
+                                  ptr(Qq), stream()), "sa_coef_fwd")
+
+
+def sa_apply(x, ldx, Pq, Qq, y, ldy, B, HW, C):
+    _check(_lib.vrnet_sa_apply_f32(ptr(x), ldx, ptr(Pq), ptr(Qq), ptr(y), ldy, B, HW, C, stream()), "sa_apply")
+
+
+def sa_bwd(dy, lddy, x, ldx, Pq, Qq, mom, params, dx, lddx, grads, EF, B, HW, C, G, accumulate_dx, accumulate_params):
+    ws = _ws.get(_lib.vrnet_sa_bwd_workspace(B, HW, C), x.device)
+    _check(_lib.vrnet_sa_bwd_f32(ptr(dy), lddy, ptr(x), ldx, ptr(Pq), ptr(Qq), ptr(mom), *[ptr(t) for t in params],
+                                 ptr(dx), lddx, *[ptr(t) for t in grads], ptr(EF), B, HW, C, G, accumulate_dx,
+                                 accumulate_params, ptr(ws), ws.numel(), stream()), "sa_bwd")

@@ -1,0 +1,171 @@
+/* vrnet_hip.h -- C ABI of libvrnet_hip.so: MI355X (gfx950) kernels for the ASY-VRNet fusion hot path.
+ *
+ * The drop-in boundary of this repository (DESIGN.md "Boundary").  Plain pointers and sizes only: no
+ * torch types.  Every pointer is a DEVICE pointer unless stated; every function enqueues work on the HIP
+ * stream `stream` (a hipStream_t passed as void*) and returns without synchronising:
+ *   0 = ok, 1 = bad argument, 2 = launch failure, 3 = workspace too small; the message of the last
+ *   failure on the calling thread is returned by vrnet_last_error().
+ * Tensors are fp32, NHWC, addressed as rows of pixels: element (pixel r, channel c) of tensor t lives at
+ * t[r * ld + c]; `ld` (row stride in floats) >= channel count lets a tensor be a channel slice of a wider
+ * buffer (torch.cat is never materialised by a copy of the producer's output).  `accumulate` != 0 makes an
+ * output `+=` instead of `=` (gradient fan-in).
+ *
+ * Each entry point names the reference code (GuanRunwei/ASY-VRNet, file:line) it replaces; the reference
+ * is pure PyTorch, so "replaces" means the ATen op sequence the reference module executes there.
+ * The reference-side binding a maintainer would add is a ctypes stub: see INTEGRATION.md.
+ */
+#ifndef VRNET_HIP_H
+#define VRNET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ------------------------------------------------------------------------------------- */
+int vrnet_abi_version(void);                 /* == 1 */
+const char* vrnet_last_error(void);          /* host string, thread local */
+int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sramecc+:xnack-" (synchronous) */
+
+/* ---- dense convolution as implicit GEMM on the fp32 MFMA ------------------------------------------
+ * Replaces nn.Conv2d forward / input-gradient for every dense conv of the path:
+ *   Cluster fc1, fc_v, fc2 (backbone/fusion/vr_coc.py:145-147,156-157,191), Mlp fc1/fc2 (:205-207,217-223),
+ *   PointRecuder.proj k1 / k4s4 / k3s2p1 (:83-102), BaseConv.conv (backbone/conv_utils/normal_conv.py:41,48),
+ *   ASPP 1x1 + dilated 3x3 (neck/coc_fpn_dual.py:50-77), head stems / pconv / preds (head/decouplehead.py:21-40).
+ * Geometry is always the FORWARD convolution's: input (B,H,W,Cin), output (B,OH,OW,Cout), kernel kh x kw.
+ * w: weights packed [kh*kw][Cout][Cin] (vrnet_pack_weight_f32; for 1x1 this IS the OIHW tensor).
+ * mode 0: y(B,OH,OW,Cout) = conv(a = x).   mode 1: y(B,H,W,Cin) = d/dx given a = dy(B,OH,OW,Cout).
+ * Fused epilogue, in this order (each optional, NULL/0 = off):
+ *   v = acc + bias[n];  v *= gelu'(aux[m,n]) (Mlp backward);  ypre[m,n] = v (pre-activation / branch output);
+ *   act: 1 ReLU, 2 exact-erf GELU;  v = res[m,n] + res_scale[n] * v (layer-scale residual, vr_coc.py:266-271);
+ *   store NHWC y[m*ldy+n] or NCHW y[b][out_coff+n][pix] of a (B,out_ctot,OH,OW) tensor (head cat, decouplehead.py:86).
+ * kscale[k]: multiplies the contraction channels of `a` (layer scale folded into the data gradient). */
+int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias, float* y, long ldy,
+                     int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride, int pad,
+                     int dil, int mode, int act, float* ypre, long ldypre, const float* res, long ldres,
+                     const float* res_scale, const float* kscale, const float* aux, long ldaux, int out_nchw,
+                     int out_ctot, int out_coff, int accumulate, void* stream);
+
+/* Weight (+ bias) gradient of the same convolutions (autograd of nn.Conv2d): dw in OIHW layout
+ * [Cout][Cin][kh][kw], dbias[Cout] (NULL = none), both scaled by row_scale[Cout] when given (layer scale).
+ * Deterministic split over output pixels into fp32 slabs in `workspace` (size from ..._workspace). */
+long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int Cout, int kh, int kw);
+int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, float* dbias,
+                           const float* row_scale, int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh,
+                           int kw, int stride, int pad, int dil, int accumulate, void* workspace,
+                           long workspace_bytes, void* stream);
+int vrnet_pack_weight_f32(const float* w_oihw, float* w_tnc, int Cout, int Cin, int kh, int kw, void* stream);
+
+/* ---- per-(sample, channel) moments in fp64 ---------------------------------------------------------
+ * out[b][c] = { sum_p x, sum_p x*x }                    (x2 == NULL)
+ *           = { sum_p xm, sum_p xm*x2 }, xm = mask>0 ? x : 0   (x2 given; mask optional)
+ * Feeds GroupNorm(1,C) (vr_coc.py:105-111), train-mode BatchNorm2d (normal_conv.py:45; vr_coc.py:310,329),
+ * ShuffleAttention's avg-pool / per-channel GroupNorm (shuffle_attention.py:57,62), ECA's avg-pool (eca.py:17),
+ * ASPP's global mean (coc_fpn_dual.py:91-92) and the layer-scale / bias / norm-parameter gradients. */
+long vrnet_moments_workspace(int B, long HW, int C);
+int vrnet_moments_f32(const float* x, long ldx, const float* x2, long ldx2, const float* mask, long ldm, int B,
+                      long HW, int C, double* out, void* workspace, long workspace_bytes, void* stream);
+
+/* out = pre(A*x1 + D1) + E*x2 + D2; pre: 0 none, 1 ReLU, 2 keep where masky > 0.  Coefficients are indexed
+ * [b*coef_bstride + c] (0 = per channel, C = per sample and channel); NULL A/E = 1, NULL D1/D2 = 0,
+ * NULL x1/x2 = term absent.  The apply step of GroupNorm / BatchNorm(+ReLU, + residual) forward AND backward,
+ * ECA gating (eca.py:22), global-feature broadcast (coc_fpn_dual.py:96). */
+int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1, int pre, const float* masky,
+                     long ldm, const float* x2, long ld2, const float* E, const float* D2, long coef_bstride,
+                     float* out, long ldo, int B, long HW, int C, int accumulate, void* stream);
+
+/* Coefficient kernels: moments -> affine coefficients, saved statistics, parameter gradients. */
+/* GroupNorm(1,C), eps 1e-5 (vr_coc.py:105-111): A,D [B][C]; mean_rstd [B][2]. */
+int vrnet_gn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, int B, long HW, int C,
+                      float* A, float* D, float* mean_rstd, void* stream);
+/* mom2 = moments(dy, x2 = x): dx = A*dy + E*x + D with A,E,D [B][C]; dgamma, dbeta [C]. */
+int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int B, long HW, int C,
+                      float* A, float* E, float* D, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* nn.BatchNorm2d: batch statistics + running-stat update (unbiased var, momentum) + num_batches_tracked += 1
+ * when training, running statistics otherwise.  A,D [C]; mean_rstd [C][2]. */
+int vrnet_bn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, long long* num_batches_tracked, int training, int B,
+                      long HW, int C, float* A, float* D, float* mean_rstd, void* stream);
+/* mom2 = moments(dy, x2 = z, mask = relu output): dz = A*dy' + E*z + D with A,E,D [C]. */
+int vrnet_bn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int training, int B, long HW,
+                      int C, float* A, float* E, float* D, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* eca_block (backbone/attention_modules/eca.py:16-22): gate[b][c] = sigmoid(conv1d_k(mean_hw x)). */
+int vrnet_eca_coef_fwd(const double* mom, const float* wk, int k, int B, long HW, int C, float* gate, void* stream);
+/* mom2 = moments(dy, x2 = x): dx = gate*dy + F[b][c]; dwk [k]. */
+int vrnet_eca_coef_bwd(const double* mom2, const double* mom, const float* gate, const float* wk, int k, int B,
+                       long HW, int C, float* F, float* dwk, int accumulate, void* stream);
+/* Layer scale x + ls*o (vr_coc.py:266-271), mom2 = moments(dx, x2 = o): dls[c] = sum dx*o; dbias = ls * sum dx. */
+int vrnet_ls_coef_bwd(const double* mom2, const float* ls, int B, int C, float* dls, float* dbias, int accumulate,
+                      void* stream);
+int vrnet_moments_to_float(const double* mom, float* out, long n, double scale, int which, void* stream);
+
+/* ---- layout ---------------------------------------------------------------------------------------- */
+/* dst[r*ldd + c*dcs] (+)= src[r*lds + c*scs]: torch.cat + shuffle_channels(groups=2) (vr_coc.py:70-80,
+ * coc_fpn_dual.py:120-130) written straight into the consumer's buffer, and their adjoints. */
+int vrnet_copy_channels_f32(const float* src, long lds, int scs, float* dst, long ldd, int dcs, long rows, int C,
+                            int accumulate, void* stream);
+int vrnet_nchw_to_nhwc_f32(const float* src, float* dst, long ldd, int B, int C, long HW, void* stream);
+int vrnet_nhwc_to_nchw_f32(const float* src, long lds, float* dst, int B, int C, long HW, int accumulate, void* stream);
+int vrnet_add_f32(float* dst, const float* src, long n, void* stream);
+int vrnet_fill_f32(float* dst, float value, long n, void* stream);
+
+/* ---- Context-Cluster core ---------------------------------------------------------------------------
+ * Replaces Cluster.forward between fc1/fc_v and fc2 (vr_coc.py:158-190; pairwise_cos_sim :114-125) and its
+ * autograd.  f, v, out: (B,H,W,E*D) NHWC; head e owns channels [e*D,(e+1)*D); regions are the fold x fold
+ * tiles of the map (fold = 1: the whole map), at most 1024 points per region, D % 4 == 0, D <= 32.
+ * idx: (B,H,W,E) u8 hard assignment (first maximum, as torch.max(dim)); wgt: (B,H,W,E) similarity of the
+ * assigned centre (optional).  alpha, beta: device scalars (sim_alpha, sim_beta, :148-149). */
+int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
+                          float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E, int D,
+                          int fold, void* stream);
+long vrnet_cluster_bwd_workspace(int B, int E, int fold);
+/* Recomputes the forward from f, v with the saved assignment idx; df, dv share row stride lddf. */
+int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
+                          const unsigned char* idx, const float* dout, long lddo, float* df, float* dv, long lddf,
+                          float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W, int E, int D,
+                          int fold, void* workspace, long workspace_bytes, void* stream);
+
+/* ---- depthwise 3x3, stride 1, pad 1 (DWConv.dconv, normal_conv.py:26-27; head towers decouplehead.py:23-34)
+ * w: [C][3][3] (the OIHW tensor of a groups=C conv).  flip = 1 gives the input gradient. */
+int vrnet_dwconv3x3_f32(const float* x, long ldx, const float* w, float* y, long ldy, int B, int H, int W, int C,
+                        int flip, int accumulate, void* stream);
+long vrnet_dwconv3x3_wgrad_workspace(int B, int H, int W, int C);
+int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, int B, int H, int W,
+                              int C, int accumulate, void* workspace, long workspace_bytes, void* stream);
+
+/* ---- nn.Upsample(scale, 'bilinear', align_corners=True) (coc_fpn_dual.py:21) and its adjoint (gather form).
+ * out_nchw / dy_nchw: the high-resolution side is a contiguous (B,C,OH,OW) tensor (the seg logits). */
+int vrnet_upsample_bilinear_f32(const float* x, long ldx, float* y, long ldy, int B, int H, int W, int C, int scale,
+                                int out_nchw, void* stream);
+int vrnet_upsample_bilinear_bwd_f32(const float* dy, long lddy, int dy_nchw, float* dx, long lddx, int B, int H, int W,
+                                    int C, int scale, int accumulate, void* stream);
+
+/* ---- ImageEnhanceByRadar gain (vr_coc.py:312-316) with data_normal (:59-67): batch-global min/max of the
+ * ReLU'd radar projection p (contiguous, n elements), out = (1 + (p-min)/(max-min)) * x, and the backward
+ * including the gradient through min and max (ties share it evenly, as torch's min()/max() backward). */
+long vrnet_reduce_workspace(void);
+int vrnet_minmax_f32(const float* p, long n, float* mm /* [2] */, void* workspace, long workspace_bytes, void* stream);
+int vrnet_enhance_mul_f32(const float* p, const float* x, const float* mm, float* out, long n, void* stream);
+int vrnet_enhance_bwd_f32(const float* dt, const float* x, const float* p, const float* mm, float* dx, float* dp,
+                          long n, int accumulate_dx, void* workspace, long workspace_bytes, void* stream);
+
+/* ---- ShuffleAttention (backbone/attention_modules/shuffle_attention.py:48-72) ---------------------------
+ * mom = moments(x).  y[dst(q)] = x[q] * sigmoid(P[b][q]*x[q] + Q[b][q]); dst() is the final 2-group channel
+ * shuffle; the G-group split and the channel/spatial halves are index arithmetic on q.
+ * Parameters: cweight, cbias, sweight, sbias, gn.weight, gn.bias, each [C/(2G)]. */
+int vrnet_sa_coef_fwd(const double* mom, const float* cw, const float* cb, const float* sw, const float* sb,
+                      const float* gnw, const float* gnb, int B, long HW, int C, int G, float* P, float* Q,
+                      void* stream);
+int vrnet_sa_apply_f32(const float* x, long ldx, const float* P, const float* Q, float* y, long ldy, int B, long HW,
+                       int C, void* stream);
+long vrnet_sa_bwd_workspace(int B, long HW, int C);
+int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long ldx, const float* P, const float* Q,
+                     const double* mom, const float* cw, const float* cb, const float* sw, const float* sb,
+                     const float* gnw, const float* gnb, float* dx, long lddx, float* dcw, float* dcb, float* dsw,
+                     float* dsb, float* dgnw, float* dgnb, float* EF /* [2][B][C] scratch */, int B, long HW, int C,
+                     int G, int accumulate_dx, int accumulate_params, void* workspace, long workspace_bytes,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRNET_HIP_H */

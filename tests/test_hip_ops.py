@@ -1,0 +1,432 @@
+"""Kernel-level parity: every C-ABI entry point of libvrnet_hip.so against the CPU oracle
+(oracle/vrnet_oracle.py) or the ATen op the reference executes at that point, on identical
+seeded inputs.  fp32 tolerance 1e-4 relative to the tensor's max (north star: 1e-3)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import asy_vrnet_amd.hip as h
+    return h
+
+
+def rnd(*shape, seed=0, kind="normal"):
+    rng = np.random.default_rng([seed, len(shape)] + list(shape))
+    a = rng.standard_normal(shape, dtype=np.float32) if kind == "normal" else rng.random(shape, dtype=np.float32)
+    return torch.from_numpy(a)
+
+
+def nhwc(x):            # NCHW cpu -> NHWC gpu
+    return x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(y):            # NHWC gpu -> NCHW cpu
+    return y.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def close(a, b, tol=TOL, what=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item() / scale
+    assert err < tol, f"{what}: rel err {err:.3e} (scale {scale:.3e})"
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, s, p, d
+    (2, 12, 10, 64, 128, 1, 1, 0, 1),
+    (1, 7, 9, 32, 9, 1, 1, 0, 1),
+    (2, 8, 8, 80, 80, 1, 1, 0, 1),
+    (2, 8, 8, 320, 48, 1, 1, 0, 1),
+    (2, 20, 20, 4, 3, 3, 1, 1, 1),
+    (2, 16, 16, 16, 32, 3, 2, 1, 1),
+    (2, 32, 32, 5, 16, 4, 4, 0, 1),
+    (2, 16, 16, 32, 32, 3, 1, 6, 6),
+    (1, 16, 16, 24, 40, 3, 1, 18, 18),
+    (2, 9, 9, 7, 4, 1, 1, 0, 1),
+    (3, 1, 1, 32, 32, 1, 1, 0, 1),
+]
+
+
+def pack(hip, w):
+    co, ci, kh, kw = w.shape
+    if kh * kw == 1:
+        return w.contiguous().cuda()
+    out = torch.empty(kh * kw, co, ci, device="cuda")
+    hip.pack_weight(w.contiguous().cuda(), out, co, ci, kh, kw)
+    return out
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_dgrad_wgrad(hip, case):
+    B, H, W, Ci, Co, k, s, p, d = case
+    x = rnd(B, Ci, H, W, seed=1).requires_grad_(True)
+    w = (rnd(Co, Ci, k, k, seed=2) / np.sqrt(Ci * k * k)).requires_grad_(True)
+    b = rnd(Co, seed=3).requires_grad_(True)
+    y = F.conv2d(x, w, b, s, p, d)
+    OH, OW = y.shape[2:]
+    g = rnd(*y.shape, seed=4)
+    y.backward(g)
+    xg, wp, bg = nhwc(x), pack(hip, w.detach()), b.detach().cuda()
+    yg = torch.empty(B, OH, OW, Co, device="cuda")
+    hip.conv2d(xg, Ci, wp, bg, yg, Co, B, H, W, Ci, OH, OW, Co, k, k, s, p, d)
+    close(nchw(yg), y, what="fwd")
+    gg = nhwc(g)
+    dx = torch.empty(B, H, W, Ci, device="cuda")
+    hip.conv2d(gg, Co, wp, None, dx, Ci, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, mode=1)
+    close(nchw(dx), x.grad, what="dgrad")
+    dw = torch.empty(Co, Ci, k, k, device="cuda")
+    db = torch.empty(Co, device="cuda")
+    hip.conv2d_wgrad(xg, Ci, gg, Co, dw, db, None, B, H, W, Ci, OH, OW, Co, k, k, s, p, d)
+    close(dw, w.grad, what="wgrad")
+    close(db, b.grad, what="bgrad")
+    # accumulate + row scale
+    rs = rnd(Co, seed=5).cuda()
+    hip.conv2d_wgrad(xg, Ci, gg, Co, dw, db, rs, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, accumulate=1)
+    close(dw, w.grad * (1 + rs.cpu()[:, None, None, None]), what="wgrad acc")
+    close(db, b.grad * (1 + rs.cpu()), what="bgrad acc")
+
+
+def test_conv_epilogues(hip):
+    B, H, W, Ci, Co = 2, 9, 11, 48, 96
+    x, w, b = rnd(B, Ci, H, W, seed=1), rnd(Co, Ci, 1, 1, seed=2) / 7, rnd(Co, seed=3)
+    res, ls = rnd(B, Co, H, W, seed=4), rnd(Co, seed=5)
+    z = F.conv2d(x, w, b)
+    xg, wg, bg = nhwc(x), w.cuda(), b.cuda()
+    # GELU with pre-activation copy
+    y, ypre = torch.empty(B, H, W, Co, device="cuda"), torch.empty(B, H, W, Co, device="cuda")
+    hip.conv2d(xg, Ci, wg, bg, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, act=2, ypre=ypre, ldypre=Co)
+    close(nchw(ypre), z, what="ypre")
+    close(nchw(y), F.gelu(z), what="gelu")
+    # ReLU
+    hip.conv2d(xg, Ci, wg, bg, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, act=1)
+    close(nchw(y), torch.relu(z), what="relu")
+    # layer-scale residual into a channel slice of a wider buffer
+    wide = torch.zeros(B, H, W, Co + 32, device="cuda")
+    hip.conv2d(xg, Ci, wg, bg, wide[..., 16:], Co + 32, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1,
+               res=nhwc(res), ldres=Co, res_scale=ls.cuda())
+    close(nchw(wide[..., 16:16 + Co]), res + ls[None, :, None, None] * z, what="residual")
+    assert wide[..., :16].abs().max().item() == 0 and wide[..., 16 + Co:].abs().max().item() == 0
+    # NCHW store into a channel range + accumulate
+    out = torch.ones(B, Co + 5, H, W, device="cuda")
+    hip.conv2d(xg, Ci, wg, bg, out, 0, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, out_nchw=1, out_ctot=Co + 5, out_coff=5,
+               accumulate=1)
+    close(out[:, 5:].cpu(), z + 1, what="nchw")
+    assert (out[:, :5] == 1).all()
+    # dgrad with contraction scale and GELU' epilogue
+    g, aux = rnd(B, Co, H, W, seed=6), rnd(B, Ci, H, W, seed=7)
+    ks = rnd(Co, seed=8)
+    dx = torch.empty(B, H, W, Ci, device="cuda")
+    hip.conv2d(nhwc(g), Co, wg, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, kscale=ks.cuda(),
+               aux=nhwc(aux), ldaux=Ci)
+    a = aux.clone().requires_grad_(True)
+    F.gelu(a).sum().backward()
+    ref = F.conv_transpose2d(g * ks[None, :, None, None], w) * a.grad
+    close(nchw(dx), ref, what="dgrad kscale+gelu'")
+
+
+def test_moments_and_affine(hip):
+    B, H, W, C = 3, 13, 7, 20
+    x, x2, m = rnd(B, C, H, W, seed=1) + 3.0, rnd(B, C, H, W, seed=2), rnd(B, C, H, W, seed=3)
+    xg, x2g, mg = nhwc(x), nhwc(x2), nhwc(m)
+    mom = hip.moments(xg, C, B, H * W, C)
+    close(mom[..., 0], x.double().sum(dim=(2, 3)), 1e-6, "sum")
+    close(mom[..., 1], (x.double() ** 2).sum(dim=(2, 3)), 1e-6, "sumsq")
+    mom2 = hip.moments(xg, C, B, H * W, C, x2=x2g, ldx2=C, mask=mg, ldm=C)
+    xm = torch.where(m > 0, x, torch.zeros_like(x)).double()
+    close(mom2[..., 0], xm.sum(dim=(2, 3)), 1e-6, "masked sum")
+    close(mom2[..., 1], (xm * x2.double()).sum(dim=(2, 3)), 1e-6, "masked dot")
+    for C2 in (3, 7):       # scalar path
+        y = rnd(B, C2, H, W, seed=4)
+        mo = hip.moments(nhwc(y), C2, B, H * W, C2)
+        close(mo[..., 0], y.double().sum(dim=(2, 3)), 1e-6, "sum scalar")
+    A, D1, E, D2 = rnd(B, C, seed=5), rnd(B, C, seed=6), rnd(B, C, seed=7), rnd(B, C, seed=8)
+    out = torch.empty(B, H, W, C, device="cuda")
+    bc = lambda t: t[:, :, None, None]
+    for pre in (0, 1, 2):
+        hip.affine(out, C, B, H * W, C, x1=xg, ld1=C, A=A.cuda(), D1=D1.cuda(), pre=pre, masky=mg, ldm=C, x2=x2g, ld2=C,
+                   E=E.cuda(), D2=D2.cuda(), bstride=C)
+        v = bc(A) * x + bc(D1)
+        v = torch.relu(v) if pre == 1 else (torch.where(m > 0, v, torch.zeros_like(v)) if pre == 2 else v)
+        close(nchw(out), v + bc(E) * x2 + bc(D2), what=f"affine pre={pre}")
+    hip.affine(out, C, B, H * W, C, x1=xg, ld1=C, A=A[0].contiguous().cuda(), bstride=0, accumulate=1)
+    close(nchw(out), v + bc(E) * x2 + bc(D2) + A[0][None, :, None, None] * x, what="affine per-channel acc")
+    hip.affine(out, C, B, H * W, C, D2=D2.cuda(), bstride=C)
+    close(nchw(out), bc(D2).expand(B, C, H, W), what="broadcast")
+
+
+def test_group_norm_chain(hip):
+    B, H, W, C = 2, 16, 16, 48
+    x = (rnd(B, C, H, W, seed=1) * 2 + 1).requires_grad_(True)
+    gam, bet = (rnd(C, seed=2) * 0.3 + 1).requires_grad_(True), rnd(C, seed=3).requires_grad_(True)
+    y = F.group_norm(x, 1, gam, bet, 1e-5)
+    g = rnd(B, C, H, W, seed=4)
+    y.backward(g)
+    xg, gg = nhwc(x), nhwc(g)
+    A, D, ms = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda"), torch.empty(B, 2, device="cuda")
+    hip.gn_coef_fwd(hip.moments(xg, C, B, H * W, C), gam.detach().cuda(), bet.detach().cuda(), 1e-5, B, H * W, C, A, D, ms)
+    out = torch.empty(B, H, W, C, device="cuda")
+    hip.affine(out, C, B, H * W, C, x1=xg, ld1=C, A=A, D2=D, bstride=C)
+    close(nchw(out), y, what="gn fwd")
+    mom2 = hip.moments(gg, C, B, H * W, C, x2=xg, ldx2=C)
+    A2, E2, D2 = (torch.empty(B, C, device="cuda") for _ in range(3))
+    dgam, dbet = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    hip.gn_coef_bwd(mom2, ms, gam.detach().cuda(), B, H * W, C, A2, E2, D2, dgam, dbet, 0)
+    dx = torch.empty(B, H, W, C, device="cuda")
+    hip.affine(dx, C, B, H * W, C, x1=gg, ld1=C, A=A2, x2=xg, ld2=C, E=E2, D2=D2, bstride=C)
+    close(nchw(dx), x.grad, what="gn dx")
+    close(dgam, gam.grad, what="gn dgamma")
+    close(dbet, bet.grad, what="gn dbeta")
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_batch_norm_relu_chain(hip, training):
+    B, H, W, C = 3, 10, 12, 24
+    z = (rnd(B, C, H, W, seed=1) * 1.5 + 0.5).requires_grad_(True)
+    gam, bet = (rnd(C, seed=2) * 0.3 + 1).requires_grad_(True), (rnd(C, seed=3) * 0.5).requires_grad_(True)
+    rm, rv = rnd(C, seed=4) * 0.1, rnd(C, seed=5, kind="uniform") + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    y = torch.relu(F.batch_norm(z, rm, rv, gam, bet, training, 0.03, 1e-3))
+    g = rnd(B, C, H, W, seed=6)
+    y.backward(g)
+    zg, gg = nhwc(z), nhwc(g)
+    rmg, rvg, nbt = rm0.cuda(), rv0.cuda(), torch.zeros((), dtype=torch.int64, device="cuda")
+    A, D, ms = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, 2, device="cuda")
+    mom = hip.moments(zg, C, B, H * W, C) if training else None
+    hip.bn_coef_fwd(mom, gam.detach().cuda(), bet.detach().cuda(), 1e-3, 0.03, rmg, rvg, nbt, training, B, H * W, C, A, D, ms)
+    out = torch.empty(B, H, W, C, device="cuda")
+    hip.affine(out, C, B, H * W, C, x1=zg, ld1=C, A=A, D1=D, pre=1)
+    close(nchw(out), y, what="bn+relu fwd")
+    close(rmg, rm, what="running_mean")
+    close(rvg, rv, what="running_var")
+    assert int(nbt.item()) == (1 if training else 0)
+    mom2 = hip.moments(gg, C, B, H * W, C, x2=zg, ldx2=C, mask=out, ldm=C)
+    A2, E2, D2 = (torch.empty(C, device="cuda") for _ in range(3))
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    hip.bn_coef_bwd(mom2, ms, gam.detach().cuda(), training, B, H * W, C, A2, E2, D2, dgam, dbet, 0)
+    dz = torch.empty(B, H, W, C, device="cuda")
+    hip.affine(dz, C, B, H * W, C, x1=gg, ld1=C, A=A2, pre=2, masky=out, ldm=C, x2=zg, ld2=C, E=E2, D2=D2)
+    close(nchw(dz), z.grad, what="bn dz")
+    close(dgam, gam.grad, what="bn dgamma")
+    close(dbet, bet.grad, what="bn dbeta")
+
+
+CLUSTER_CASES = [
+    # B, E, D, H, W, fold
+    (2, 4, 32, 32, 32, 2),     # N = 256 (every backbone stage at 512 px)
+    (2, 4, 24, 16, 16, 2),     # N = 64, neck head_dim
+    (1, 4, 24, 64, 64, 2),     # N = 1024 (neck p3 at 512 px)
+    (2, 8, 32, 16, 16, 1),     # fold 1 (stage 3)
+    (1, 2, 32, 10, 14, 2),     # odd 5x7 regions: overlapping pooling windows
+    (2, 4, 32, 4, 4, 2),       # N = 4
+    (2, 4, 24, 2, 2, 2),       # N = 1: all four centres coincide -> ties -> index 0
+    (1, 4, 32, 128, 128, 8),   # fold 8 (stage 0)
+]
+
+
+@pytest.mark.parametrize("case", CLUSTER_CASES)
+def test_cluster_core(hip, case):
+    from oracle import vrnet_oracle as O
+    B, E, D, H, W, fold = case
+    f = rnd(B, E * D, H, W, seed=1).requires_grad_(True)
+    v = rnd(B, E * D, H, W, seed=2).requires_grad_(True)
+    alpha, beta = torch.tensor([1.3], requires_grad=True), torch.tensor([-0.2], requires_grad=True)
+    fg, vg = nhwc(f), nhwc(v)
+    out = torch.empty(B, H, W, E * D, device="cuda")
+    idx = torch.empty(B, H, W, E, dtype=torch.uint8, device="cuda")
+    wgt = torch.empty(B, H, W, E, device="cuda")
+    hip.cluster_fwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), out, E * D, idx, wgt, B, H, W, E, D, fold)
+    idx_cpu = idx.permute(0, 3, 1, 2).contiguous().cpu().long()
+    rep = {}
+    ref, ref_idx = O.cluster_core(f, v, alpha, beta, E, fold, forced_idx=idx_cpu, report=rep)
+    # every disagreement with the oracle's own argmax must be a numerical near-tie
+    assert rep["mismatch"] <= max(2, rep["points"] // 5000), rep
+    assert rep["max_gap"] < 1e-5, rep
+    close(nchw(out), ref, what="cluster fwd")
+    g = rnd(B, E * D, H, W, seed=3)
+    ref.backward(g)
+    df, dv = torch.empty_like(fg), torch.empty_like(vg)
+    dab = torch.zeros(2, device="cuda")
+    hip.cluster_bwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), idx, nhwc(g), E * D, df, dv, E * D,
+                    dab[0:1], dab[1:2], 0, B, H, W, E, D, fold)
+    close(nchw(dv), v.grad, what="cluster dv")
+    close(nchw(df), f.grad, 5e-4, what="cluster df")
+    close(dab[0:1], alpha.grad, 5e-4, what="dalpha")
+    close(dab[1:2], beta.grad, 5e-4, what="dbeta")
+    # bitwise reproducible
+    out2 = torch.empty_like(out)
+    hip.cluster_fwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), out2, E * D, idx, wgt, B, H, W, E, D, fold)
+    assert torch.equal(out, out2)
+
+
+def test_cluster_rejects_bad_shapes(hip):
+    f = torch.zeros(1, 6, 6, 32, device="cuda")
+    o = torch.empty_like(f)
+    idx = torch.empty(1, 6, 6, 1, dtype=torch.uint8, device="cuda")
+    ab = torch.ones(1, device="cuda")
+    with pytest.raises(RuntimeError, match="divided by fold"):
+        hip.cluster_fwd(f, f, 32, ab, ab, o, 32, idx, None, 1, 6, 6, 1, 32, 4)
+
+
+def test_depthwise(hip):
+    B, H, W, C = 2, 9, 8, 64
+    x = rnd(B, C, H, W, seed=1).requires_grad_(True)
+    w = rnd(C, 1, 3, 3, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, None, 1, 1, 1, C)
+    g = rnd(B, C, H, W, seed=3)
+    y.backward(g)
+    xg, gg, wg = nhwc(x), nhwc(g), w.detach().cuda()
+    out = torch.empty(B, H, W, C, device="cuda")
+    hip.dwconv3x3(xg, C, wg, out, C, B, H, W, C)
+    close(nchw(out), y, what="dw fwd")
+    hip.dwconv3x3(gg, C, wg, out, C, B, H, W, C, flip=1)
+    close(nchw(out), x.grad, what="dw dgrad")
+    dw = torch.empty(C, 1, 3, 3, device="cuda")
+    hip.dwconv3x3_wgrad(xg, C, gg, C, dw, B, H, W, C)
+    close(dw, w.grad, what="dw wgrad")
+
+
+@pytest.mark.parametrize("scale,nchw_out", [(2, 0), (4, 0), (4, 1), (2, 1)])
+def test_upsample(hip, scale, nchw_out):
+    B, H, W, C = 2, 6, 5, 9
+    x = rnd(B, C, H, W, seed=1).requires_grad_(True)
+    y = F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=True)
+    g = rnd(*y.shape, seed=2)
+    y.backward(g)
+    xg = nhwc(x)
+    OH, OW = H * scale, W * scale
+    if nchw_out:
+        out = torch.empty(B, C, OH, OW, device="cuda")
+        hip.upsample(xg, C, out, 0, B, H, W, C, scale, out_nchw=1)
+        close(out.cpu(), y, what="up fwd nchw")
+        gg = g.cuda()
+    else:
+        out = torch.empty(B, OH, OW, C, device="cuda")
+        hip.upsample(xg, C, out, C, B, H, W, C, scale)
+        close(nchw(out), y, what="up fwd")
+        gg = nhwc(g)
+    dx = torch.empty(B, H, W, C, device="cuda")
+    hip.upsample_bwd(gg, C, nchw_out, dx, C, B, H, W, C, scale)
+    close(nchw(dx), x.grad, what="up bwd")
+
+
+def test_image_gain(hip):
+    B, H, W, C = 2, 8, 8, 16
+    p = torch.relu(rnd(B, C, H, W, seed=1)).requires_grad_(True)
+    x = rnd(B, C, H, W, seed=2).requires_grad_(True)
+    out = (1 + (p - p.min()) / (p.max() - p.min())) * x
+    g = rnd(B, C, H, W, seed=3)
+    out.backward(g)
+    pg, xg, gg = nhwc(p), nhwc(x), nhwc(g)
+    mm = torch.empty(2, device="cuda")
+    hip.minmax(pg, pg.numel(), mm)
+    assert mm[0].item() == p.min().item() and mm[1].item() == p.max().item()
+    o = torch.empty_like(xg)
+    hip.enhance_mul(pg, xg, mm, o, o.numel())
+    close(nchw(o), out, what="gain fwd")
+    dx, dp = torch.empty_like(xg), torch.empty_like(xg)
+    hip.enhance_bwd(gg, xg, pg, mm, dx, dp, dx.numel())
+    close(nchw(dx), x.grad, what="gain dx")
+    close(nchw(dp), p.grad, what="gain dp")
+
+
+@pytest.mark.parametrize("C,G", [(64, 8), (32, 4), (16, 8)])
+def test_shuffle_attention(hip, C, G):
+    from oracle import vrnet_oracle as O
+    B, H, W = 2, 7, 9
+    cp = C // (2 * G)
+    x = (rnd(B, C, H, W, seed=1) + 0.3).requires_grad_(True)
+    names = ["cweight", "cbias", "sweight", "sbias"]
+    P = {"m." + n: rnd(1, cp, 1, 1, seed=10 + i).requires_grad_(True) for i, n in enumerate(names)}
+    P["m.gn.weight"] = (rnd(cp, seed=20) * 0.3 + 1).requires_grad_(True)
+    P["m.gn.bias"] = rnd(cp, seed=21).requires_grad_(True)
+    y = O.shuffle_attention(P, "m", x, G)
+    g = rnd(B, C, H, W, seed=3)
+    y.backward(g)
+    xg, gg = nhwc(x), nhwc(g)
+    order = ["m.cweight", "m.cbias", "m.sweight", "m.sbias", "m.gn.weight", "m.gn.bias"]
+    params = [P[k].detach().reshape(-1).contiguous().cuda() for k in order]
+    mom = hip.moments(xg, C, B, H * W, C)
+    Pq, Qq = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+    hip.sa_coef_fwd(mom, *params, B, H * W, C, G, Pq, Qq)
+    out = torch.empty(B, H, W, C, device="cuda")
+    hip.sa_apply(xg, C, Pq, Qq, out, C, B, H * W, C)
+    close(nchw(out), y, what="sa fwd")
+    grads = [torch.zeros(cp, device="cuda") for _ in range(6)]
+    dx = torch.empty_like(xg)
+    EF = torch.empty(2, B, C, device="cuda")
+    hip.sa_bwd(gg, C, xg, C, Pq, Qq, mom, params, dx, C, grads, EF, B, H * W, C, G, 0, 0)
+    close(nchw(dx), x.grad, what="sa dx")
+    for gk, k in zip(grads, order):
+        close(gk, P[k].grad.reshape(-1), 2e-4, what="sa d" + k)
+
+
+@pytest.mark.parametrize("C", [7, 64, 256])
+def test_eca(hip, C):
+    from oracle import vrnet_oracle as O
+    B, H, W = 2, 6, 5
+    k = O.eca_kernel_size(C)
+    x = rnd(B, C, H, W, seed=1).requires_grad_(True)
+    P = {"m.conv.weight": rnd(1, 1, k, seed=2).requires_grad_(True)}
+    y = O.eca(P, "m", x)
+    g = rnd(B, C, H, W, seed=3)
+    y.backward(g)
+    xg, gg = nhwc(x), nhwc(g)
+    wk = P["m.conv.weight"].detach().reshape(-1).cuda()
+    mom = hip.moments(xg, C, B, H * W, C)
+    gate = torch.empty(B, C, device="cuda")
+    hip.eca_coef_fwd(mom, wk, k, B, H * W, C, gate)
+    out = torch.empty_like(xg)
+    hip.affine(out, C, B, H * W, C, x1=xg, ld1=C, A=gate, bstride=C)
+    close(nchw(out), y, what="eca fwd")
+    mom2 = hip.moments(gg, C, B, H * W, C, x2=xg, ldx2=C)
+    Fc, dwk = torch.empty(B, C, device="cuda"), torch.empty(k, device="cuda")
+    hip.eca_coef_bwd(mom2, mom, gate, wk, k, B, H * W, C, Fc, dwk, 0)
+    dx = torch.empty_like(xg)
+    hip.affine(dx, C, B, H * W, C, x1=gg, ld1=C, A=gate, D2=Fc, bstride=C)
+    close(nchw(dx), x.grad, what="eca dx")
+    close(dwk, P["m.conv.weight"].grad.reshape(-1), what="eca dwk")
+
+
+def test_layer_scale_coef_and_layout(hip):
+    B, H, W, C = 2, 5, 6, 12
+    dx, o, ls = rnd(B, C, H, W, seed=1), rnd(B, C, H, W, seed=2), rnd(C, seed=3)
+    mom2 = hip.moments(nhwc(dx), C, B, H * W, C, x2=nhwc(o), ldx2=C)
+    dls, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    hip.ls_coef_bwd(mom2, ls.cuda(), B, C, dls, db, 0)
+    close(dls, (dx * o).sum(dim=(0, 2, 3)), what="dls")
+    close(db, ls * dx.sum(dim=(0, 2, 3)), what="dbias")
+    # cat + 2-group shuffle through strided copies, and the adjoint
+    a, b = rnd(B, C, H, W, seed=4), rnd(B, C, H, W, seed=5)
+    buf = torch.empty(B, H, W, 2 * C, device="cuda")
+    hip.copy_channels(nhwc(a), C, 1, buf, 2 * C, 2, B * H * W, C)
+    hip.copy_channels(nhwc(b), C, 1, buf[..., 1:], 2 * C, 2, B * H * W, C)
+    from oracle import vrnet_oracle as O
+    close(nchw(buf), O.shuffle2(torch.cat([a, b], 1)), 1e-7, "cat+shuffle")
+    back = torch.ones(B, H, W, C, device="cuda")
+    hip.copy_channels(buf[..., 1:], 2 * C, 2, back, C, 1, B * H * W, C, accumulate=1)
+    close(nchw(back), b + 1, 1e-7, "adjoint")
+    # transposes
+    t = rnd(B, C, H, W, seed=6)
+    dst = torch.empty(B, H, W, C + 4, device="cuda")
+    hip.nchw_to_nhwc(t.cuda(), dst, C + 4, B, C, H * W)
+    close(nchw(dst[..., :C]), t, 1e-7, "nchw->nhwc")
+    out = torch.zeros(B, C, H, W, device="cuda")
+    hip.nhwc_to_nchw(dst, C + 4, out, B, C, H * W)
+    close(out.cpu(), t, 1e-7, "nhwc->nchw")
+    hip.add_(out, out.clone())
+    close(out.cpu(), 2 * t, 1e-7, "add")
+    hip.fill_(out, 3.0)
+    assert (out == 3).all()
+    mf = torch.empty(B, C, device="cuda")
+    hip.moments_to_float(hip.moments(nhwc(t), C, B, H * W, C), mf, B * C, 1.0 / (H * W))
+    close(mf, t.mean(dim=(2, 3)), what="gap")
