@@ -1,0 +1,735 @@
+"""Forward / backward program of the fusion hot path over the C-ABI kernels (hip.py).
+
+Host-side mirror of the reference call tree (nets/efficient_vrnet.py:24-27 ->
+neck/coc_fpn_dual.py:184-224 -> backbone/fusion/vr_coc.py:575-704 -> head/decouplehead.py:42-88).
+Activations are NHWC fp32 tensors that live on the GPU for the whole step; torch only allocates
+them.  The backward pass is hand-written: every forward block pushes one closure on a tape, the
+tape is replayed in reverse, gradients are accumulated in place by the kernels (`accumulate`
+flags) and parameter gradients are written once per parameter.  A single autograd.Function
+exposes the whole network to torch.autograd, so `loss.backward()`, optimizers, EMA deep-copies
+and state_dict work exactly as with the reference module.
+"""
+import torch
+
+from . import hip
+from . import modules as M
+
+
+class Act:
+    """NHWC activation: `t` is a (B,H,W,C) tensor or channel-slice view; row stride `ld` floats."""
+    __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad")
+
+    def __init__(self, t, need_grad=True):
+        self.t = t
+        self.B, self.H, self.W, self.C = t.shape
+        self.ld = t.stride(2)
+        self.grad = None
+        self.need_grad = need_grad
+
+    @property
+    def HW(self):
+        return self.H * self.W
+
+    @property
+    def rows(self):
+        return self.B * self.H * self.W
+
+
+class RT:
+    """Per-call runtime: mode, tape, parameter-gradient table, packed-weight cache."""
+
+    def __init__(self, device, training, record):
+        self.device, self.training, self.record = device, training, record
+        self.tape = []
+        self.pgrads = {}
+        self.packed = {}
+        self.consts = {}
+        self.idx_maps = {}
+        self.on_param_grad = None
+
+    def new(self, B, H, W, C, need_grad=True):
+        return Act(torch.empty((B, H, W, C), dtype=torch.float32, device=self.device), need_grad)
+
+    def buf(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def const(self, n, value):
+        key = (n, value)
+        c = self.consts.get(key)
+        if c is None:
+            c = self.buf(n)
+            hip.fill_(c, value)
+            self.consts[key] = c
+        return c
+
+    def weight(self, conv):
+        """[kh*kw][Cout][Cin] packing of a dense conv weight (the OIHW tensor itself for 1x1)."""
+        w = conv.weight
+        co, ci, kh, kw = w.shape
+        if kh * kw == 1:
+            return w
+        p = self.packed.get(conv)
+        if p is None:
+            p = self.buf(kh * kw, co, ci)
+            hip.pack_weight(w, p, co, ci, kh, kw)
+            self.packed[conv] = p
+        return p
+
+    def pgrad(self, param):
+        """(gradient buffer, accumulate flag) for a parameter; None if it needs no gradient."""
+        if not param.requires_grad or param.numel() == 0:
+            return None, 0
+        g = self.pgrads.get(param)
+        if g is None:
+            g = torch.empty_like(param)
+            self.pgrads[param] = g
+            return g, 0
+        return g, 1
+
+    def push(self, fn):
+        if self.record:
+            self.tape.append(fn)
+
+    def grad_target(self, act):
+        """(buffer, accumulate) to write d(act) into."""
+        if act.grad is None:
+            act.grad = self.buf(act.B, act.H, act.W, act.C)
+            return act.grad, 0
+        return act.grad, 1
+
+    def give_grad(self, act, g):
+        """Hands an owned, contiguous gradient buffer to `act`."""
+        if not act.need_grad:
+            return
+        if act.grad is None:
+            act.grad = g
+        else:
+            hip.add_(act.grad, g)
+
+
+def take_grad(act):
+    g = act.grad
+    act.grad = None
+    return g
+
+
+# ----------------------------------------------------------------------------------------- conv helpers
+def conv_geom(x, conv):
+    co, ci, kh, kw = conv.weight.shape
+    s, p, d = conv.stride[0], conv.padding[0], conv.dilation[0]
+    OH = (x.H + 2 * p - d * (kh - 1) - 1) // s + 1
+    OW = (x.W + 2 * p - d * (kw - 1) - 1) // s + 1
+    return co, ci, kh, kw, s, p, d, OH, OW
+
+
+def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw=None, bias=True):
+    """out: Act (NHWC target) or, with nchw=(tensor, ctot, coff), a channel range of an NCHW tensor."""
+    co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, conv)
+    b = conv.bias if bias else None
+    if nchw is None:
+        hip.conv2d(x.t, x.ld, rt.weight(conv), b, out.t, out.ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
+                   mode=0, act=act, ypre=None if ypre is None else ypre.t, ldypre=0 if ypre is None else ypre.ld,
+                   res=None if res is None else res.t, ldres=0 if res is None else res.ld, res_scale=res_scale)
+    else:
+        t, ctot, coff = nchw
+        hip.conv2d(x.t, x.ld, rt.weight(conv), b, t, 0, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=0, act=act,
+                   out_nchw=1, out_ctot=ctot, out_coff=coff)
+
+
+def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, skip_bias=False, dx_to=None):
+    """Gradients of y = conv(x): weight/bias into the parameter table, dx accumulated into x.grad
+    (or written to the Act `dx_to`).  dy: tensor whose data_ptr is the (0,0) element, row stride lddy."""
+    co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, conv)
+    gw, accw = rt.pgrad(conv.weight)
+    gb, accb = (None, 0) if (conv.bias is None or skip_bias) else rt.pgrad(conv.bias)
+    if gw is not None or gb is not None:
+        assert gb is None or gw is not None
+        assert gb is None or accb == accw
+        hip.conv2d_wgrad(x.t, x.ld, dy, lddy, gw, gb, row_scale, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
+                         accumulate=accw)
+        if rt.on_param_grad:
+            rt.on_param_grad(conv.weight)
+            if gb is not None:
+                rt.on_param_grad(conv.bias)
+    target = dx_to if dx_to is not None else (x if x.need_grad else None)
+    if target is not None:
+        if dx_to is not None:
+            buf, acc, ld = dx_to.t, 0, dx_to.ld
+        else:
+            buf, acc = rt.grad_target(x)
+            ld = x.C
+        hip.conv2d(dy, lddy, rt.weight(conv), None, buf, ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=1,
+                   kscale=kscale, aux=None if aux is None else aux.t, ldaux=0 if aux is None else aux.ld, accumulate=acc)
+
+
+def simple_conv(rt, x, conv, out=None):
+    """Plain conv with bias (PointRecuder.proj): recorded on the tape."""
+    co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, conv)
+    y = out if out is not None else rt.new(x.B, OH, OW, co)
+    conv_call(rt, x, conv, y)
+
+    def bwd():
+        g = take_grad(y)
+        conv_backward(rt, x, conv, g, y.C)
+    rt.push(bwd)
+    return y
+
+
+# ----------------------------------------------------------------------------------------- norms
+def bn_forward(rt, z, bn, relu, out=None, residual=None):
+    """y = [relu](BN(z)) [+ residual].  Returns (y, ctx) where ctx feeds bn_backward."""
+    B, HW, C = z.B, z.HW, z.C
+    A, D, ms = rt.buf(C), rt.buf(C), rt.buf(C, 2)
+    mom = hip.moments(z.t, z.ld, B, HW, C) if rt.training else None
+    hip.bn_coef_fwd(mom, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                    bn.num_batches_tracked, rt.training, B, HW, C, A, D, ms)
+    y = out if out is not None else rt.new(z.B, z.H, z.W, C)
+    hip.affine(y.t, y.ld, B, HW, C, x1=z.t, ld1=z.ld, A=A, D1=D, pre=1 if relu else 0,
+               x2=None if residual is None else residual.t, ld2=0 if residual is None else residual.ld)
+    return y, ms
+
+
+def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
+    """dz of y = [relu](BN(z)); mask = the ReLU output (None: no ReLU).  Returns contiguous dz tensor."""
+    B, HW, C = z.B, z.HW, z.C
+    mom2 = hip.moments(dy, lddy, B, HW, C, x2=z.t, ldx2=z.ld, mask=None if mask is None else mask.t,
+                       ldm=0 if mask is None else mask.ld)
+    A, E, D = rt.buf(C), rt.buf(C), rt.buf(C)
+    gw, accw = rt.pgrad(bn.weight)
+    gb, accb = rt.pgrad(bn.bias)
+    if gw is None:
+        gw, accw = rt.buf(C), 0
+    if gb is None:
+        gb = rt.buf(C)
+    hip.bn_coef_bwd(mom2, ms, bn.weight, rt.training, B, HW, C, A, E, D, gw, gb, accw)
+    if rt.on_param_grad:
+        rt.on_param_grad(bn.weight)
+        rt.on_param_grad(bn.bias)
+    dz = dz_out if dz_out is not None else rt.buf(z.B, z.H, z.W, C)
+    hip.affine(dz, C, B, HW, C, x1=dy, ld1=lddy, A=A, pre=2 if mask is not None else 0,
+               masky=None if mask is None else mask.t, ldm=0 if mask is None else mask.ld, x2=z.t, ld2=z.ld, E=E, D2=D)
+    return dz
+
+
+def gn_forward(rt, x, gn):
+    B, HW, C = x.B, x.HW, x.C
+    A, D, ms = rt.buf(B, C), rt.buf(B, C), rt.buf(B, 2)
+    hip.gn_coef_fwd(hip.moments(x.t, x.ld, B, HW, C), gn.weight, gn.bias, gn.eps, B, HW, C, A, D, ms)
+    y = rt.new(x.B, x.H, x.W, C)
+    hip.affine(y.t, C, B, HW, C, x1=x.t, ld1=x.ld, A=A, D2=D, bstride=C)
+    return y, ms
+
+
+def gn_backward(rt, gn, x, ms, dy, out, accumulate):
+    """out (+)= dx of y = GN(x) given contiguous dy."""
+    B, HW, C = x.B, x.HW, x.C
+    mom2 = hip.moments(dy, C, B, HW, C, x2=x.t, ldx2=x.ld)
+    A, E, D = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C)
+    gw, accw = rt.pgrad(gn.weight)
+    gb, _ = rt.pgrad(gn.bias)
+    if gw is None:
+        gw, accw = rt.buf(C), 0
+    if gb is None:
+        gb = rt.buf(C)
+    hip.gn_coef_bwd(mom2, ms, gn.weight, B, HW, C, A, E, D, gw, gb, accw)
+    if rt.on_param_grad:
+        rt.on_param_grad(gn.weight)
+        rt.on_param_grad(gn.bias)
+    hip.affine(out, C, B, HW, C, x1=dy, ld1=C, A=A, x2=x.t, ld2=x.ld, E=E, D2=D, bstride=C, accumulate=accumulate)
+
+
+# ----------------------------------------------------------------------------------------- BaseConv
+def base_conv(rt, x, m, out=None):
+    """BaseConv (normal_conv.py:36-49): [dw3x3 ->] conv -> BN -> ReLU."""
+    if m.ds_conv:
+        return ds_base_conv(rt, x, m, out)
+    conv = m.conv
+    co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, conv)
+    z = rt.new(x.B, OH, OW, co)
+    conv_call(rt, x, conv, z, bias=False)
+    y, ms = bn_forward(rt, z, m.bn, relu=True, out=out)
+
+    def bwd():
+        g = take_grad(y)
+        dz = bn_backward(rt, m.bn, z, ms, g, y.C, mask=y)
+        conv_backward(rt, x, conv, dz, co)
+    rt.push(bwd)
+    return y
+
+
+def ds_base_conv(rt, x, m, out=None):
+    """BaseConv(ds_conv=True): depthwise 3x3 (no bias) -> pointwise 1x1 (no bias) -> BN -> ReLU."""
+    dconv, pconv = m.conv.dconv, m.conv.pconv
+    C = x.C
+    t = rt.new(x.B, x.H, x.W, C)
+    hip.dwconv3x3(x.t, x.ld, dconv.weight, t.t, C, x.B, x.H, x.W, C)
+    z = rt.new(x.B, x.H, x.W, pconv.weight.shape[0])
+    conv_call(rt, t, pconv, z, bias=False)
+    y, ms = bn_forward(rt, z, m.bn, relu=True, out=out)
+
+    def bwd():
+        g = take_grad(y)
+        dz = bn_backward(rt, m.bn, z, ms, g, y.C, mask=y)
+        conv_backward(rt, t, pconv, dz, z.C)
+        dt = take_grad(t)
+        gw, acc = rt.pgrad(dconv.weight)
+        if gw is not None:
+            hip.dwconv3x3_wgrad(x.t, x.ld, dt, C, gw, x.B, x.H, x.W, C, accumulate=acc)
+            if rt.on_param_grad:
+                rt.on_param_grad(dconv.weight)
+        if x.need_grad:
+            buf, acc = rt.grad_target(x)
+            hip.dwconv3x3(dt, C, dconv.weight, buf, C, x.B, x.H, x.W, C, flip=1, accumulate=acc)
+    rt.push(bwd)
+    return y
+
+
+# ----------------------------------------------------------------------------------------- ClusterBlock
+def cluster_block(rt, x, m, name=None):
+    """ClusterBlock.forward (vr_coc.py:264-271): x + ls1*Cluster(GN(x)), then + ls2*Mlp(GN(.))."""
+    tm, mlp = m.token_mixer, m.mlp
+    B, H, W, C = x.B, x.H, x.W, x.C
+    E, Dh, fold = tm.heads, tm.head_dim, tm.fold
+    ED = E * Dh
+    xn, ms1 = gn_forward(rt, x, m.norm1)
+    f, v = rt.new(B, H, W, ED), rt.new(B, H, W, ED)
+    conv_call(rt, xn, tm.fc1, f)
+    conv_call(rt, xn, tm.fc_v, v)
+    o = rt.new(B, H, W, ED)
+    idx = rt.buf(B, H, W, E, dtype=torch.uint8)
+    hip.cluster_fwd(f.t, v.t, ED, tm.sim_alpha, tm.sim_beta, o.t, ED, idx, None, B, H, W, E, Dh, fold)
+    if name is not None:
+        rt.idx_maps[name] = idx
+    t1 = rt.new(B, H, W, C) if rt.record else None
+    x1 = rt.new(B, H, W, C)
+    conv_call(rt, o, tm.fc2, x1, ypre=t1, res=x, res_scale=m.layer_scale_1)
+    xn2, ms2 = gn_forward(rt, x1, m.norm2)
+    hid = mlp.fc1.weight.shape[0]
+    u = rt.new(B, H, W, hid) if rt.record else None
+    h = rt.new(B, H, W, hid)
+    conv_call(rt, xn2, mlp.fc1, h, act=2, ypre=u)
+    t2 = rt.new(B, H, W, C) if rt.record else None
+    x2 = rt.new(B, H, W, C)
+    conv_call(rt, h, mlp.fc2, x2, ypre=t2, res=x1, res_scale=m.layer_scale_2)
+
+    def bwd():
+        dx2 = take_grad(x2)                                      # owned; becomes dx1, then dx
+        # ---- MLP branch
+        ls2 = m.layer_scale_2
+        mom2 = hip.moments(dx2, C, B, H * W, C, x2=t2.t, ldx2=C)
+        _ls_grads(rt, mom2, ls2, mlp.fc2.bias, B, C)
+        du = rt.new(B, H, W, hid)
+        conv_backward(rt, h, mlp.fc2, dx2, C, kscale=ls2, aux=u, row_scale=ls2, skip_bias=True, dx_to=du)
+        dxn2 = rt.new(B, H, W, C)
+        conv_backward(rt, xn2, mlp.fc1, du.t, hid, dx_to=dxn2)
+        gn_backward(rt, m.norm2, x1, ms2, dxn2.t, dx2, accumulate=1)          # dx2 now holds dx1
+        # ---- Cluster branch
+        ls1 = m.layer_scale_1
+        mom2 = hip.moments(dx2, C, B, H * W, C, x2=t1.t, ldx2=C)
+        _ls_grads(rt, mom2, ls1, tm.fc2.bias, B, C)
+        do = rt.new(B, H, W, ED)
+        conv_backward(rt, o, tm.fc2, dx2, C, kscale=ls1, row_scale=ls1, skip_bias=True, dx_to=do)
+        df, dv = rt.new(B, H, W, ED), rt.new(B, H, W, ED)
+        ga, acca = rt.pgrad(tm.sim_alpha)
+        gb, _ = rt.pgrad(tm.sim_beta)
+        if ga is None:
+            ga, acca = rt.buf(1), 0
+        if gb is None:
+            gb = rt.buf(1)
+        hip.cluster_bwd(f.t, v.t, ED, tm.sim_alpha, tm.sim_beta, idx, do.t, ED, df.t, dv.t, ED, ga, gb, acca, B, H, W, E,
+                        Dh, fold)
+        if rt.on_param_grad:
+            rt.on_param_grad(tm.sim_alpha)
+            rt.on_param_grad(tm.sim_beta)
+        dxn = rt.new(B, H, W, C)
+        conv_backward(rt, xn, tm.fc1, df.t, ED, dx_to=dxn)
+        xn.grad = dxn.t                                          # fc_v accumulates onto fc1's dx
+        xn.need_grad = True
+        conv_backward(rt, xn, tm.fc_v, dv.t, ED)
+        gn_backward(rt, m.norm1, x, ms1, take_grad(xn), dx2, accumulate=1)     # dx2 now holds dx
+        rt.give_grad(x, dx2)
+    rt.push(bwd)
+    return x2
+
+
+def _ls_grads(rt, mom2, ls, bias, B, C):
+    gl, accl = rt.pgrad(ls)
+    gb, accb = rt.pgrad(bias)
+    if gl is not None or gb is not None:
+        assert gl is None or gb is None or accl == accb
+        hip.ls_coef_bwd(mom2, ls, B, C, gl, gb, accl if gl is not None else accb)
+        if rt.on_param_grad:
+            rt.on_param_grad(ls)
+            rt.on_param_grad(bias)
+
+
+# ----------------------------------------------------------------------------------------- fusion blocks
+def image_enhance(rt, x, r, m):
+    """ImageEnhanceByRadar.forward (vr_coc.py:312-316): BN((1 + minmax(ReLU(BN(conv3x3(r))))) * x)."""
+    conv, bn1 = m.radar_projection.conv, m.radar_projection.bn
+    B, H, W, C = x.B, x.H, x.W, x.C
+    z = rt.new(B, H, W, C)
+    conv_call(rt, r, conv, z, bias=False)
+    p, ms1 = bn_forward(rt, z, bn1, relu=True)
+    mm = rt.buf(2)
+    n = p.t.numel()
+    hip.minmax(p.t, n, mm)
+    t = rt.new(B, H, W, C)
+    assert x.ld == C, "image map must be contiguous"
+    hip.enhance_mul(p.t, x.t, mm, t.t, n)
+    y, ms2 = bn_forward(rt, t, m.norm, relu=False)
+
+    def bwd():
+        g = take_grad(y)
+        dt = bn_backward(rt, m.norm, t, ms2, g, C)
+        dp = rt.buf(B, H, W, C)
+        if x.need_grad:
+            dxb, acc = rt.grad_target(x)
+        else:
+            dxb, acc = rt.buf(B, H, W, C), 0
+        hip.enhance_bwd(dt, x.t, p.t, mm, dxb, dp, n, accumulate_dx=acc)
+        dz = bn_backward(rt, bn1, z, ms1, dp, C, mask=p)
+        conv_backward(rt, r, conv, dz, C)
+    rt.push(bwd)
+    return y
+
+
+def shuffle_attention(rt, x, m):
+    """ShuffleAttention.forward (shuffle_attention.py:48-72) on a contiguous map."""
+    B, HW, C, G = x.B, x.HW, x.C, m.G
+    params = [t.reshape(-1) for t in (m.cweight, m.cbias, m.sweight, m.sbias, m.gn.weight, m.gn.bias)]
+    mom = hip.moments(x.t, x.ld, B, HW, C)
+    P, Q = rt.buf(B, C), rt.buf(B, C)
+    hip.sa_coef_fwd(mom, *params, B, HW, C, G, P, Q)
+    y = rt.new(x.B, x.H, x.W, C)
+    hip.sa_apply(x.t, x.ld, P, Q, y.t, C, B, HW, C)
+
+    def bwd():
+        g = take_grad(y)
+        plist = (m.cweight, m.cbias, m.sweight, m.sbias, m.gn.weight, m.gn.bias)
+        grads, acc = [], 0
+        for prm in plist:
+            gp, a = rt.pgrad(prm)
+            if gp is None:
+                gp, a = rt.buf(prm.numel()), 0
+            grads.append(gp)
+            acc = a
+        if x.need_grad:
+            dxb, accx = rt.grad_target(x)
+        else:
+            dxb, accx = rt.buf(x.B, x.H, x.W, C), 0
+        hip.sa_bwd(g, C, x.t, x.ld, P, Q, mom, params, dxb, C, grads, rt.buf(2, B, C), B, HW, C, G, accx, acc)
+        if rt.on_param_grad:
+            for prm in plist:
+                rt.on_param_grad(prm)
+    rt.push(bwd)
+    return y
+
+
+def cat2(rt, a, b, interleave):
+    """torch.cat([a, b], 1) [+ 2-group channel shuffle when both halves have equal width]
+    (vr_coc.py:70-80, coc_fpn_dual.py:120-130): strided copies into one buffer."""
+    B, H, W = a.B, a.H, a.W
+    Ct = a.C + b.C
+    out = rt.new(B, H, W, Ct)
+    rows = a.rows
+    if interleave and Ct % 2 == 0:
+        assert a.C == b.C
+        hip.copy_channels(a.t, a.ld, 1, out.t, Ct, 2, rows, a.C)
+        hip.copy_channels(b.t, b.ld, 1, out.t[..., 1:], Ct, 2, rows, b.C)
+        sa, sb, cs = out.t, out.t[..., 1:], 2
+    else:
+        hip.copy_channels(a.t, a.ld, 1, out.t, Ct, 1, rows, a.C)
+        hip.copy_channels(b.t, b.ld, 1, out.t[..., a.C:], Ct, 1, rows, b.C)
+        sa, sb, cs = out.t, out.t[..., a.C:], 1
+
+    def bwd():
+        g = take_grad(out)
+        ga, gb = g, (g[..., 1:] if cs == 2 else g[..., a.C:])
+        for src, act in ((ga, a), (gb, b)):
+            if act.need_grad:
+                buf, acc = rt.grad_target(act)
+                hip.copy_channels(src, Ct, cs, buf, act.C, 1, rows, act.C, accumulate=acc)
+    rt.push(bwd)
+    return out
+
+
+def eca(rt, x, m):
+    """eca_block.forward (eca.py:16-22)."""
+    B, HW, C = x.B, x.HW, x.C
+    k = m.kernel_size
+    wk = m.conv.weight.reshape(-1)
+    mom = hip.moments(x.t, x.ld, B, HW, C)
+    gate = rt.buf(B, C)
+    hip.eca_coef_fwd(mom, wk, k, B, HW, C, gate)
+    y = rt.new(x.B, x.H, x.W, C)
+    hip.affine(y.t, C, B, HW, C, x1=x.t, ld1=x.ld, A=gate, bstride=C)
+
+    def bwd():
+        g = take_grad(y)
+        mom2 = hip.moments(g, C, B, HW, C, x2=x.t, ldx2=x.ld)
+        Fc = rt.buf(B, C)
+        gw, acc = rt.pgrad(m.conv.weight)
+        if gw is None:
+            gw, acc = rt.buf(k), 0
+        hip.eca_coef_bwd(mom2, mom, gate, wk, k, B, HW, C, Fc, gw, acc)
+        if rt.on_param_grad:
+            rt.on_param_grad(m.conv.weight)
+        if x.need_grad:
+            buf, accx = rt.grad_target(x)
+            hip.affine(buf, C, B, HW, C, x1=g, ld1=C, A=gate, D2=Fc, bstride=C, accumulate=accx)
+    rt.push(bwd)
+    return y
+
+
+def radar_enhance(rt, x, r, m):
+    """RadarEnhanceByImage.forward (vr_coc.py:331-359)."""
+    a = x if m.initial else shuffle_attention(rt, x, m.image_attn)
+    u = eca(rt, cat2(rt, a, r, interleave=True), m.channel_attn)
+    conv, bn1 = m.inverse_projection.conv, m.inverse_projection.bn
+    B, H, W, C = r.B, r.H, r.W, r.C
+    z = rt.new(B, H, W, C)
+    conv_call(rt, u, conv, z, bias=False)
+    q, ms1 = bn_forward(rt, z, bn1, relu=True)
+    s = rt.new(B, H, W, C)
+    hip.affine(s.t, C, B, H * W, C, x1=q.t, ld1=C, x2=r.t, ld2=r.ld)
+    y, ms2 = bn_forward(rt, s, m.norm, relu=False)
+
+    def bwd():
+        g = take_grad(y)
+        ds = bn_backward(rt, m.norm, s, ms2, g, C)
+        dz = bn_backward(rt, bn1, z, ms1, ds, C, mask=q)
+        rt.give_grad(r, ds)                                       # long residual path (+ radar_map)
+        conv_backward(rt, u, conv, dz, C)
+    rt.push(bwd)
+    return y
+
+
+# ----------------------------------------------------------------------------------------- neck pieces
+def coc_upsample(rt, x, m, nchw_out=None):
+    """CoCUpsample.forward (coc_fpn_dual.py:24-26): BaseConv 1x1 -> bilinear, align_corners=True."""
+    lo = base_conv(rt, x, m.upsample[0])
+    s = m.scale
+    B, H, W, C = lo.B, lo.H, lo.W, lo.C
+    if nchw_out is not None:
+        hip.upsample(lo.t, C, nchw_out, 0, B, H, W, C, s, out_nchw=1)
+        return lo                                                  # caller seeds lo.grad from the NCHW gradient
+    hi = rt.new(B, H * s, W * s, C)
+    hip.upsample(lo.t, C, hi.t, C, B, H, W, C, s)
+
+    def bwd():
+        g = take_grad(hi)
+        buf, acc = rt.grad_target(lo)
+        hip.upsample_bwd(g, C, 0, buf, C, B, H, W, C, s, accumulate=acc)
+    rt.push(bwd)
+    return hi
+
+
+def coc_conv(rt, x, m, name=None):
+    """CoC_Conv.forward (coc_fpn_dual.py:36-39)."""
+    return base_conv(rt, cluster_block(rt, x, m.coc, name), m.conv_att)
+
+
+def aspp(rt, x, m):
+    """ASPP.forward (coc_fpn_dual.py:79-104); the five branches write channel slices of one buffer."""
+    B, H, W, C = x.B, x.H, x.W, x.C
+    HW = H * W
+    cat = rt.new(B, H, W, 5 * C)
+    saved = []
+    for k, br in enumerate((m.branch1, m.branch2, m.branch3, m.branch4)):
+        conv, bn = br[0], br[1]
+        z = rt.new(B, H, W, C)
+        conv_call(rt, x, conv, z)
+        sl = Act(cat.t[..., k * C:(k + 1) * C])
+        _, ms = bn_forward(rt, z, bn, relu=True, out=sl)
+        saved.append((conv, bn, z, sl, ms))
+    # global-average branch: (B,1,1,C) "pixels"
+    gm = rt.new(B, 1, 1, C)
+    hip.moments_to_float(hip.moments(x.t, x.ld, B, HW, C), gm.t, B * C, 1.0 / HW)
+    z5 = rt.new(B, 1, 1, C)
+    conv_call(rt, gm, m.branch5_conv, z5)
+    q5, ms5 = bn_forward(rt, z5, m.branch5_bn, relu=True)
+    sl5 = cat.t[..., 4 * C:]
+    hip.affine(sl5, 5 * C, B, HW, C, D2=q5.t, bstride=C)           # bilinear from 1x1, align_corners: constant
+    convc, bnc = m.conv_cat[0], m.conv_cat[1]
+    zc = rt.new(B, H, W, C)
+    conv_call(rt, cat, convc, zc)
+    y, msc = bn_forward(rt, zc, bnc, relu=True)
+
+    def bwd():
+        g = take_grad(y)
+        dzc = bn_backward(rt, bnc, zc, msc, g, C, mask=y)
+        conv_backward(rt, cat, convc, dzc, C)
+        dcat = take_grad(cat)
+        for k, (conv, bn, z, sl, ms) in enumerate(saved):
+            dz = bn_backward(rt, bn, z, ms, dcat[..., k * C:], 5 * C, mask=sl)
+            conv_backward(rt, x, conv, dz, C)
+        dq5 = rt.buf(B, 1, 1, C)
+        hip.moments_to_float(hip.moments(dcat[..., 4 * C:], 5 * C, B, HW, C), dq5, B * C, 1.0)
+        dz5 = bn_backward(rt, m.branch5_bn, z5, ms5, dq5, C, mask=q5)
+        conv_backward(rt, gm, m.branch5_conv, dz5, C)
+        dgm = take_grad(gm)
+        if x.need_grad:
+            buf, acc = rt.grad_target(x)
+            scaled = rt.buf(B, C)
+            hip.affine(scaled, C, B, 1, C, x1=dgm, ld1=C, A=rt.const(C, 1.0 / HW))
+            hip.affine(buf, C, B, HW, C, D2=scaled, bstride=C, accumulate=acc)
+    rt.push(bwd)
+    return y
+
+
+# ----------------------------------------------------------------------------------------- assembly
+def backbone_forward(rt, bb, x, r):
+    """VRCoC.forward_embeddings + forward_tokens (vr_coc.py:575-675)."""
+    B, H, W = x.B, x.H, x.W
+    x = simple_conv(rt, x, bb.image_initial.proj)
+    r = simple_conv(rt, r, bb.radar_initial.proj)
+    x = image_enhance(rt, x, r, bb.image_enhance_by_radar1)
+    r = radar_enhance(rt, x, r, bb.radar_enhance_by_image1)
+    if tuple(bb.fea_pos.shape[:2]) != (H, W):
+        raise RuntimeError(f"input {H}x{W} does not match fea_pos {tuple(bb.fea_pos.shape[:2])}: "
+                           "construct EfficientVRNet(..., img_size=(H, W))")
+    embeds = []
+    for act, pe in ((x, bb.patch_embed), (r, bb.patch_embed_radar)):
+        C = act.C
+        cat = rt.new(B, H, W, C + 2)
+        hip.copy_channels(act.t, act.ld, 1, cat.t, C + 2, 1, act.rows, C)
+        for b in range(B):                                         # fea_pos (H,W,2) is already NHWC; :585 uses fea_pos twice
+            hip.copy_channels(bb.fea_pos, 2, 1, cat.t[b, :, :, C:], C + 2, 1, H * W, 2)
+
+        def bwd(cat=cat, act=act, C=C):
+            g = take_grad(cat)
+            if act.need_grad:
+                buf, acc = rt.grad_target(act)
+                hip.copy_channels(g, C + 2, 1, buf, C, 1, act.rows, C, accumulate=acc)
+        rt.push(bwd)
+        embeds.append(simple_conv(rt, cat, pe.proj))
+    x, r = embeds
+    outs, outs_r = [], []
+    for i in range(4):
+        for j, (blk, blk_r) in enumerate(zip(bb.network[3 * i], bb.network_radar[3 * i])):
+            x = cluster_block(rt, x, blk, f"backbone.backbone.network.{3 * i}.{j}.token_mixer")
+            r = cluster_block(rt, r, blk_r, f"backbone.backbone.network_radar.{3 * i}.{j}.token_mixer")
+        x = image_enhance(rt, x, r, bb.network[3 * i + 1])
+        r = radar_enhance(rt, x, r, bb.network_radar[3 * i + 1])
+        if i in (0, 3):
+            outs.append(x)
+            outs_r.append(r)
+        if i < 3:
+            x = simple_conv(rt, x, bb.network[3 * i + 2].proj)
+            r = simple_conv(rt, r, bb.network_radar[3 * i + 2].proj)
+            if i < 2:
+                outs.append(x)
+                outs_r.append(r)
+    return outs, outs_r
+
+
+def neck_forward(rt, nk, x, r, seg_out):
+    """CoCFpnDual.forward (coc_fpn_dual.py:184-224). seg_out: NCHW tensor for the seg logits."""
+    (x2, x3, x4, x5), (r2, r3, r4, r5) = backbone_forward(rt, nk.backbone, x, r)
+    x5 = aspp(rt, x5, nk.aspp)
+    t = shuffle_attention(rt, cat2(rt, x4, coc_upsample(rt, x5, nk.upsample5_4), True), nk.sc_attn_seg4)
+    t = shuffle_attention(rt, cat2(rt, coc_upsample(rt, t, nk.upsample4_3), x3, True), nk.sc_attn_seg3)
+    t = shuffle_attention(rt, cat2(rt, coc_upsample(rt, t, nk.upsample3_2), x2, True), nk.sc_attn_seg2)
+    seg_lo = coc_upsample(rt, t, nk.upsample2_0, nchw_out=seg_out)
+    p5 = coc_conv(rt, r5, nk.p5_out_det, "backbone.p5_out_det.coc.token_mixer")
+    p4 = coc_conv(rt, cat2(rt, r4, coc_upsample(rt, p5, nk.p5_4_det), False), nk.p4_out_det,
+                  "backbone.p4_out_det.coc.token_mixer")
+    p3 = coc_conv(rt, cat2(rt, r3, coc_upsample(rt, p4, nk.p4_3_det), False), nk.p3_out_det,
+                  "backbone.p3_out_det.coc.token_mixer")
+    return (p3, p4, p5), seg_lo
+
+
+def head_forward(rt, hd, feats, det_outs):
+    """DecoupleHead.forward (decouplehead.py:42-88): the three prediction convs store straight into the
+    channel ranges [reg 0:4 | obj 4:5 | cls 5:] of the NCHW output (the reference's torch.cat)."""
+    ctot = 5 + hd.num_classes
+    recs = []
+    for k, x in enumerate(feats):
+        s = base_conv(rt, x, hd.stems[k])
+        c = base_conv(rt, base_conv(rt, s, hd.cls_convs[k][0]), hd.cls_convs[k][1])
+        g = base_conv(rt, base_conv(rt, s, hd.reg_convs[k][0]), hd.reg_convs[k][1])
+        out = det_outs[k]
+        conv_call(rt, g, hd.reg_preds[k], None, nchw=(out, ctot, 0))
+        conv_call(rt, g, hd.obj_preds[k], None, nchw=(out, ctot, 4))
+        conv_call(rt, c, hd.cls_preds[k], None, nchw=(out, ctot, 5))
+        recs.append((k, c, g))
+    return recs
+
+
+def head_backward(rt, hd, recs, det_grads):
+    ctot = 5 + hd.num_classes
+    for k, c, g in recs:
+        dg = det_grads[k]
+        if dg is None:
+            continue
+        B, _, h, w = dg.shape
+        d = rt.buf(B, h, w, ctot)
+        hip.nchw_to_nhwc(dg.contiguous(), d, ctot, B, ctot, h * w)
+        conv_backward(rt, g, hd.reg_preds[k], d, ctot)
+        conv_backward(rt, g, hd.obj_preds[k], d[..., 4:], ctot)
+        conv_backward(rt, c, hd.cls_preds[k], d[..., 5:], ctot)
+
+
+class _VRNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, x_radar, *params):
+        if not (x.is_cuda and x_radar.is_cuda):
+            raise RuntimeError("EfficientVRNet (HIP hot path) needs inputs on a HIP device; there is no CPU fallback")
+        if x.dtype != torch.float32 or x_radar.dtype != torch.float32:
+            x, x_radar = x.float(), x_radar.float()
+        B, _, H, W = x.shape
+        if H % 64 or W % 64:
+            raise RuntimeError(f"input size {H}x{W} must be a multiple of 64 (fold-2 Cluster on the H/32 map)")
+        record = any(ctx.needs_input_grad)
+        rt = RT(x.device, model.training, record)
+        rt.on_param_grad = getattr(model, "_on_param_grad", None)
+        xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=ctx.needs_input_grad[1])
+        ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=ctx.needs_input_grad[2])
+        hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)
+        hip.nchw_to_nhwc(x_radar.contiguous(), ra.t, 4, B, 4, H * W)
+        nc, ns = model.num_classes, model.num_seg_classes
+        seg = torch.empty((B, ns, H, W), device=x.device)
+        dets = [torch.empty((B, 5 + nc, H // s, W // s), device=x.device) for s in (8, 16, 32)]
+        feats, seg_lo = neck_forward(rt, model.backbone, xa, ra, seg)
+        recs = head_forward(rt, model.head, feats, dets)
+        ctx.rt, ctx.recs, ctx.seg_lo, ctx.inputs = rt, recs, seg_lo, (xa, ra)
+        ctx.params = params
+        ctx.model = model
+        ctx.set_materialize_grads(False)
+        model._last_idx_maps = rt.idx_maps
+        return (*dets, seg)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, gseg):
+        rt, model = ctx.rt, ctx.model
+        if rt.tape is None:
+            raise RuntimeError("EfficientVRNet backward called twice (activations are freed after the first pass)")
+        head_backward(rt, model.head, ctx.recs, (g0, g1, g2))
+        if gseg is not None:
+            lo = ctx.seg_lo
+            buf, acc = rt.grad_target(lo)
+            hip.upsample_bwd(gseg.contiguous(), 0, 1, buf, lo.C, lo.B, lo.H, lo.W, lo.C, model.backbone.upsample2_0.scale,
+                             accumulate=acc)
+        for fn in reversed(rt.tape):
+            fn()
+        rt.tape = None
+        xa, ra = ctx.inputs
+        outs = [None]
+        for act, need in ((xa, ctx.needs_input_grad[1]), (ra, ctx.needs_input_grad[2])):
+            if need and act.grad is not None:
+                g = torch.empty((act.B, act.C, act.H, act.W), device=act.t.device)
+                hip.nhwc_to_nchw(act.grad, act.C, g, act.B, act.C, act.H * act.W)
+                outs.append(g)
+            else:
+                outs.append(None)
+        for i, p in enumerate(ctx.params):
+            outs.append(rt.pgrads.get(p) if ctx.needs_input_grad[3 + i] else None)
+        ctx.rt = ctx.recs = ctx.seg_lo = ctx.inputs = None
+        return tuple(outs)
+
+
+def run_forward(model, x, x_radar):
+    params = tuple(model.parameters())
+    out = _VRNetFunction.apply(model, x, x_radar, *params)
+    return [out[0], out[1], out[2]], out[3]

@@ -1,0 +1,81 @@
+"""Flip-aware parity of the HIP hot path against the CPU oracle (test infrastructure).
+
+The Cluster op assigns every point to its arg-max centre (vr_coc.py:173-176).  Two correct fp32
+implementations with different summation orders disagree on a handful of numerically tied points,
+and one flipped point changes downstream features by O(1) (measured: the oracle in fp64 vs fp32
+flips 0.07 % of points at 512 px and moves det outputs by 7 %).  Parity is therefore stated as:
+
+ 1. teacher forcing: the oracle re-runs the forward with the HIP path's assignment maps; every
+    point where the oracle's own arg-max differs must be a near-tie (similarity gap < 1e-4 under
+    the oracle's arithmetic), and such points must be rare (< 0.1 %);
+ 2. conditional on the assignments, det maps and seg logits agree within 1e-3 relative
+    (the north star's tolerance), gradients within 5e-3 of the oracle's.
+"""
+import torch
+
+import asy_vrnet_amd as A
+from oracle import vrnet_oracle as O
+
+
+def rel_err(a, b, floor=1e-6):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(floor)).item()
+
+
+def hip_idx_maps(model):
+    """{oracle cluster prefix: (B,E,H,W) int64 cpu} from the last HIP forward."""
+    return {k: v.permute(0, 3, 1, 2).contiguous().cpu().long() for k, v in model._last_idx_maps.items()}
+
+
+def compare_with_oracle(model, batch, size, iseed, check_grads=True, oracle_dtype=torch.float32, tol=1e-3,
+                        gtol=5e-3):
+    dev = next(model.parameters()).device
+    x, r = A.synthetic_inputs(batch, size, iseed)
+    sd0 = {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+    xg, rg = x.to(dev).requires_grad_(check_grads), r.to(dev).requires_grad_(check_grads)
+    model.zero_grad(set_to_none=True)
+    det, seg = model(xg, rg)
+    if check_grads:
+        O.synthetic_loss(det, seg).backward()
+    torch.cuda.synchronize()
+    forced = hip_idx_maps(model)
+    pnames = {k for k, _ in model.named_parameters()}
+    P = {}
+    for k, v in sd0.items():
+        t = v.to(oracle_dtype) if v.dtype.is_floating_point else v
+        if check_grads and k in pnames and t.numel():
+            t.requires_grad_(True)
+        P[k] = t
+    xo = x.to(oracle_dtype).requires_grad_(check_grads)
+    ro = r.to(oracle_dtype).requires_grad_(check_grads)
+    det_o, seg_o, ctx = O.forward(P, xo, ro, model.phi, model.training, forced_idx=forced)
+    rep = {"flips": sum(v.get("mismatch", 0) for v in ctx.idx_report.values()),
+           "points": sum(v.get("points", 0) for v in ctx.idx_report.values()),
+           "max_gap": max([v.get("max_gap", 0.0) for v in ctx.idx_report.values()] + [0.0])}
+    rep["det_err"] = max(rel_err(a, b) for a, b in zip(det, det_o))
+    rep["seg_err"] = rel_err(seg, seg_o)
+    ok = rep["det_err"] < tol and rep["seg_err"] < tol and rep["max_gap"] < 1e-4 and \
+        rep["flips"] <= max(3, rep["points"] // 1000)
+    if model.training:
+        sd1 = model.state_dict()
+        rep["stat_err"] = max(rel_err(sd1[k], v) for k, v in ctx.new_stats.items())
+        ok = ok and rep["stat_err"] < tol
+    if check_grads:
+        O.synthetic_loss(det_o, seg_o).backward()
+        rep["dx_err"] = rel_err(xg.grad, xo.grad)
+        rep["dr_err"] = rel_err(rg.grad, ro.grad)
+        worst, worst_k = 0.0, None
+        gmax = max(float(P[k].grad.abs().max()) for k in pnames if P[k].numel() and P[k].grad is not None)
+        for k, p in model.named_parameters():
+            if p.numel() == 0:
+                continue
+            go = P[k].grad
+            assert p.grad is not None, f"no gradient for {k}"
+            # floor: gradients that are analytically ~0 hold rounding noise on both sides
+            e = rel_err(p.grad, go, floor=1e-4 * gmax)
+            if e > worst:
+                worst, worst_k = e, k
+        rep["grad_err"], rep["grad_worst"] = worst, worst_k
+        ok = ok and rep["dx_err"] < gtol and rep["dr_err"] < gtol and worst < gtol
+    rep["ok"] = bool(ok)
+    return rep

@@ -33,10 +33,12 @@ def nchw(y):            # NHWC gpu -> NCHW cpu
     return y.permute(0, 3, 1, 2).contiguous().cpu()
 
 
-def close(a, b, tol=TOL, what=""):
+def close(a, b, tol=TOL, what="", floor=1e-6):
+    """max |a-b| <= tol * max(max|b|, floor).  `floor` = natural magnitude of the quantity when the
+    exact value can be identically zero (e.g. d/df of the cluster core when every point is its own centre)."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     assert a.shape == b.shape, (what, a.shape, b.shape)
-    scale = max(b.abs().max().item(), 1e-6)
+    scale = max(b.abs().max().item(), floor)
     err = (a - b).abs().max().item() / scale
     assert err < tol, f"{what}: rel err {err:.3e} (scale {scale:.3e})"
 
@@ -259,9 +261,9 @@ def test_cluster_core(hip, case):
     hip.cluster_bwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), idx, nhwc(g), E * D, df, dv, E * D,
                     dab[0:1], dab[1:2], 0, B, H, W, E, D, fold)
     close(nchw(dv), v.grad, what="cluster dv")
-    close(nchw(df), f.grad, 5e-4, what="cluster df")
-    close(dab[0:1], alpha.grad, 5e-4, what="dalpha")
-    close(dab[1:2], beta.grad, 5e-4, what="dbeta")
+    close(nchw(df), f.grad, 5e-4, what="cluster df", floor=1e-2)
+    close(dab[0:1], alpha.grad, 5e-4, what="dalpha", floor=1e-2)
+    close(dab[1:2], beta.grad, 5e-4, what="dbeta", floor=1e-2)
     # bitwise reproducible
     out2 = torch.empty_like(out)
     hip.cluster_fwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), out2, E * D, idx, wgt, B, H, W, E, D, fold)

@@ -1,0 +1,97 @@
+"""Whole-path parity on the GPU: EfficientVRNet.forward/backward through the C-ABI kernels against
+(a) the CPU oracle with teacher-forced assignments (tests/parity.py) and (b) the golden vectors the
+reference itself produced (tests/golden/net_*.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import asy_vrnet_amd
+    return asy_vrnet_amd
+
+
+def build(A, phi, size, pseed, training):
+    m = A.EfficientVRNet(4, 9, phi, img_size=size).cuda()
+    A.randomize_state_dict(m.state_dict(), seed=pseed)
+    return m.train(training)
+
+
+@pytest.mark.parametrize("phi,size,batch,training", [
+    ("nano", 64, 2, True), ("nano", 64, 2, False), ("nano", 128, 2, True), ("tiny", 128, 3, True),
+    ("nano", 256, 2, True), ("l", 128, 2, True)])
+def test_against_oracle(A, phi, size, batch, training):
+    from tests.parity import compare_with_oracle
+    m = build(A, phi, size, 21, training)
+    rep = compare_with_oracle(m, batch, size, iseed=31, check_grads=training, oracle_dtype=torch.float64)
+    print(rep)
+    assert rep["ok"], rep
+
+
+def test_512_bs2_against_oracle(A):
+    from tests.parity import compare_with_oracle
+    m = build(A, "nano", 512, 3, True)
+    rep = compare_with_oracle(m, 2, 512, iseed=9, check_grads=True, oracle_dtype=torch.float64)
+    print(rep)
+    assert rep["ok"], rep
+
+
+@pytest.mark.parametrize("name", ["net_nano_64_train", "net_nano_64_eval", "net_nano_128_train", "net_tiny_128_eval"])
+def test_against_reference_golden(A, name, golden_dir):
+    """Direct comparison with the reference's own outputs.  These small cases have no numerical
+    near-ties between the reference and this implementation (checked: zero flips), so plain 1e-3 holds."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.load(open(os.path.join(golden_dir, name + ".json")))
+    m = build(A, meta["phi"], meta["size"], meta["pseed"], meta["training"])
+    x, r = A.synthetic_inputs(meta["batch"], meta["size"], meta["iseed"])
+    grads = "dx" in z.files
+    xg, rg = x.cuda().requires_grad_(grads), r.cuda().requires_grad_(grads)
+    det, seg = m(xg, rg)
+    from tests.parity import rel_err
+    for i in range(3):
+        assert rel_err(det[i], torch.from_numpy(z[f"det{i}"])) < 1e-3
+    assert rel_err(seg, torch.from_numpy(z["seg"])) < 1e-3
+    if meta["training"]:
+        sd = m.state_dict()
+        for k in z.files:
+            if k.startswith("s:"):
+                assert rel_err(sd[k[2:]], torch.from_numpy(z[k])) < 1e-3, k
+    if grads:
+        sum((d * d).mean() for d in det).add((seg * seg).mean()).backward()
+        assert rel_err(xg.grad, torch.from_numpy(z["dx"])) < 5e-3
+        assert rel_err(rg.grad, torch.from_numpy(z["dr"])) < 5e-3
+        pd = dict(m.named_parameters())
+        for k in z.files:
+            if k.startswith("g:"):
+                ref = torch.from_numpy(z[k])
+                if ref.abs().max() < 1e-6:
+                    assert pd[k[2:]].grad.abs().max() < 1e-4, k
+                else:
+                    assert rel_err(pd[k[2:]].grad, ref) < 5e-3, k
+
+
+def test_module_surface_behaviour(A):
+    """deepcopy (ModelEMA, yolo_training.py:457), no_grad eval, repeated backward error, seg-only loss."""
+    import copy
+    m = build(A, "nano", 64, 5, True)
+    x, r = A.synthetic_inputs(2, 64, 1)
+    x, r = x.cuda(), r.cuda()
+    ema = copy.deepcopy(m).eval()
+    with torch.no_grad():
+        d1, s1 = ema(x, r)
+        d2, s2 = ema(x, r)
+    assert torch.equal(s1, s2) and all(torch.equal(a, b) for a, b in zip(d1, d2))   # deterministic
+    det, seg = m(x, r)
+    seg.mean().backward()                                                           # det grads absent
+    assert m.head.cls_preds[0].weight.grad is None or m.head.cls_preds[0].weight.grad.abs().max() == 0
+    assert m.backbone.upsample2_0.upsample[0].conv.weight.grad.abs().max() > 0
+    with pytest.raises(RuntimeError):
+        m(x.cpu(), r.cpu())
