@@ -46,6 +46,7 @@ class RT:
         self.consts = {}
         self.idx_maps = {}
         self.on_param_grad = None
+        self.bucketer = None        # parallel.GradBucketer: gradients are written into its flat buckets
 
     def new(self, B, H, W, C, need_grad=True):
         return Act(torch.empty((B, H, W, C), dtype=torch.float32, device=self.device), need_grad)
@@ -81,7 +82,9 @@ class RT:
             return None, 0
         g = self.pgrads.get(param)
         if g is None:
-            g = torch.empty_like(param)
+            g = self.bucketer.view(param) if self.bucketer is not None else None
+            if g is None:
+                g = torch.empty_like(param)
             self.pgrads[param] = g
             return g, 0
         return g, 1
@@ -683,7 +686,8 @@ class _VRNetFunction(torch.autograd.Function):
             raise RuntimeError(f"input size {H}x{W} must be a multiple of 64 (fold-2 Cluster on the H/32 map)")
         record = any(ctx.needs_input_grad)
         rt = RT(x.device, model.training, record)
-        rt.on_param_grad = getattr(model, "_on_param_grad", None)
+        rt.bucketer = getattr(model, "_grad_bucketer", None)
+        rt.on_param_grad = getattr(model, "_on_param_grad", None) if rt.bucketer is not None else None
         xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=ctx.needs_input_grad[1])
         ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=ctx.needs_input_grad[2])
         hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)
@@ -723,8 +727,12 @@ class _VRNetFunction(torch.autograd.Function):
                 outs.append(g)
             else:
                 outs.append(None)
-        for i, p in enumerate(ctx.params):
-            outs.append(rt.pgrads.get(p) if ctx.needs_input_grad[3 + i] else None)
+        if rt.bucketer is not None:          # data parallel: buckets own the gradients (all-reduced, then .grad = view)
+            rt.bucketer.finish()
+            outs.extend([None] * len(ctx.params))
+        else:
+            for i, p in enumerate(ctx.params):
+                outs.append(rt.pgrads.get(p) if ctx.needs_input_grad[3 + i] else None)
         ctx.rt = ctx.recs = ctx.seg_lo = ctx.inputs = None
         return tuple(outs)
 

@@ -1,0 +1,209 @@
+"""Headline benchmark: images/sec forward+backward of the ASY-VRNet fusion hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--phi l|nano|...] [--batch 8] [--size 512]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(one rank per GPU, RCCL).  A "step" is one forward+backward pass of EfficientVRNet over one
+synthetic batch (BASELINE.json configs[1]: bs=8/GPU, 512x512 image + 4x512x512 radar, fp32, det+seg
+heads), driven by the fixed scalar sum_k mean(det_k^2) + mean(seg^2).  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      dominant kernel class (implicit-GEMM conv fwd/dgrad on the fp32 MFMA): algorithmic FLOPs per
+                launch / average launch duration, measured with HIP events on the launch stream in an
+                instrumented replay of the timed steps (events around ~700 launches per step would perturb
+                `value`, so the timed region itself is un-instrumented); profiles/ holds the rocprofv3 summary
+                of the same command.
+  cpu_baseline  the CPU oracle (pure-torch restatement, kind "port") timed on the host cores, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def loss_of(det, seg):
+    return sum((d * d).mean() for d in det) + (seg * seg).mean()
+
+
+def make_batches(n, batch, size, rank, device):
+    out = []
+    for s in range(n):
+        g = torch.Generator().manual_seed(1234 + 1000 * rank + s)
+        x = torch.randn((batch, 3, size, size), generator=g)
+        r = torch.rand((batch, 4, size, size), generator=g)
+        out.append((x.to(device), r.to(device)))
+    return out
+
+
+class ConvTimer:
+    """Wraps hip.conv2d / hip.conv2d_wgrad with HIP events (torch.cuda.Event on the current = launch stream)."""
+
+    def __init__(self, hip):
+        self.hip = hip
+        self.rec = {"igemm": [], "wgrad": []}
+        self.orig = (hip.conv2d, hip.conv2d_wgrad)
+
+    def __enter__(self):
+        hip, rec = self.hip, self.rec
+        o_conv, o_wgrad = self.orig
+
+        def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_conv(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_)
+            e1.record()
+            rec["igemm"].append((2.0 * B * OH * OW * Cout * Cin * kh * kw, e0, e1))
+
+        def conv2d_wgrad(x, ldx, dy, lddy, dw, db, rs, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_wgrad(x, ldx, dy, lddy, dw, db, rs, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_)
+            e1.record()
+            rec["wgrad"].append((2.0 * B * OH * OW * Cout * Cin * kh * kw, e0, e1))
+        hip.conv2d, hip.conv2d_wgrad = conv2d, conv2d_wgrad
+        return self
+
+    def __exit__(self, *a):
+        self.hip.conv2d, self.hip.conv2d_wgrad = self.orig
+
+    def summary(self, key):
+        torch.cuda.synchronize()
+        r = self.rec[key]
+        flops = sum(f for f, _, _ in r)
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in r)
+        return len(r), flops, ms
+
+
+def cpu_baseline(phi, size, batch, seed_sd):
+    """Oracle fwd+bwd on the host cores: a bounded sample of the same workload."""
+    from oracle import vrnet_oracle as O
+    import asy_vrnet_amd as A
+    torch.set_num_threads(os.cpu_count() or 1)
+    m = A.EfficientVRNet(4, 9, phi, img_size=size)
+    A.randomize_state_dict(m.state_dict(), seed=seed_sd)
+    pn = {k for k, _ in m.named_parameters()}
+    P = {k: (v.detach().clone().requires_grad_(k in pn and v.numel() > 0) if v.dtype.is_floating_point else v.clone())
+         for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    x, r = torch.randn((batch, 3, size, size), generator=g), torch.rand((batch, 4, size, size), generator=g)
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        det, seg, _ = O.forward(P, x, r, phi, True)
+        loss_of(det, seg).backward()
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or iters >= 4:
+            break
+    return {"value": round(iters * batch / el, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"CPU oracle (pure-torch restatement of the reference) fwd+bwd, phi={phi}, bs={batch}, "
+                      f"{size}x{size}, {iters} iteration(s) in {el:.1f} s, no warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--phi", default="l")
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import asy_vrnet_amd as A
+    from asy_vrnet_amd import hip
+    from asy_vrnet_amd.parallel import DataParallelVRNet
+    model = A.EfficientVRNet(4, 9, args.phi, img_size=args.size).to(dev).train()
+    A.randomize_state_dict(model.state_dict(), seed=0)
+    net = DataParallelVRNet(model) if world > 1 else model
+    batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
+
+    def step(i):
+        x, r = batches[i]
+        if world == 1:
+            model.zero_grad(set_to_none=True)
+        det, seg = net(x, r)
+        loss_of(det, seg).backward()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms_per_step = 1e3 * el / args.steps
+    value = world * args.batch * args.steps / el
+
+    roof = None
+    if not args.no_roofline:
+        with ConvTimer(hip) as ct:
+            for i in range(args.steps):
+                step(args.warmup + i)
+            n, flops, ms = ct.summary("igemm")
+            nw, fw, msw = ct.summary("wgrad")
+        ach = flops / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32)",
+                "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n // args.steps, "avg_launch_us": round(1e3 * ms / n, 2),
+                "avg_launch_gflop": round(flops / n / 1e9, 3),
+                "share_of_step": round(ms / args.steps / ms_per_step, 3),
+                "wgrad": {"achieved": round(fw / (msw * 1e-3) / 1e12, 2), "launches_per_step": nw // args.steps,
+                          "share_of_step": round(msw / args.steps / ms_per_step, 3)}}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.phi, args.size, args.cpu_batch, 0)
+
+    if rank == 0:
+        line = {"metric": "images/sec fwd+bwd, 512x512 img+4ch radar, bs=8/GPU", "value": round(value, 3),
+                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"EfficientVRNet(phi={args.phi}) forward+backward, {args.size}x{args.size} image + "
+                                       f"4x{args.size}x{args.size} radar, bs={args.batch}/GPU, fp32, det+seg heads "
+                                       "(BASELINE.json configs[1]); random weights",
+                           "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}"},
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

