@@ -99,15 +99,19 @@ def empty(*shape, dtype=torch.float32, like=None, device=None):
 
 
 class Workspace:
-    """Grow-only scratch arena (bytes) per device; the caching allocator keeps it alive."""
+    """Grow-only scratch arena (bytes) per device.  Outgrown arenas are retired, never freed: a captured
+    HIP graph may still reference them."""
 
     def __init__(self):
         self.buf = {}
+        self.retired = []
 
     def get(self, nbytes, device):
         b = self.buf.get(device)
         if b is None or b.numel() < nbytes:
-            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            if b is not None:
+                self.retired.append(b)
+            b = torch.empty(max(int(nbytes) * 2, 8 << 20), dtype=torch.uint8, device=device)
             self.buf[device] = b
         return b
 

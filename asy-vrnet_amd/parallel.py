@@ -27,6 +27,7 @@ class GradBucketer:
     def __init__(self, params_in_backward_order, bucket_bytes=32 << 20, process_group=None, average=True):
         self.group = process_group
         self.average = average
+        self.deferred = False      # True: no collective inside backward (HIP-graph capture); call allreduce_all()
         self.params = [p for p in params_in_backward_order if p.requires_grad and p.numel() > 0]
         self.bucket_of, self.views, self.buckets, self.pending0 = {}, {}, [], []
         cur, cur_bytes = [], 0
@@ -70,6 +71,8 @@ class GradBucketer:
             self._launch(bi)
 
     def _launch(self, bi):
+        if self.deferred:
+            return
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return
         flat = self.buckets[bi]
@@ -96,6 +99,25 @@ class GradBucketer:
         for p in self.params:
             p.grad = self.views[p]
         self.reset()
+
+
+def _allreduce_all(self):
+    """Deferred mode: all buckets at once, after the captured step has been replayed."""
+    was, self.deferred = self.deferred, False
+    try:
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        ws = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        for w, scale in self.works:
+            w.wait()
+            if scale is not None:
+                scale.div_(ws)
+        self.works = []
+    finally:
+        self.deferred = was
+
+
+GradBucketer.allreduce_all = _allreduce_all
 
 
 def backward_param_order(model):

@@ -116,6 +116,11 @@ def take_grad(act):
     return g
 
 
+def tape_fn(fn):
+    """Marks a backward closure; closures return early when their output got no gradient."""
+    return fn
+
+
 # ----------------------------------------------------------------------------------------- conv helpers
 def conv_geom(x, conv):
     co, ci, kh, kw = conv.weight.shape
@@ -173,6 +178,8 @@ def simple_conv(rt, x, conv, out=None):
 
     def bwd():
         g = take_grad(y)
+        if g is None:
+            return
         conv_backward(rt, x, conv, g, y.C)
     rt.push(bwd)
     return y
@@ -254,6 +261,8 @@ def base_conv(rt, x, m, out=None):
 
     def bwd():
         g = take_grad(y)
+        if g is None:
+            return
         dz = bn_backward(rt, m.bn, z, ms, g, y.C, mask=y)
         conv_backward(rt, x, conv, dz, co)
     rt.push(bwd)
@@ -272,6 +281,8 @@ def ds_base_conv(rt, x, m, out=None):
 
     def bwd():
         g = take_grad(y)
+        if g is None:
+            return
         dz = bn_backward(rt, m.bn, z, ms, g, y.C, mask=y)
         conv_backward(rt, t, pconv, dz, z.C)
         dt = take_grad(t)
@@ -317,6 +328,8 @@ def cluster_block(rt, x, m, name=None):
 
     def bwd():
         dx2 = take_grad(x2)                                      # owned; becomes dx1, then dx
+        if dx2 is None:
+            return
         # ---- MLP branch
         ls2 = m.layer_scale_2
         mom2 = hip.moments(dx2, C, B, H * W, C, x2=t2.t, ldx2=C)
@@ -384,6 +397,8 @@ def image_enhance(rt, x, r, m):
 
     def bwd():
         g = take_grad(y)
+        if g is None:
+            return
         dt = bn_backward(rt, m.norm, t, ms2, g, C)
         dp = rt.buf(B, H, W, C)
         if x.need_grad:
@@ -409,6 +424,8 @@ def shuffle_attention(rt, x, m):
 
     def bwd():
         g = take_grad(y)
+        if g is None:
+            return
         plist = (m.cweight, m.cbias, m.sweight, m.sbias, m.gn.weight, m.gn.bias)
         grads, acc = [], 0
         for prm in plist:
@@ -448,6 +465,8 @@ def cat2(rt, a, b, interleave):
 
     def bwd():
         g = take_grad(out)
+        if g is None:
+            return
         ga, gb = g, (g[..., 1:] if cs == 2 else g[..., a.C:])
         for src, act in ((ga, a), (gb, b)):
             if act.need_grad:
@@ -470,6 +489,8 @@ def eca(rt, x, m):
 
     def bwd():
         g = take_grad(y)
+        if g is None:
+            return
         mom2 = hip.moments(g, C, B, HW, C, x2=x.t, ldx2=x.ld)
         Fc = rt.buf(B, C)
         gw, acc = rt.pgrad(m.conv.weight)
@@ -500,6 +521,8 @@ def radar_enhance(rt, x, r, m):
 
     def bwd():
         g = take_grad(y)
+        if g is None:
+            return
         ds = bn_backward(rt, m.norm, s, ms2, g, C)
         dz = bn_backward(rt, bn1, z, ms1, ds, C, mask=q)
         rt.give_grad(r, ds)                                       # long residual path (+ radar_map)
@@ -522,6 +545,8 @@ def coc_upsample(rt, x, m, nchw_out=None):
 
     def bwd():
         g = take_grad(hi)
+        if g is None:
+            return
         buf, acc = rt.grad_target(lo)
         hip.upsample_bwd(g, C, 0, buf, C, B, H, W, C, s, accumulate=acc)
     rt.push(bwd)
@@ -561,6 +586,8 @@ def aspp(rt, x, m):
 
     def bwd():
         g = take_grad(y)
+        if g is None:
+            return
         dzc = bn_backward(rt, bnc, zc, msc, g, C, mask=y)
         conv_backward(rt, cat, convc, dzc, C)
         dcat = take_grad(cat)
@@ -602,6 +629,8 @@ def backbone_forward(rt, bb, x, r):
 
         def bwd(cat=cat, act=act, C=C):
             g = take_grad(cat)
+            if g is None:
+                return
             if act.need_grad:
                 buf, acc = rt.grad_target(act)
                 hip.copy_channels(g, C + 2, 1, buf, C, 1, act.rows, C, accumulate=acc)
@@ -733,6 +762,7 @@ class _VRNetFunction(torch.autograd.Function):
         else:
             for i, p in enumerate(ctx.params):
                 outs.append(rt.pgrads.get(p) if ctx.needs_input_grad[3 + i] else None)
+        rt.pgrads.clear()
         ctx.rt = ctx.recs = ctx.seg_lo = ctx.inputs = None
         return tuple(outs)
 

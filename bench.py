@@ -89,7 +89,10 @@ def cpu_baseline(phi, size, batch, seed_sd):
     """Oracle fwd+bwd on the host cores: a bounded sample of the same workload."""
     from oracle import vrnet_oracle as O
     import asy_vrnet_amd as A
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:                                        # cores this process may actually use (cgroup / affinity aware)
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0)))))
+    except AttributeError:
+        pass
     m = A.EfficientVRNet(4, 9, phi, img_size=size)
     A.randomize_state_dict(m.state_dict(), seed=seed_sd)
     pn = {k for k, _ in m.named_parameters()}
@@ -121,6 +124,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,12 +146,28 @@ def main():
     net = DataParallelVRNet(model) if world > 1 else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 
-    def step(i):
+    def eager_step(i):
         x, r = batches[i]
         if world == 1:
             model.zero_grad(set_to_none=True)
         det, seg = net(x, r)
         loss_of(det, seg).backward()
+
+    launch = "eager"
+    step = eager_step
+    if not args.no_graph:
+        try:
+            from asy_vrnet_amd.graph import GraphedStep
+            gs = GraphedStep(net, loss_of, args.batch, args.size, dev)
+            launch = "hipgraph"
+
+            def step(i):
+                gs(*batches[i])
+        except Exception as e:                      # capture unsupported: fall back to eager launches
+            print(f"hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            bk = getattr(model, "_grad_bucketer", None)
+            if bk is not None:
+                bk.deferred = False
 
     def fence():
         torch.cuda.synchronize()
@@ -174,7 +194,7 @@ def main():
     if not args.no_roofline:
         with ConvTimer(hip) as ct:
             for i in range(args.steps):
-                step(args.warmup + i)
+                eager_step(args.warmup + i)
             n, flops, ms = ct.summary("igemm")
             nw, fw, msw = ct.summary("wgrad")
         ach = flops / (ms * 1e-3) / 1e12
@@ -198,7 +218,7 @@ def main():
                 "config": {"workload": f"EfficientVRNet(phi={args.phi}) forward+backward, {args.size}x{args.size} image + "
                                        f"4x{args.size}x{args.size} radar, bs={args.batch}/GPU, fp32, det+seg heads "
                                        "(BASELINE.json configs[1]); random weights",
-                           "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}"},
+                           "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}", "launch": launch},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line))
     if world > 1:
