@@ -25,31 +25,38 @@ struct IgemmArgs {
   const float* aux; long ldaux;
   int M, MH, MW, SH, SW, CK, CN;
   int kh, kw, stride, pad, dil;
-  int mode, act, a_vec, b_vec;
+  int mode, act, a_vec, b_vec, e_vec;
   int out_nchw, out_ctot, out_coff, accumulate;
   long wtap;   // Cout*Cin
   int Cin;
 };
 
-constexpr int BM = 128, BK = 16;
+constexpr int BK = 16;
+constexpr int STAGE_LD = 36;                       // epilogue staging tile: 32 rows x 36 floats per wave
 
-template <int BN, int TM, int TN, int WM, int WN>
+template <int BM, int BN, int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
-  __shared__ float As[BK][BM + 4];
-  __shared__ float Bs[BK][BN + 4];
+  constexpr int AS_FLOATS = BK * (BM + 4), BS_FLOATS = BK * (BN + 4);
+  constexpr int SM_FLOATS = (AS_FLOATS + BS_FLOATS) > 4 * 32 * STAGE_LD ? (AS_FLOATS + BS_FLOATS) : 4 * 32 * STAGE_LD;
+  __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+  float (*As)[BM + 4] = reinterpret_cast<float (*)[BM + 4]>(smem);
+  float (*Bs)[BN + 4] = reinterpret_cast<float (*)[BN + 4]>(smem + AS_FLOATS);
+  constexpr int AROWS = BM / 64;                   // A rows per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int nkb = (p.CK + BK - 1) / BK;
-  const int nsteps = p.kh * p.kw * nkb;
+  const int T = p.kh * p.kw;
+  __shared__ unsigned tapmask_s;
+  __shared__ unsigned char taps_s[32];
 
   // ---- A-side: each thread owns rows (tid>>2) and (tid>>2)+64, k-quad tid&3
   const int kq = tid & 3;
-  int a_b[2], a_y[2], a_x[2];
-  bool a_ok[2];
+  int a_b[AROWS], a_y[AROWS], a_x[AROWS];
+  bool a_ok[AROWS];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < AROWS; ++i) {
     const int m = m0 + (tid >> 2) + 64 * i;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
@@ -58,29 +65,62 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     a_y[i] = q % p.MH;
     a_b[i] = q / p.MH;
   }
+  auto src_of = [&](int i, int ky, int kx, int& sy, int& sx) -> bool {
+    bool ok = a_ok[i];
+    if (p.mode == 0) {
+      sy = a_y[i] * p.stride - p.pad + ky * p.dil;
+      sx = a_x[i] * p.stride - p.pad + kx * p.dil;
+    } else {
+      const int ty = a_y[i] + p.pad - ky * p.dil, tx = a_x[i] + p.pad - kx * p.dil;
+      ok = ok && ty >= 0 && tx >= 0 && (ty % p.stride) == 0 && (tx % p.stride) == 0;
+      sy = ty / p.stride;
+      sx = tx / p.stride;
+    }
+    return ok && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
+  };
+  // Taps that are invalid for every row of this tile (padding of dilated convs on small maps, the stride
+  // phases of a strided data gradient) are dropped from the K loop: block-uniform list of live taps.
+  int ntaps = T;
+  if (T > 1 && T <= 32) {
+    if (tid == 0) tapmask_s = 0u;
+    __syncthreads();
+    unsigned mine = 0u;
+    for (int t = 0; t < T; ++t) {
+      const int ky = t / p.kw, kx = t - ky * p.kw;
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        int sy, sx;
+        if (src_of(i, ky, kx, sy, sx)) mine |= 1u << t;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine |= (unsigned)__shfl_xor((int)mine, o, 64);
+    if (lane == 0 && mine) atomicOr(&tapmask_s, mine);
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned mk = tapmask_s;
+      int c = 0;
+      for (int t = 0; t < T; ++t)
+        if (mk & (1u << t)) taps_s[c++] = (unsigned char)t;
+    }
+    __syncthreads();
+    ntaps = __popc(tapmask_s);
+  }
+  const int nsteps = ntaps * nkb;
   constexpr int BROWS = (BN >= 64) ? BN / 64 : 1;     // NK loader: rows per thread
   constexpr int BVEC = (BN * BK / 4 + 255) / 256;     // KN loader: float4 per thread
 
-  f32x4 areg[2], breg[2];
+  f32x4 areg[AROWS], breg[2];
 
   auto load_tiles = [&](int s) {
-    const int t = s / nkb, c0 = (s - t * nkb) * BK;
+    const int ti = s / nkb, c0 = (s - ti * nkb) * BK;
+    const int t = (T > 1 && T <= 32) ? (int)taps_s[ti] : ti;
     const int ky = t / p.kw, kx = t - ky * p.kw;
     const int kc = c0 + 4 * kq;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AROWS; ++i) {
       int sy, sx;
-      bool ok = a_ok[i];
-      if (p.mode == 0) {
-        sy = a_y[i] * p.stride - p.pad + ky * p.dil;
-        sx = a_x[i] * p.stride - p.pad + kx * p.dil;
-      } else {
-        const int ty = a_y[i] + p.pad - ky * p.dil, tx = a_x[i] + p.pad - kx * p.dil;
-        ok = ok && ty >= 0 && tx >= 0 && (ty % p.stride) == 0 && (tx % p.stride) == 0;
-        sy = ty / p.stride;
-        sx = tx / p.stride;
-      }
-      ok = ok && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
+      const bool ok = src_of(i, ky, kx, sy, sx);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (ok) {
         const float* src = p.a + ((long)(a_b[i] * p.SH + sy) * p.SW + sx) * p.lda + kc;
@@ -141,7 +181,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AROWS; ++i) {
       const int r = (tid >> 2) + 64 * i;
 #pragma unroll
       for (int j = 0; j < 4; ++j) As[4 * kq + j][r] = areg[i][j];
@@ -177,7 +217,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   const int bcol = wn * TN * 32 + (lane & 31);
   const int khalf = lane >> 5;
 
-  load_tiles(0);
+  if (nsteps > 0) load_tiles(0);
   for (int s = 0; s < nsteps; ++s) {
     store_tiles();
     __syncthreads();
@@ -200,6 +240,56 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const long hw = (long)p.MH * p.MW;
+  if (p.e_vec) {
+    // Row-contiguous float4 epilogue: each wave transposes one 32x32 accumulator tile through its private
+    // LDS staging tile, then 8 lanes cover one 128-byte output row segment (aux / residual loads and all
+    // stores are whole lines).  The main loop ended with a barrier, so the operand images can be reused.
+    float* stage = smem + wave * (32 * STAGE_LD);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * STAGE_LD + (lane & 31)] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int q = lane + 64 * t;
+          const int row = q >> 3, c4 = (q & 7) * 4;
+          const int m = m0 + wm * TM * 32 + i * 32 + row;
+          const int n = n0 + wn * TN * 32 + j * 32 + c4;
+          if (m < p.M && n < p.CN) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * STAGE_LD + c4]);
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.aux) {
+              const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.ldaux + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= vr_gelu_grad(a[e]);
+            }
+            if (p.ypre) *reinterpret_cast<f32x4*>(p.ypre + (long)m * p.ldypre + n) = v;
+            if (p.act == 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.act == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = vr_gelu(v[e]);
+            }
+            if (p.res) {
+              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (long)m * p.ldres + n);
+              if (p.res_scale) v = rv + *reinterpret_cast<const f32x4*>(p.res_scale + n) * v;
+              else v = rv + v;
+            }
+            f32x4* dst = reinterpret_cast<f32x4*>(p.y + (long)m * p.ldy + n);
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
@@ -247,6 +337,7 @@ struct WgradArgs {
 
 template <int BN, int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+  constexpr int BM = 128;
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
   __shared__ float As[BK][BM + 4];   // dy tile, [m][n]
   __shared__ float Bs[BK][BN + 4];   // gathered x tile, [m][c]
@@ -414,6 +505,20 @@ __global__ void pack_weight_kernel(const float* w, float* out, int Cout, int Cin
 
 }  // namespace
 
+// tinyconv.hip
+int vr_tiny_conv(int mode, const float* a, long lda, const float* w, const float* bias, float* y, long ldy, int B, int H,
+                 int W, int Cin, int Cout, int k, int pad, int dil, int accumulate, hipStream_t st);
+long vr_tiny_wgrad_workspace(long npix, int Cin, int Cout, int T);
+int vr_tiny_wgrad(const float* x, long ldx, const float* dy, long lddy, float* dw, float* db, const float* row_scale,
+                  int B, int H, int W, int Cin, int Cout, int k, int pad, int dil, int accumulate, void* workspace,
+                  hipStream_t st);
+int vr_patch_dgrad(const float* dy, long lddy, const float* w, float* dx, long lddx, int B, int H, int W, int Cin,
+                   int Cout, int k, int accumulate, hipStream_t st);
+
+static bool tiny_shape(int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride) {
+  return Cin <= 8 && Cout <= 8 && stride == 1 && kh == kw && (kh == 1 || kh == 3) && OH == H && OW == W;
+}
+
 extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias, float* y, long ldy,
                                 int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride,
                                 int pad, int dil, int mode, int act, float* ypre, long ldypre, const float* res,
@@ -427,6 +532,13 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                    (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1 == OW,
                "conv2d: output size %dx%d inconsistent with input %dx%d k%d s%d p%d d%d", OH, OW, H, W, kh,
                stride, pad, dil);
+  const bool plain = !ypre && !res && !kscale && !aux && !out_nchw && act == 0;
+  if (plain && tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride))
+    return vr_tiny_conv(mode, a, lda, w, mode == 0 ? bias : nullptr, y, ldy, B, H, W, Cin, Cout, kh, pad, dil, accumulate,
+                        vr_stream(stream));
+  if (plain && mode == 1 && Cin <= 8 && kh == kw && kh == stride && pad == 0 && dil == 1 && H == OH * kh &&
+      W == OW * kw && (size_t)kh * kw * Cout * Cin * 4 <= 60000)
+    return vr_patch_dgrad(a, lda, w, y, ldy, B, H, W, Cin, Cout, kh, accumulate, vr_stream(stream));
   IgemmArgs p{};
   p.a = a; p.lda = lda; p.w = w; p.bias = bias; p.y = y; p.ldy = ldy;
   p.ypre = ypre; p.ldypre = ldypre; p.res = res; p.ldres = ldres; p.res_scale = res_scale;
@@ -443,19 +555,31 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   VR_CHECK_ARG(M < (1L << 31) && (long)B * p.SH * p.SW < (1L << 31), "conv2d: too many pixels");
   p.M = (int)M;
   VR_CHECK_ARG(lda >= p.CK && (out_nchw || ldy >= p.CN), "conv2d: row stride smaller than channel count");
-  p.a_vec = (p.CK % 4 == 0) && (lda % 4 == 0) && vr_aligned16(a) && (!kscale || true);
+  p.a_vec = (p.CK % 4 == 0) && (lda % 4 == 0) && vr_aligned16(a);
   p.b_vec = (Cin % 4 == 0) && vr_aligned16(w);
+  p.e_vec = !out_nchw && (p.CN % 4 == 0) && (ldy % 4 == 0) && vr_aligned16(y) &&
+            (!bias || vr_aligned16(bias)) && (!ypre || ((ldypre % 4 == 0) && vr_aligned16(ypre))) &&
+            (!res || ((ldres % 4 == 0) && vr_aligned16(res))) && (!res_scale || vr_aligned16(res_scale)) &&
+            (!aux || ((ldaux % 4 == 0) && vr_aligned16(aux)));
   dim3 block(256);
   hipStream_t st = vr_stream(stream);
-  if (p.CN > 64) {
-    dim3 grid(vr_cdiv(M, BM), vr_cdiv(p.CN, 128));
-    hipLaunchKernelGGL((igemm_kernel<128, 2, 2, 2, 2>), grid, block, 0, st, p);
-  } else if (p.CN > 32) {
-    dim3 grid(vr_cdiv(M, BM), 1);
-    hipLaunchKernelGGL((igemm_kernel<64, 2, 1, 2, 2>), grid, block, 0, st, p);
+  // Tile choice: 128-row tiles while they fill the chip (256 CUs x >= 2 workgroups); otherwise 64 x 64 tiles,
+  // which quadruple the workgroup count of the small-M layers (M = 2048 / 8192 at the 16x16 / 32x32 stages).
+  const long mt128 = vr_cdiv(M, 128);
+  const int bn128 = p.CN > 64 ? 128 : (p.CN > 32 ? 64 : 32);
+  const long blocks128 = mt128 * vr_cdiv(p.CN, bn128);
+  if (p.CN > 32 && blocks128 < 512) {
+    dim3 grid(vr_cdiv(M, 64), vr_cdiv(p.CN, 64));
+    hipLaunchKernelGGL((igemm_kernel<64, 64, 1, 1, 2, 2>), grid, block, 0, st, p);
+  } else if (bn128 == 128) {
+    dim3 grid(mt128, vr_cdiv(p.CN, 128));
+    hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 2, 2, 2>), grid, block, 0, st, p);
+  } else if (bn128 == 64) {
+    dim3 grid(mt128, 1);
+    hipLaunchKernelGGL((igemm_kernel<128, 64, 2, 1, 2, 2>), grid, block, 0, st, p);
   } else {
-    dim3 grid(vr_cdiv(M, BM), 1);
-    hipLaunchKernelGGL((igemm_kernel<32, 1, 1, 4, 1>), grid, block, 0, st, p);
+    dim3 grid(mt128, 1);
+    hipLaunchKernelGGL((igemm_kernel<128, 32, 1, 1, 4, 1>), grid, block, 0, st, p);
   }
   VR_LAUNCH_CHECK("conv2d");
   return VR_OK;
@@ -463,11 +587,13 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
 
 static void wgrad_plan(long M, int Cin, int Cout, int T, int* bn, int* n_tiles, int* c_tiles, int* S, int* rows) {
   *bn = Cin > 64 ? 128 : (Cin > 32 ? 64 : 32);
-  *n_tiles = (int)vr_cdiv(Cout, BM);
+  *n_tiles = (int)vr_cdiv(Cout, 128);
   *c_tiles = (int)vr_cdiv(Cin, *bn);
   const long tiles = (long)(*n_tiles) * (*c_tiles) * T;
-  long s = vr_cdiv(1024, tiles);
-  const long smax = vr_cdiv(M, 64);
+  // ~768 workgroups, but at least 512 contraction rows per workgroup: every split costs one slab of
+  // |dW| floats written and read back by the reduce pass.
+  long s = vr_cdiv(768, tiles);
+  const long smax = vr_cdiv(M, 512);
   if (s > smax) s = smax;
   if (s < 1) s = 1;
   long r = vr_cdiv(vr_cdiv(M, s), BK) * BK;
@@ -478,7 +604,12 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* bn, int* n_tiles, 
 extern "C" long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int Cout, int kh, int kw) {
   int bn, nt, ct, S, rows;
   wgrad_plan((long)B * OH * OW, Cin, Cout, kh * kw, &bn, &nt, &ct, &S, &rows);
-  return ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
+  long need = ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
+  if (Cin <= 8 && Cout <= 8) {
+    const long t = vr_tiny_wgrad_workspace((long)B * OH * OW, Cin, Cout, kh * kw);
+    if (t > need) need = t;
+  }
+  return need;
 }
 
 extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, float* dbias,
@@ -496,6 +627,9 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
     vr_set_error("conv2d_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
     return VR_ERR_WORKSPACE;
   }
+  if (tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride))
+    return vr_tiny_wgrad(x, ldx, dy, lddy, dw, dbias, row_scale, B, H, W, Cin, Cout, kh, pad, dil, accumulate, workspace,
+                         vr_stream(stream));
   WgradArgs p{};
   p.x = x; p.ldx = ldx; p.dy = dy; p.lddy = lddy;
   p.slab = reinterpret_cast<float*>(workspace);

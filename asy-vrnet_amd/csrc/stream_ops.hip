@@ -428,9 +428,9 @@ static int moments_plan(long HW, int C, int vec, int* TPR, int* ncb, int* nchunk
   while (t < CV && t < 256) t <<= 1;
   *TPR = t;
   *ncb = (int)vr_cdiv(CV, t);
-  long nc = vr_cdiv(HW * C, 8192);
+  long nc = vr_cdiv(HW * C, 16384);   // >= 64 elements per thread; the cross-chunk reduce is serial per output
   if (nc < 1) nc = 1;
-  if (nc > 1024) nc = 1024;
+  if (nc > 96) nc = 96;
   if (nc > HW) nc = HW;
   *rows = vr_cdiv(HW, nc);
   *nchunks = (int)vr_cdiv(HW, *rows);
