@@ -34,25 +34,28 @@ struct IgemmArgs {
 constexpr int BK = 16;
 constexpr int STAGE_LD = 36;                       // epilogue staging tile: 32 rows x 36 floats per wave
 
-template <int BM, int BN, int TM, int TN, int WM, int WN>
+template <int BM, int BN, int TM, int TN, int WM, int WN, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
   constexpr int AS_FLOATS = BK * (BM + 4), BS_FLOATS = BK * (BN + 4);
   constexpr int SM_FLOATS = (AS_FLOATS + BS_FLOATS) > 4 * 32 * STAGE_LD ? (AS_FLOATS + BS_FLOATS) : 4 * 32 * STAGE_LD;
   __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+  __shared__ unsigned tapmask_s;
+  __shared__ unsigned char taps_s[32];
   float (*As)[BM + 4] = reinterpret_cast<float (*)[BM + 4]>(smem);
   float (*Bs)[BN + 4] = reinterpret_cast<float (*)[BN + 4]>(smem + AS_FLOATS);
-  constexpr int AROWS = BM / 64;                   // A rows per thread
+  constexpr int AROWS = BM / 64;                      // A rows per thread
+  constexpr int BROWS = (BN >= 64) ? BN / 64 : 1;     // NK loader (MODE 0): rows per thread
+  constexpr int BVEC = (BN * BK / 4 + 255) / 256;     // KN loader (MODE 1): float4 per thread
+  constexpr int BSLOTS = MODE == 0 ? BROWS : BVEC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int nkb = (p.CK + BK - 1) / BK;
   const int T = p.kh * p.kw;
-  __shared__ unsigned tapmask_s;
-  __shared__ unsigned char taps_s[32];
-
-  // ---- A-side: each thread owns rows (tid>>2) and (tid>>2)+64, k-quad tid&3
   const int kq = tid & 3;
+
+  // ---- A-side: each thread owns rows (tid>>2) [+64], k-quad tid&3.  Pixel decomposition once per kernel.
   int a_b[AROWS], a_y[AROWS], a_x[AROWS];
   bool a_ok[AROWS];
 #pragma unroll
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   }
   auto src_of = [&](int i, int ky, int kx, int& sy, int& sx) -> bool {
     bool ok = a_ok[i];
-    if (p.mode == 0) {
+    if (MODE == 0) {
       sy = a_y[i] * p.stride - p.pad + ky * p.dil;
       sx = a_x[i] * p.stride - p.pad + kx * p.dil;
     } else {
@@ -81,7 +84,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   // Taps that are invalid for every row of this tile (padding of dilated convs on small maps, the stride
   // phases of a strided data gradient) are dropped from the K loop: block-uniform list of live taps.
   int ntaps = T;
-  if (T > 1 && T <= 32) {
+  const bool use_list = T > 1 && T <= 32;
+  if (use_list) {
     if (tid == 0) tapmask_s = 0u;
     __syncthreads();
     unsigned mine = 0u;
@@ -107,31 +111,54 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     ntaps = __popc(tapmask_s);
   }
   const int nsteps = ntaps * nkb;
-  constexpr int BROWS = (BN >= 64) ? BN / 64 : 1;     // NK loader: rows per thread
-  constexpr int BVEC = (BN * BK / 4 + 255) / 256;     // KN loader: float4 per thread
 
-  f32x4 areg[AROWS], breg[2];
-
-  auto load_tiles = [&](int s) {
-    const int ti = s / nkb, c0 = (s - ti * nkb) * BK;
-    const int t = (T > 1 && T <= 32) ? (int)taps_s[ti] : ti;
+  // ---- per-tap operand pointers (hoisted out of the K loop): row bases, nullptr = masked
+  const float* a_ptr[AROWS];
+  const float* b_ptr[BSLOTS];
+  auto setup_tap = [&](int t) {
     const int ky = t / p.kw, kx = t - ky * p.kw;
-    const int kc = c0 + 4 * kq;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       int sy, sx;
       const bool ok = src_of(i, ky, kx, sy, sx);
+      a_ptr[i] = ok ? p.a + ((long)(a_b[i] * p.SH + sy) * p.SW + sx) * p.lda : nullptr;
+    }
+    const float* wt = p.w + (long)t * p.wtap;
+    if (MODE == 0) {              // B[k = c][n] = w[t][n][c]: rows n, contiguous contraction
+#pragma unroll
+      for (int i = 0; i < BSLOTS; ++i) {
+        const int n = (tid >> 2) + 64 * i;
+        b_ptr[i] = (n < BN && n0 + n < p.CN) ? wt + (long)(n0 + n) * p.Cin : nullptr;
+      }
+    } else {                      // B[k = n'][j = c] = w[t][n'][c]: rows = contraction, contiguous output col
+#pragma unroll
+      for (int i = 0; i < BSLOTS; ++i) {
+        const int idx = tid + 256 * i;
+        const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
+        const int col = n0 + 4 * cq;
+        b_ptr[i] = (kr < BK && col < p.CN) ? wt + (long)kr * p.Cin + col : nullptr;
+      }
+    }
+  };
+
+  f32x4 areg[AROWS], breg[BSLOTS];
+  int ld_ti = 0, ld_kb = 0;        // (tap index, k block) of the NEXT tile to load
+  auto load_tiles = [&]() {
+    if (ld_kb == 0) setup_tap(use_list ? (int)taps_s[ld_ti] : ld_ti);
+    const int c0 = ld_kb * BK;
+    const int kc = c0 + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const float* src = p.a + ((long)(a_b[i] * p.SH + sy) * p.SW + sx) * p.lda + kc;
-        if (p.a_vec) {
-          if (kc < p.CK) v = *reinterpret_cast<const f32x4*>(src);
+      if (a_ptr[i] != nullptr && kc < p.CK) {
+        if (VEC) {
+          v = *reinterpret_cast<const f32x4*>(a_ptr[i] + kc);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (kc + j < p.CK) v[j] = src[j];
+            if (kc + j < p.CK) v[j] = a_ptr[i][kc + j];
         }
-        if (p.kscale) {
+        if (MODE == 1 && p.kscale) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (kc + j < p.CK) v[j] *= p.kscale[kc + j];
@@ -139,36 +166,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
       }
       areg[i] = v;
     }
-    const float* wt = p.w + (long)t * p.wtap;
-    if (p.mode == 0) {            // B[k = c][n] = w[t][n][c]: rows n, contiguous contraction
+    if (MODE == 0) {
 #pragma unroll
-      for (int i = 0; i < BROWS; ++i) {
-        const int n = (tid >> 2) + 64 * i;
+      for (int i = 0; i < BSLOTS; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < BN && n0 + n < p.CN) {
-          const float* src = wt + (long)(n0 + n) * p.Cin + kc;
-          if (p.b_vec) {
-            if (kc < p.CK) v = *reinterpret_cast<const f32x4*>(src);
+        if (b_ptr[i] != nullptr && kc < p.CK) {
+          if (VEC) {
+            v = *reinterpret_cast<const f32x4*>(b_ptr[i] + kc);
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (kc + j < p.CK) v[j] = src[j];
+              if (kc + j < p.CK) v[j] = b_ptr[i][kc + j];
           }
         }
         breg[i] = v;
       }
-    } else {                      // B[k = n'][j = c] = w[t][n'][c]: rows = contraction, contiguous output col
+    } else {
 #pragma unroll
-      for (int i = 0; i < BVEC; ++i) {
+      for (int i = 0; i < BSLOTS; ++i) {
         const int idx = tid + 256 * i;
         const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kr < BK && c0 + kr < p.CK) {
-          const int col = n0 + 4 * cq;
-          const float* src = wt + (long)(c0 + kr) * p.Cin + col;
-          if (p.b_vec) {
-            if (col < p.CN) v = *reinterpret_cast<const f32x4*>(src);
+        if (b_ptr[i] != nullptr && c0 + kr < p.CK) {
+          const float* src = b_ptr[i] + (long)c0 * p.Cin;
+          if (VEC) {
+            v = *reinterpret_cast<const f32x4*>(src);
           } else {
+            const int col = n0 + 4 * cq;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
               if (col + j < p.CN) v[j] = src[j];
@@ -176,6 +200,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
         }
         breg[i] = v;
       }
+    }
+    if (++ld_kb == nkb) {
+      ld_kb = 0;
+      ++ld_ti;
     }
   };
 
@@ -186,9 +214,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) As[4 * kq + j][r] = areg[i][j];
     }
-    if (p.mode == 0) {
+    if (MODE == 0) {
 #pragma unroll
-      for (int i = 0; i < BROWS; ++i) {
+      for (int i = 0; i < BSLOTS; ++i) {
         const int n = (tid >> 2) + 64 * i;
         if (n < BN) {
 #pragma unroll
@@ -197,7 +225,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < BVEC; ++i) {
+      for (int i = 0; i < BSLOTS; ++i) {
         const int idx = tid + 256 * i;
         const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
         if (kr < BK) *reinterpret_cast<f32x4*>(&Bs[kr][4 * cq]) = breg[i];
@@ -217,11 +245,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   const int bcol = wn * TN * 32 + (lane & 31);
   const int khalf = lane >> 5;
 
-  if (nsteps > 0) load_tiles(0);
+  if (nsteps > 0) load_tiles();
   for (int s = 0; s < nsteps; ++s) {
     store_tiles();
     __syncthreads();
-    if (s + 1 < nsteps) load_tiles(s + 1);
+    if (s + 1 < nsteps) load_tiles();
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       float af[TM], bf[TN];
@@ -568,19 +596,31 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   const long mt128 = vr_cdiv(M, 128);
   const int bn128 = p.CN > 64 ? 128 : (p.CN > 32 ? 64 : 32);
   const long blocks128 = mt128 * vr_cdiv(p.CN, bn128);
+  const bool vec = p.a_vec && p.b_vec;
+#define VR_IGEMM(BM_, BN_, TM_, TN_, WM_, WN_, GRID)                                                              \
+  do {                                                                                                            \
+    if (mode == 0) {                                                                                              \
+      if (vec) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, TM_, TN_, WM_, WN_, 0, true>), GRID, block, 0, st, p);  \
+      else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, TM_, TN_, WM_, WN_, 0, false>), GRID, block, 0, st, p);     \
+    } else {                                                                                                      \
+      if (vec) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, TM_, TN_, WM_, WN_, 1, true>), GRID, block, 0, st, p);  \
+      else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, TM_, TN_, WM_, WN_, 1, false>), GRID, block, 0, st, p);     \
+    }                                                                                                             \
+  } while (0)
   if (p.CN > 32 && blocks128 < 512) {
     dim3 grid(vr_cdiv(M, 64), vr_cdiv(p.CN, 64));
-    hipLaunchKernelGGL((igemm_kernel<64, 64, 1, 1, 2, 2>), grid, block, 0, st, p);
+    VR_IGEMM(64, 64, 1, 1, 2, 2, grid);
   } else if (bn128 == 128) {
     dim3 grid(mt128, vr_cdiv(p.CN, 128));
-    hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 2, 2, 2>), grid, block, 0, st, p);
+    VR_IGEMM(128, 128, 2, 2, 2, 2, grid);
   } else if (bn128 == 64) {
     dim3 grid(mt128, 1);
-    hipLaunchKernelGGL((igemm_kernel<128, 64, 2, 1, 2, 2>), grid, block, 0, st, p);
+    VR_IGEMM(128, 64, 2, 1, 2, 2, grid);
   } else {
     dim3 grid(mt128, 1);
-    hipLaunchKernelGGL((igemm_kernel<128, 32, 1, 1, 4, 1>), grid, block, 0, st, p);
+    VR_IGEMM(128, 32, 1, 1, 4, 1, grid);
   }
+#undef VR_IGEMM
   VR_LAUNCH_CHECK("conv2d");
   return VR_OK;
 }

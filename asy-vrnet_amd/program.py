@@ -759,9 +759,21 @@ class _VRNetFunction(torch.autograd.Function):
         if rt.bucketer is not None:          # data parallel: buckets own the gradients (all-reduced, then .grad = view)
             rt.bucketer.finish()
             outs.extend([None] * len(ctx.params))
-        else:
-            for i, p in enumerate(ctx.params):
+        elif getattr(model, "autograd_param_grads", False):
+            for i, p in enumerate(ctx.params):      # through autograd (AccumulateGrad clones each buffer once)
                 outs.append(rt.pgrads.get(p) if ctx.needs_input_grad[3 + i] else None)
+        else:
+            # Default: publish parameter gradients directly (.grad = buffer, or += into an existing .grad, as
+            # loss.backward() would) -- saves one copy of every gradient per step.  Set
+            # model.autograd_param_grads = True to receive them through torch.autograd.grad instead.
+            for i, p in enumerate(ctx.params):
+                g = rt.pgrads.get(p) if ctx.needs_input_grad[3 + i] else None
+                if g is not None:
+                    if p.grad is None:
+                        p.grad = g
+                    else:
+                        hip.add_(p.grad, g)
+            outs.extend([None] * len(ctx.params))
         rt.pgrads.clear()
         ctx.rt = ctx.recs = ctx.seg_lo = ctx.inputs = None
         return tuple(outs)
