@@ -360,15 +360,14 @@ struct WgradArgs {
   int M, OH, OW, H, W, Cin, Cout;
   int kh, kw, stride, pad, dil;
   int rows_per_split, n_tiles, c_tiles;
-  int x_vec, dy_vec;
 };
 
-template <int BN, int TM, int TN, int WM, int WN>
+// IDENT: 1x1 / stride 1 / pad 0 -- the gathered x row of output pixel m is row m itself (no index math).
+template <int BM, int BN, int TM, int TN, int WM, int WN, bool IDENT, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
-  constexpr int BM = 128;
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
-  __shared__ float As[BK][BM + 4];   // dy tile, [m][n]
-  __shared__ float Bs[BK][BN + 4];   // gathered x tile, [m][c]
+  __shared__ __attribute__((aligned(16))) float As[BK][BM + 4];   // dy tile, [m][n]
+  __shared__ __attribute__((aligned(16))) float Bs[BK][BN + 4];   // gathered x tile, [m][c]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   int bid = blockIdx.x;
@@ -380,49 +379,68 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
   const int split = blockIdx.y;
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
+  constexpr int AVEC = (BM * BK / 4 + 255) / 256;
   constexpr int BVEC = (BN * BK / 4 + 255) / 256;
-  f32x4 areg[2], breg[BVEC];
+  f32x4 areg[AVEC], breg[BVEC];
   const bool do_bias = p.bslab != nullptr && ct == 0 && t == 0;
   float bsum = 0.f;
+  // per-thread fixed (row-in-tile, column) slots
+  int a_kr[AVEC], a_col[AVEC], b_kr[BVEC], b_col[BVEC];
+#pragma unroll
+  for (int i = 0; i < AVEC; ++i) {
+    const int idx = tid + 256 * i;
+    a_kr[i] = idx / (BM / 4);
+    a_col[i] = n0 + 4 * (idx - a_kr[i] * (BM / 4));
+  }
+#pragma unroll
+  for (int i = 0; i < BVEC; ++i) {
+    const int idx = tid + 256 * i;
+    b_kr[i] = idx / (BN / 4);
+    b_col[i] = c0 + 4 * (idx - b_kr[i] * (BN / 4));
+  }
 
   auto load_tiles = [&](int mb) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i;
-      const int kr = idx >> 5, cq = idx & 31;
-      const int m = mb + kr, col = n0 + 4 * cq;
+    for (int i = 0; i < AVEC; ++i) {
+      const int m = mb + a_kr[i];
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end) {
-        const float* src = p.dy + (long)m * p.lddy + col;
-        if (p.dy_vec) {
-          if (col < p.Cout) v = *reinterpret_cast<const f32x4*>(src);
+      if (a_kr[i] < BK && m < m_end && a_col[i] < p.Cout) {
+        const float* src = p.dy + (long)m * p.lddy + a_col[i];
+        if (VEC) {
+          v = *reinterpret_cast<const f32x4*>(src);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (col + j < p.Cout) v[j] = src[j];
+            if (a_col[i] + j < p.Cout) v[j] = src[j];
         }
       }
       areg[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < BVEC; ++i) {
-      const int idx = tid + 256 * i;
-      const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int m = mb + kr, col = c0 + 4 * cq;
-      if (kr < BK && m < m_end) {
-        const int ox = m % p.OW;
-        const int q = m / p.OW;
-        const int oy = q % p.OH, b = q / p.OH;
-        const int sy = oy * p.stride - p.pad + ky * p.dil, sx = ox * p.stride - p.pad + kx * p.dil;
-        if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) {
-          const float* src = p.x + ((long)(b * p.H + sy) * p.W + sx) * p.ldx + col;
-          if (p.x_vec) {
-            if (col < p.Cin) v = *reinterpret_cast<const f32x4*>(src);
+      const int m = mb + b_kr[i];
+      if (b_kr[i] < BK && m < m_end && b_col[i] < p.Cin) {
+        long row;
+        bool ok = true;
+        if (IDENT) {
+          row = m;
+        } else {
+          const int ox = m % p.OW;
+          const int q = m / p.OW;
+          const int oy = q % p.OH, b = q / p.OH;
+          const int sy = oy * p.stride - p.pad + ky * p.dil, sx = ox * p.stride - p.pad + kx * p.dil;
+          ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+          row = (long)(b * p.H + sy) * p.W + sx;
+        }
+        if (ok) {
+          const float* src = p.x + row * p.ldx + b_col[i];
+          if (VEC) {
+            v = *reinterpret_cast<const f32x4*>(src);
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (col + j < p.Cin) v[j] = src[j];
+              if (b_col[i] + j < p.Cin) v[j] = src[j];
           }
         }
       }
@@ -431,16 +449,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
   };
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i;
-      *reinterpret_cast<f32x4*>(&As[idx >> 5][4 * (idx & 31)]) = areg[i];
-    }
+    for (int i = 0; i < AVEC; ++i)
+      if (a_kr[i] < BK) *reinterpret_cast<f32x4*>(&As[a_kr[i]][a_col[i] - n0]) = areg[i];
 #pragma unroll
-    for (int i = 0; i < BVEC; ++i) {
-      const int idx = tid + 256 * i;
-      const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
-      if (kr < BK) *reinterpret_cast<f32x4*>(&Bs[kr][4 * cq]) = breg[i];
-    }
+    for (int i = 0; i < BVEC; ++i)
+      if (b_kr[i] < BK) *reinterpret_cast<f32x4*>(&Bs[b_kr[i]][b_col[i] - c0]) = breg[i];
   };
 
   f32x16 acc[TM][TN];
@@ -625,25 +638,41 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   return VR_OK;
 }
 
-static void wgrad_plan(long M, int Cin, int Cout, int T, int* bn, int* n_tiles, int* c_tiles, int* S, int* rows) {
-  *bn = Cin > 64 ? 128 : (Cin > 32 ? 64 : 32);
-  *n_tiles = (int)vr_cdiv(Cout, 128);
-  *c_tiles = (int)vr_cdiv(Cin, *bn);
-  const long tiles = (long)(*n_tiles) * (*c_tiles) * T;
-  // ~768 workgroups, but at least 512 contraction rows per workgroup: every split costs one slab of
-  // |dW| floats written and read back by the reduce pass.
-  long s = vr_cdiv(768, tiles);
-  const long smax = vr_cdiv(M, 512);
-  if (s > smax) s = smax;
-  if (s < 1) s = 1;
-  long r = vr_cdiv(vr_cdiv(M, s), BK) * BK;
-  *rows = (int)r;
-  *S = (int)vr_cdiv(M, r);
+// Tile + split plan.  cfg 0: 128 x {128,64,32} tiles; cfg 1: 64 x 64 tiles (more workgroups for the
+// small-M stages).  Every split costs one slab of |dW| floats written and read back by the reduce pass,
+// so splits are bounded by >= 128 contraction rows each and <= 48 MB of slabs.
+static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int* n_tiles, int* c_tiles, int* S,
+                       int* rows) {
+  const long wsz = (long)T * Cout * Cin;
+  auto splits = [&](long tiles) {
+    long s = vr_cdiv(1024, tiles);
+    const long smax = vr_cdiv(M, 128);
+    if (s > smax) s = smax;
+    const long sbytes = (48L << 20) / (wsz * 4);
+    if (s > sbytes) s = sbytes;
+    return s < 1 ? 1 : s;
+  };
+  const int bn128 = Cin > 64 ? 128 : (Cin > 32 ? 64 : 32);
+  const long tiles128 = vr_cdiv(Cout, 128) * vr_cdiv(Cin, bn128) * T;
+  const long s128 = splits(tiles128);
+  const long tiles64 = vr_cdiv(Cout, 64) * vr_cdiv(Cin, 64) * T;
+  if (tiles128 * s128 < 512 && Cin > 32 && Cout > 32) {
+    *cfg = 1; *bn = 64;
+    *n_tiles = (int)vr_cdiv(Cout, 64); *c_tiles = (int)vr_cdiv(Cin, 64);
+    const long s = splits(tiles64);
+    const long r = vr_cdiv(vr_cdiv(M, s), BK) * BK;
+    *rows = (int)r; *S = (int)vr_cdiv(M, r);
+  } else {
+    *cfg = 0; *bn = bn128;
+    *n_tiles = (int)vr_cdiv(Cout, 128); *c_tiles = (int)vr_cdiv(Cin, bn128);
+    const long r = vr_cdiv(vr_cdiv(M, s128), BK) * BK;
+    *rows = (int)r; *S = (int)vr_cdiv(M, r);
+  }
 }
 
 extern "C" long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int Cout, int kh, int kw) {
-  int bn, nt, ct, S, rows;
-  wgrad_plan((long)B * OH * OW, Cin, Cout, kh * kw, &bn, &nt, &ct, &S, &rows);
+  int cfg, bn, nt, ct, S, rows;
+  wgrad_plan((long)B * OH * OW, Cin, Cout, kh * kw, &cfg, &bn, &nt, &ct, &S, &rows);
   long need = ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
   if (Cin <= 8 && Cout <= 8) {
     const long t = vr_tiny_wgrad_workspace((long)B * OH * OW, Cin, Cout, kh * kw);
@@ -660,8 +689,8 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   const long M = (long)B * OH * OW;
   VR_CHECK_ARG(M < (1L << 31) && (long)B * H * W < (1L << 31), "conv2d_wgrad: too many pixels");
   const int T = kh * kw;
-  int bn, nt, ct, S, rows;
-  wgrad_plan(M, Cin, Cout, T, &bn, &nt, &ct, &S, &rows);
+  int cfg, bn, nt, ct, S, rows;
+  wgrad_plan(M, Cin, Cout, T, &cfg, &bn, &nt, &ct, &S, &rows);
   const long need = vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw);
   if (workspace_bytes < need) {
     vr_set_error("conv2d_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
@@ -677,13 +706,22 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   p.M = (int)M; p.OH = OH; p.OW = OW; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
   p.rows_per_split = rows; p.n_tiles = nt; p.c_tiles = ct;
-  p.x_vec = (Cin % 4 == 0) && (ldx % 4 == 0) && vr_aligned16(x);
-  p.dy_vec = (Cout % 4 == 0) && (lddy % 4 == 0) && vr_aligned16(dy);
+  const bool vec = (Cin % 4 == 0) && (ldx % 4 == 0) && vr_aligned16(x) && (Cout % 4 == 0) && (lddy % 4 == 0) &&
+                   vr_aligned16(dy);
+  const bool ident = kh == 1 && kw == 1 && stride == 1 && pad == 0;
   hipStream_t st = vr_stream(stream);
   dim3 grid(nt * ct * T, S), block(256);
-  if (bn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 2, 2, 2, 2>), grid, block, 0, st, p);
-  else if (bn == 64) hipLaunchKernelGGL((wgrad_kernel<64, 2, 1, 2, 2>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((wgrad_kernel<32, 1, 1, 4, 1>), grid, block, 0, st, p);
+#define VR_WGRAD(BM_, BN_, TM_, TN_, WM_, WN_)                                                                      \
+  do {                                                                                                              \
+    if (ident && vec) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, TM_, TN_, WM_, WN_, true, true>), grid, block, 0, st, p);   \
+    else if (vec) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, TM_, TN_, WM_, WN_, false, true>), grid, block, 0, st, p);     \
+    else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, TM_, TN_, WM_, WN_, false, false>), grid, block, 0, st, p);             \
+  } while (0)
+  if (cfg == 1) VR_WGRAD(64, 64, 1, 1, 2, 2);
+  else if (bn == 128) VR_WGRAD(128, 128, 2, 2, 2, 2);
+  else if (bn == 64) VR_WGRAD(128, 64, 2, 1, 2, 2);
+  else VR_WGRAD(128, 32, 1, 1, 4, 1);
+#undef VR_WGRAD
   VR_LAUNCH_CHECK("conv2d_wgrad");
   const long total = (long)T * Cout * Cin + (dbias ? Cout : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(vr_cdiv(total, 256)), dim3(256), 0, st, p.slab, p.bslab, row_scale, dw,
