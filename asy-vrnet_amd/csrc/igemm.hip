@@ -12,6 +12,8 @@
 // Exact fp32: the MFMA is an fmaf chain in k order (guide: cdna_hip_programming.md section 3).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 struct IgemmArgs {
@@ -610,6 +612,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   const int bn128 = p.CN > 64 ? 128 : (p.CN > 32 ? 64 : 32);
   const long blocks128 = mt128 * vr_cdiv(p.CN, bn128);
   const bool vec = p.a_vec && p.b_vec;
+  static const int force_cfg = getenv("VRNET_IGEMM_CFG") ? atoi(getenv("VRNET_IGEMM_CFG")) : -1;   // tuning aid
 #define VR_IGEMM(BM_, BN_, TM_, TN_, WM_, WN_, GRID)                                                              \
   do {                                                                                                            \
     if (mode == 0) {                                                                                              \
@@ -620,9 +623,14 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
       else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, TM_, TN_, WM_, WN_, 1, false>), GRID, block, 0, st, p);     \
     }                                                                                                             \
   } while (0)
-  if (p.CN > 32 && blocks128 < 512) {
+  int cfg = (p.CN > 32 && blocks128 < 512) ? 2 : (bn128 == 128 ? 0 : (bn128 == 64 ? 1 : 3));
+  if (force_cfg >= 0 && p.CN > 32) cfg = (force_cfg == 0 && p.CN <= 64) ? 1 : force_cfg;
+  if (cfg == 2) {
     dim3 grid(vr_cdiv(M, 64), vr_cdiv(p.CN, 64));
     VR_IGEMM(64, 64, 1, 1, 2, 2, grid);
+  } else if (cfg == 1) {
+    dim3 grid(mt128, vr_cdiv(p.CN, 64));
+    VR_IGEMM(128, 64, 2, 1, 2, 2, grid);
   } else if (bn128 == 128) {
     dim3 grid(mt128, vr_cdiv(p.CN, 128));
     VR_IGEMM(128, 128, 2, 2, 2, 2, grid);
@@ -646,7 +654,11 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
   const long wsz = (long)T * Cout * Cin;
   auto splits = [&](long tiles) {
     long s = vr_cdiv(1024, tiles);
-    const long smax = vr_cdiv(M, 128);
+    // >= 512 rows per split on the big maps (the reduce pass is serial in S); down to 128 rows, at most 64
+    // splits, on the small ones (M <= 8192), which otherwise cannot fill the chip
+    long smax = vr_cdiv(M, 512);
+    const long small = vr_cdiv(M, 128) < 64 ? vr_cdiv(M, 128) : 64;
+    if (small > smax) smax = small;
     if (s > smax) s = smax;
     const long sbytes = (48L << 20) / (wsz * 4);
     if (s > sbytes) s = sbytes;
