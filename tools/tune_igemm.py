@@ -7,8 +7,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = sys.argv[1:]
 res = {}
-for cfg in (0, 1, 2):
-    env = dict(os.environ, VRNET_IGEMM_CFG=str(cfg))
+WG = "--wgrad" in args
+if WG:
+    args.remove("--wgrad")
+for cfg in ((0, 1) if WG else (0, 1, 2)):
+    env = dict(os.environ, **({"VRNET_WGRAD_CFG": str(cfg)} if WG else {"VRNET_IGEMM_CFG": str(cfg)}))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_kernels.py")] + args, env=env,
                          capture_output=True, text=True).stdout
     for line in out.splitlines():
@@ -16,13 +19,14 @@ for cfg in (0, 1, 2):
             continue
         f = line.split()
         key = " ".join(f[5:])
-        if f[5] == "2":
+        if (f[5] == "2") != WG:
             continue
         res.setdefault(key, {})[cfg] = (float(f[2]), int(f[1]), float(f[3]))
 rows = []
 for key, d in res.items():
-    if len(d) < 3:
+    if len(d) < (2 if WG else 3):
         continue
+    d.setdefault(2, d[0])
     best = min(d, key=lambda c: d[c][0])
     rows.append((d[best][0] * d[best][1], key, d, best))
 rows.sort(reverse=True)
