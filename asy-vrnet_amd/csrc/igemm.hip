@@ -674,7 +674,9 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
   const long tiles64 = vr_cdiv(Cout, 64) * vr_cdiv(Cin, 64) * T;
   static const int force = getenv("VRNET_WGRAD_CFG") ? atoi(getenv("VRNET_WGRAD_CFG")) : -1;   // tuning aid
   const bool small_ok = Cin > 32 && Cout > 32;
-  if ((force < 0 && tiles128 * s128 < 512 && small_ok) || (force == 1 && small_ok)) {
+  // Measured (tools/tune_igemm.py --wgrad): 64 x 64 tiles win except for the large weight matrices whose
+  // 128-wide tiling already yields >= 64 tiles (2560x640, 3x3 512x512, ...).
+  if ((force < 0 && tiles128 < 64 && small_ok) || (force == 1 && small_ok)) {
     *cfg = 1; *bn = 64;
     *n_tiles = (int)vr_cdiv(Cout, 64); *c_tiles = (int)vr_cdiv(Cin, 64);
     const long s = splits(tiles64);
