@@ -506,10 +506,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (n < p.Cout) slab[(long)n * p.Cin + c] = acc[i][j][r];
+        if (n < p.Cout) vr_store_wt(slab + (long)n * p.Cin + c, acc[i][j][r]);
       }
   }
-  if (do_bias && tid < BM && n0 + tid < p.Cout) p.bslab[(long)split * p.Cout + n0 + tid] = bsum;
+  if (do_bias && tid < BM && n0 + tid < p.Cout) vr_store_wt(p.bslab + (long)split * p.Cout + n0 + tid, bsum);
 
   // dw (OIHW) = row_scale[n] * sum_s slab[s][t][n][c] (+ dw);  db[n] = row_scale[n] * sum_s bslab[s][n] (+ db)
   __shared__ int last_flag;

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, 
     double* po = partial + (((long)b * nchunks + chunk) * C + (long)cv * VEC) * 2;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      po[2 * j] = s1[j];
-      po[2 * j + 1] = s2[j];
+      vr_store_wt(po + 2 * j, s1[j]);
+      vr_store_wt(po + 2 * j + 1, s2[j]);
     }
   }
   // the last chunk-workgroup of this (sample, channel block) sums the chunk partials in chunk order
