@@ -362,8 +362,6 @@ struct WgradArgs {
   int M, OH, OW, H, W, Cin, Cout;
   int kh, kw, stride, pad, dil;
   int rows_per_split, n_tiles, c_tiles;
-  // fused reduction (last-arriving split of a tile sums the slabs in split order)
-  float* dw; float* db; const float* row_scale; unsigned* counters; int S, accumulate;
 };
 
 // IDENT: 1x1 / stride 1 / pad 0 -- the gathered x row of output pixel m is row m itself (no index math).
@@ -506,32 +504,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (n < p.Cout) vr_store_wt(slab + (long)n * p.Cin + c, acc[i][j][r]);
+        if (n < p.Cout) slab[(long)n * p.Cin + c] = acc[i][j][r];
       }
   }
-  if (do_bias && tid < BM && n0 + tid < p.Cout) vr_store_wt(p.bslab + (long)split * p.Cout + n0 + tid, bsum);
+  if (do_bias && tid < BM && n0 + tid < p.Cout) p.bslab[(long)split * p.Cout + n0 + tid] = bsum;
 
-  // dw (OIHW) = row_scale[n] * sum_s slab[s][t][n][c] (+ dw);  db[n] = row_scale[n] * sum_s bslab[s][n] (+ db)
-  __shared__ int last_flag;
-  if (!vr_last_block(p.counters + blockIdx.x, (unsigned)p.S, &last_flag)) return;
-  const long per = T * p.Cout * p.Cin;
-  for (int e = tid; e < BM * BN; e += 256) {
-    const int nl = e / BN, cl = e - nl * BN;
-    const int n = n0 + nl, c = c0 + cl;
-    if (n >= p.Cout || c >= p.Cin) continue;
-    const float* src = p.slab + ((long)t * p.Cout + n) * p.Cin + c;
-    float sum = 0.f;
-    for (int k = 0; k < p.S; ++k) sum += src[(long)k * per];
-    if (p.row_scale) sum *= p.row_scale[n];
-    float* d = p.dw + ((long)n * p.Cin + c) * T + t;
-    *d = p.accumulate ? *d + sum : sum;
-  }
-  if (do_bias && tid < BM && n0 + tid < p.Cout) {
-    float sum = 0.f;
-    for (int k = 0; k < p.S; ++k) sum += p.bslab[(long)k * p.Cout + n0 + tid];
-    if (p.row_scale) sum *= p.row_scale[n0 + tid];
-    p.db[n0 + tid] = p.accumulate ? p.db[n0 + tid] + sum : sum;
-  }
 }
 
 // dw (OIHW) = row_scale[n] * sum_s slab[s][t][n][c] (+ dw);  db[n] = row_scale[n] * sum_s bslab[s][n] (+ db)
@@ -750,9 +727,6 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   p.M = (int)M; p.OH = OH; p.OW = OW; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
   p.rows_per_split = rows; p.n_tiles = nt; p.c_tiles = ct;
-  p.dw = dw; p.db = dbias; p.row_scale = row_scale; p.S = S; p.accumulate = accumulate;
-  p.counters = vr_counters(VR_CNT_WGRAD);
-  VR_CHECK_ARG(p.counters && (long)nt * ct * T <= VR_CNT_REGION, "conv2d_wgrad: counter buffer unavailable");
   const bool vec = (Cin % 4 == 0) && (ldx % 4 == 0) && vr_aligned16(x) && (Cout % 4 == 0) && (lddy % 4 == 0) &&
                    vr_aligned16(dy);
   const bool ident = kh == 1 && kw == 1 && stride == 1 && pad == 0;
@@ -770,6 +744,12 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   else VR_WGRAD(128, 32, 1, 1, 4, 1);
 #undef VR_WGRAD
   VR_LAUNCH_CHECK("conv2d_wgrad");
+  // A separate, fully parallel reduce pass: fusing it into the last-arriving split (as moments does) serialises
+  // S * tile loads in one workgroup and measured 2x slower end to end.
+  const long total = (long)T * Cout * Cin + (dbias ? Cout : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(vr_cdiv(total, 256)), dim3(256), 0, st, p.slab, p.bslab, row_scale, dw,
+                     dbias, S, T, Cout, Cin, accumulate);
+  VR_LAUNCH_CHECK("conv2d_wgrad_reduce");
   return VR_OK;
 }
 
