@@ -27,20 +27,3 @@ extern "C" int vrnet_device_arch(char* buf, int len) {
   buf[len - 1] = 0;
   return VR_OK;
 }
-
-// Library-owned, zero-initialised counters for the in-kernel "last workgroup reduces" pattern (common.h).
-// Allocated on first use per device (the first call of every kernel family happens in warm-up, never inside
-// a graph capture); every kernel leaves its counters at zero.
-unsigned* vr_counters(int region) {
-  static unsigned* bufs[64] = {nullptr};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!bufs[dev]) {
-    unsigned* p = nullptr;
-    const size_t bytes = (size_t)4 * VR_CNT_REGION * sizeof(unsigned);
-    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-    bufs[dev] = p;
-  }
-  return bufs[dev] + (size_t)region * VR_CNT_REGION;
-}

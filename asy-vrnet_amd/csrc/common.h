@@ -45,41 +45,6 @@ __device__ __forceinline__ float vr_gelu_grad(float x) {
   return cdf + x * pdf;
 }
 
-// Zero-initialised device counters owned by the library (api.hip); region [off, off+n) per kernel family.
-unsigned* vr_counters(int region);
-constexpr int VR_CNT_MOMENTS = 0, VR_CNT_WGRAD = 1, VR_CNT_MISC = 2, VR_CNT_REGION = 8192;
-
-// "Last-arriving workgroup reduces": every workgroup of a group of `total` stores its partial result, then
-// calls this (all threads).  Returns true in exactly one workgroup -- the last to arrive -- after an
-// agent-scope acquire, so that it may read every other workgroup's partials with plain loads.  The counter
-// resets itself for the next launch.  Protocol: cdna_hip_programming.md G16, write-through form: the partials
-// are stored with vr_store_wt (sc1 stores: no release fence, which would write back the whole L2) -> s_waitcnt
-// vmcnt(0) in every wave -> barrier -> lane 0: relaxed agent atomic; last arriver: acquire fence, vmcnt(0),
-// barrier, plain loads.  The reduction order is fixed (by partial index), so results do not depend on which
-// workgroup arrives last.
-__device__ __forceinline__ void vr_store_wt(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void vr_store_wt(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool vr_last_block(unsigned* cnt, unsigned total, int* flag_lds) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = old == total - 1u;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    *flag_lds = last;
-  }
-  __syncthreads();
-  return *flag_lds != 0;
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

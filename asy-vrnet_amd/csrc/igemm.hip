@@ -508,7 +508,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
       }
   }
   if (do_bias && tid < BM && n0 + tid < p.Cout) p.bslab[(long)split * p.Cout + n0 + tid] = bsum;
-
 }
 
 // dw (OIHW) = row_scale[n] * sum_s slab[s][t][n][c] (+ dw);  db[n] = row_scale[n] * sum_s bslab[s][n] (+ db)
@@ -744,8 +743,6 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   else VR_WGRAD(128, 32, 1, 1, 4, 1);
 #undef VR_WGRAD
   VR_LAUNCH_CHECK("conv2d_wgrad");
-  // A separate, fully parallel reduce pass: fusing it into the last-arriving split (as moments does) serialises
-  // S * tile loads in one workgroup and measured 2x slower end to end.
   const long total = (long)T * Cout * Cin + (dbias ? Cout : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(vr_cdiv(total, 256)), dim3(256), 0, st, p.slab, p.bslab, row_scale, dw,
                      dbias, S, T, Cout, Cin, accumulate);

@@ -8,57 +8,63 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ depthwise 3x3
-// One workgroup per image row (b, y); all index math is 32-bit and row-uniform; x-neighbour loads hit L1.
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* x, long ldx, const float* w, float* y, long ldy,
-                                                        int H, int W, int C, int flip, int accumulate) {
-  const int b = blockIdx.x / H, yy = blockIdx.x - b * H;
-  for (int e = threadIdx.x; e < W * C; e += 256) {
-    const int xx = e / C, c = e - xx * C;
+                                                        int B, int H, int W, int C, int flip, int accumulate) {
+  const long total = (long)B * H * W * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = e % C;
+    const long pix = e / C;
+    const int xx = pix % W;
+    const long q = pix / W;
+    const int yy = q % H;
+    const long b = q / H;
     float s = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int sy = yy + ky - 1;
       if (sy < 0 || sy >= H) continue;
-      const float* row = x + ((long)(b * H + sy) * W) * ldx + c;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int sx = xx + kx - 1;
         if (sx < 0 || sx >= W) continue;
         const int t = ky * 3 + kx;
-        s += row[(long)sx * ldx] * w[c * 9 + (flip ? 8 - t : t)];
+        s += x[((b * H + sy) * W + sx) * ldx + c] * w[c * 9 + (flip ? 8 - t : t)];
       }
     }
-    float* d = y + ((long)(b * H + yy) * W + xx) * ldy + c;
+    float* d = y + pix * ldy + c;
     *d = accumulate ? *d + s : s;
   }
 }
 
-// dw[c][t] = sum_pix dy[pix, c] * x[pix + tap t, c].  One workgroup per (image row, channel block); the last
-// row-workgroup of a channel block sums the per-row partials in row order (deterministic).
+// partial[chunk][c][9]: dw[c][t] = sum_pix dy[pix, c] * x[pix + tap t, c]
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* x, long ldx, const float* dy, long lddy,
-                                                              int H, int W, int C, int TPR, float* partial, float* dw,
-                                                              unsigned* counters, int nrows, int accumulate) {
+                                                              int B, int H, int W, int C, long pix_per_chunk,
+                                                              float* partial) {
   __shared__ float sm[256 * 9];
-  __shared__ int last_flag;
+  const int TPR = min(256, C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256)));
   const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR, RP = 256 / TPR;
   const int c = blockIdx.y * TPR + tx;
-  const int b = blockIdx.x / H, yy = blockIdx.x - b * H;
+  const long npix = (long)B * H * W;
+  const long p0 = blockIdx.x * pix_per_chunk, p1 = min(npix, p0 + pix_per_chunk);
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
   if (c < C) {
-    for (int xx = ty; xx < W; xx += RP) {
-      const float g = dy[((long)(b * H + yy) * W + xx) * lddy + c];
+    for (long pix = p0 + ty; pix < p1; pix += RP) {
+      const int xx = pix % W;
+      const long q = pix / W;
+      const int yy = q % H;
+      const long b = q / H;
+      const float g = dy[pix * lddy + c];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int sy = yy + ky - 1;
         if (sy < 0 || sy >= H) continue;
-        const float* row = x + ((long)(b * H + sy) * W) * ldx + c;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int sx = xx + kx - 1;
           if (sx < 0 || sx >= W) continue;
-          acc[ky * 3 + kx] += g * row[(long)sx * ldx];
+          acc[ky * 3 + kx] += g * x[((b * H + sy) * W + sx) * ldx + c];
         }
       }
     }
@@ -71,16 +77,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* x, lo
 #pragma unroll
       for (int t = 0; t < 9; ++t) acc[t] += sm[(r * TPR + tx) * 9 + t];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) vr_store_wt(partial + ((long)blockIdx.x * C + c) * 9 + t, acc[t]);
+    for (int t = 0; t < 9; ++t) partial[((long)blockIdx.x * C + c) * 9 + t] = acc[t];
   }
-  if (!vr_last_block(counters + blockIdx.y, (unsigned)nrows, &last_flag)) return;
-  const int c_lo = blockIdx.y * TPR, nval = min(C - c_lo, TPR) * 9;
-  for (int i = threadIdx.x; i < nval; i += 256) {
-    double s = 0;
-    for (int k = 0; k < nrows; ++k) s += partial[((long)k * C + c_lo) * 9 + i];
-    float* d = dw + (long)c_lo * 9 + i;
-    *d = (accumulate ? *d : 0.f) + (float)s;
-  }
+}
+__global__ void dwconv3x3_wgrad_reduce_kernel(const float* partial, int nchunks, int C, float* dw, int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= C * 9) return;
+  double s = 0;
+  for (int k = 0; k < nchunks; ++k) s += partial[(long)k * C * 9 + e];
+  dw[e] = (accumulate ? dw[e] : 0.f) + (float)s;
 }
 
 // ------------------------------------------------------------------------------------------ bilinear upsample
@@ -455,27 +460,45 @@ void sa_plan(long HW, int C, int* TPR, int* ncb, int* nchunks, long* rows) {
 extern "C" int vrnet_dwconv3x3_f32(const float* x, long ldx, const float* w, float* y, long ldy, int B, int H, int W,
                                    int C, int flip, int accumulate, void* stream) {
   VR_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && C > 0, "dwconv3x3: bad arguments");
-  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(B * H), dim3(256), 0, vr_stream(stream), x, ldx, w, y, ldy, H, W, C, flip,
-                     accumulate);
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, vr_stream(stream), x, ldx, w, y,
+                     ldy, B, H, W, C, flip, accumulate);
   VR_LAUNCH_CHECK("dwconv3x3");
   return VR_OK;
 }
 
-extern "C" long vrnet_dwconv3x3_wgrad_workspace(int B, int H, int W, int C) { return (long)B * H * C * 9 * 4 + 256; }
+static void dw_wgrad_plan(long npix, int C, int* nchunks, long* ppc) {
+  long nc = vr_cdiv(npix * C, 16384);
+  if (nc < 1) nc = 1;
+  if (nc > 512) nc = 512;
+  *ppc = vr_cdiv(npix, nc);
+  *nchunks = (int)vr_cdiv(npix, *ppc);
+}
+extern "C" long vrnet_dwconv3x3_wgrad_workspace(int B, int H, int W, int C) {
+  int nchunks;
+  long ppc;
+  dw_wgrad_plan((long)B * H * W, C, &nchunks, &ppc);
+  return (long)nchunks * C * 9 * 4 + 256;
+}
 extern "C" int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, int B, int H,
                                          int W, int C, int accumulate, void* workspace, long workspace_bytes,
                                          void* stream) {
   VR_CHECK_ARG(x && dy && dw && workspace, "dwconv3x3_wgrad: null tensor");
+  int nchunks;
+  long ppc;
+  dw_wgrad_plan((long)B * H * W, C, &nchunks, &ppc);
   if (workspace_bytes < vrnet_dwconv3x3_wgrad_workspace(B, H, W, C)) {
     vr_set_error("dwconv3x3_wgrad: workspace too small");
     return VR_ERR_WORKSPACE;
   }
   const int TPR = C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256));
-  unsigned* counters = vr_counters(VR_CNT_MISC);
-  VR_CHECK_ARG(counters && vr_cdiv(C, TPR) <= VR_CNT_REGION, "dwconv3x3_wgrad: counter buffer unavailable");
-  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(B * H, vr_cdiv(C, TPR)), dim3(256), 0, vr_stream(stream), x, ldx, dy, lddy,
-                     H, W, C, TPR, reinterpret_cast<float*>(workspace), dw, counters, B * H, accumulate);
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipStream_t st = vr_stream(stream);
+  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(nchunks, vr_cdiv(C, TPR)), dim3(256), 0, st, x, ldx, dy, lddy, B, H, W,
+                     C, ppc, partial);
   VR_LAUNCH_CHECK("dwconv3x3_wgrad");
+  hipLaunchKernelGGL(dwconv3x3_wgrad_reduce_kernel, dim3(vr_cdiv(C * 9, 256)), dim3(256), 0, st, partial, nchunks, C, dw,
+                     accumulate);
+  VR_LAUNCH_CHECK("dwconv3x3_wgrad_reduce");
   return VR_OK;
 }
 

@@ -16,10 +16,8 @@ namespace {
 template <int VEC>
 __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, const float* x2, long ldx2,
                                                       const float* mask, long ldm, long HW, int C, int TPR,
-                                                      long rows_per_chunk, int nchunks, double* partial,
-                                                      double* out, unsigned* counters) {
+                                                      long rows_per_chunk, int nchunks, double* partial) {
   extern __shared__ double sm[];   // [256][2*VEC]
-  __shared__ int last_flag;
   const int tid = threadIdx.x;
   const int tx = tid % TPR, ty = tid / TPR, RP = 256 / TPR;
   const int chunk = blockIdx.x, b = blockIdx.y;
@@ -76,21 +74,12 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, 
         s2[j] += sm[(long)(q * TPR + tx) * 2 * VEC + VEC + j];
       }
     }
-    double* po = partial + (((long)b * nchunks + chunk) * C + (long)cv * VEC) * 2;
+    double* out = partial + (((long)b * nchunks + chunk) * C + (long)cv * VEC) * 2;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      vr_store_wt(po + 2 * j, s1[j]);
-      vr_store_wt(po + 2 * j + 1, s2[j]);
+      out[2 * j] = s1[j];
+      out[2 * j + 1] = s2[j];
     }
-  }
-  // the last chunk-workgroup of this (sample, channel block) sums the chunk partials in chunk order
-  if (!vr_last_block(counters + (long)b * gridDim.z + blockIdx.z, (unsigned)nchunks, &last_flag)) return;
-  const int c_lo = blockIdx.z * TPR * VEC;
-  const int nval = min(C - c_lo, TPR * VEC) * 2;
-  for (int i = tid; i < nval; i += 256) {
-    double s = 0.0;
-    for (int k = 0; k < nchunks; ++k) s += partial[(((long)b * nchunks + k) * C + c_lo) * 2 + i];
-    out[((long)b * C + c_lo) * 2 + i] = s;
   }
 }
 
@@ -474,16 +463,17 @@ extern "C" int vrnet_moments_f32(const float* x, long ldx, const float* x2, long
   }
   double* partial = reinterpret_cast<double*>(workspace);
   hipStream_t st = vr_stream(stream);
-  unsigned* counters = vr_counters(VR_CNT_MOMENTS);
-  VR_CHECK_ARG(counters && (long)B * ncb <= VR_CNT_REGION, "moments: counter buffer unavailable");
   dim3 grid(nchunks, B, ncb), block(256);
   if (vec)
     hipLaunchKernelGGL((moments_kernel<4>), grid, block, 256 * 8 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
-                       TPR, rows, nchunks, partial, out, counters);
+                       TPR, rows, nchunks, partial);
   else
     hipLaunchKernelGGL((moments_kernel<1>), grid, block, 256 * 2 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
-                       TPR, rows, nchunks, partial, out, counters);
+                       TPR, rows, nchunks, partial);
   VR_LAUNCH_CHECK("moments");
+  const long n = (long)B * C * 2;
+  hipLaunchKernelGGL(moments_reduce_kernel, dim3(vr_cdiv(n, 256)), dim3(256), 0, st, partial, out, B, nchunks, C);
+  VR_LAUNCH_CHECK("moments_reduce");
   return VR_OK;
 }
 
