@@ -33,12 +33,13 @@ struct IgemmArgs {
   int Cin;
 };
 
-constexpr int BK = 16;
 constexpr int STAGE_LD = 36;                       // epilogue staging tile: 32 rows x 36 floats per wave
 
-template <int BM, int BN, int TM, int TN, int WM, int WN, int MODE, bool VEC>
+template <int BM, int BN, int BK, int TM, int TN, int WM, int WN, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
+  constexpr int KQ = BK / 4;            // k-quads per row
+  constexpr int RPP = 256 / KQ;         // rows covered per pass of the transposing loaders
   constexpr int AS_FLOATS = BK * (BM + 4), BS_FLOATS = BK * (BN + 4);
   constexpr int SM_FLOATS = (AS_FLOATS + BS_FLOATS) > 4 * 32 * STAGE_LD ? (AS_FLOATS + BS_FLOATS) : 4 * 32 * STAGE_LD;
   __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
@@ -46,8 +47,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   __shared__ unsigned char taps_s[32];
   float (*As)[BM + 4] = reinterpret_cast<float (*)[BM + 4]>(smem);
   float (*Bs)[BN + 4] = reinterpret_cast<float (*)[BN + 4]>(smem + AS_FLOATS);
-  constexpr int AROWS = BM / 64;                      // A rows per thread
-  constexpr int BROWS = (BN >= 64) ? BN / 64 : 1;     // NK loader (MODE 0): rows per thread
+  constexpr int AROWS = BM / RPP;                     // A rows per thread
+  constexpr int BROWS = (BN >= RPP) ? BN / RPP : 1;   // NK loader (MODE 0): rows per thread
   constexpr int BVEC = (BN * BK / 4 + 255) / 256;     // KN loader (MODE 1): float4 per thread
   constexpr int BSLOTS = MODE == 0 ? BROWS : BVEC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,14 +56,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int nkb = (p.CK + BK - 1) / BK;
   const int T = p.kh * p.kw;
-  const int kq = tid & 3;
+  const int kq = tid % KQ, rbase = tid / KQ;
 
-  // ---- A-side: each thread owns rows (tid>>2) [+64], k-quad tid&3.  Pixel decomposition once per kernel.
+  // ---- A-side: each thread owns rows rbase [+RPP...], k-quad kq.  Pixel decomposition once per kernel.
   int a_b[AROWS], a_y[AROWS], a_x[AROWS];
   bool a_ok[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
-    const int m = m0 + (tid >> 2) + 64 * i;
+    const int m = m0 + rbase + RPP * i;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
     a_x[i] = mm % p.MW;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     if (MODE == 0) {              // B[k = c][n] = w[t][n][c]: rows n, contiguous contraction
 #pragma unroll
       for (int i = 0; i < BSLOTS; ++i) {
-        const int n = (tid >> 2) + 64 * i;
+        const int n = rbase + RPP * i;
         b_ptr[i] = (n < BN && n0 + n < p.CN) ? wt + (long)(n0 + n) * p.Cin : nullptr;
       }
     } else {                      // B[k = n'][j = c] = w[t][n'][c]: rows = contraction, contiguous output col
@@ -212,14 +213,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   auto store_tiles = [&]() {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      const int r = (tid >> 2) + 64 * i;
+      const int r = rbase + RPP * i;
 #pragma unroll
       for (int j = 0; j < 4; ++j) As[4 * kq + j][r] = areg[i][j];
     }
     if (MODE == 0) {
 #pragma unroll
       for (int i = 0; i < BSLOTS; ++i) {
-        const int n = (tid >> 2) + 64 * i;
+        const int n = rbase + RPP * i;
         if (n < BN) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) Bs[4 * kq + j][n] = breg[i][j];
@@ -365,6 +366,8 @@ struct WgradArgs {
 };
 
 // IDENT: 1x1 / stride 1 / pad 0 -- the gathered x row of output pixel m is row m itself (no index math).
+constexpr int BK = 16;   // wgrad contraction step
+
 template <int BM, int BN, int TM, int TN, int WM, int WN, bool IDENT, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
@@ -613,15 +616,22 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   const long blocks128 = mt128 * vr_cdiv(p.CN, bn128);
   const bool vec = p.a_vec && p.b_vec;
   static const int force_cfg = getenv("VRNET_IGEMM_CFG") ? atoi(getenv("VRNET_IGEMM_CFG")) : -1;   // tuning aid
-#define VR_IGEMM(BM_, BN_, TM_, TN_, WM_, WN_, GRID)                                                              \
-  do {                                                                                                            \
-    if (mode == 0) {                                                                                              \
-      if (vec) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, TM_, TN_, WM_, WN_, 0, true>), GRID, block, 0, st, p);  \
-      else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, TM_, TN_, WM_, WN_, 0, false>), GRID, block, 0, st, p);     \
-    } else {                                                                                                      \
-      if (vec) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, TM_, TN_, WM_, WN_, 1, true>), GRID, block, 0, st, p);  \
-      else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, TM_, TN_, WM_, WN_, 1, false>), GRID, block, 0, st, p);     \
-    }                                                                                                             \
+  static const int force_bk = getenv("VRNET_IGEMM_BK") ? atoi(getenv("VRNET_IGEMM_BK")) : 0;   // tuning aid
+  const bool bk32 = force_bk ? force_bk == 32 : p.CK >= 64;
+#define VR_IGEMM_(BM_, BN_, BK_, TM_, TN_, WM_, WN_, GRID)                                                              \
+  do {                                                                                                                  \
+    if (mode == 0) {                                                                                                    \
+      if (vec) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, BK_, TM_, TN_, WM_, WN_, 0, true>), GRID, block, 0, st, p);   \
+      else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, BK_, TM_, TN_, WM_, WN_, 0, false>), GRID, block, 0, st, p);      \
+    } else {                                                                                                            \
+      if (vec) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, BK_, TM_, TN_, WM_, WN_, 1, true>), GRID, block, 0, st, p);   \
+      else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, BK_, TM_, TN_, WM_, WN_, 1, false>), GRID, block, 0, st, p);      \
+    }                                                                                                                   \
+  } while (0)
+#define VR_IGEMM(BM_, BN_, TM_, TN_, WM_, WN_, GRID)                     \
+  do {                                                                   \
+    if (bk32) VR_IGEMM_(BM_, BN_, 32, TM_, TN_, WM_, WN_, GRID);         \
+    else VR_IGEMM_(BM_, BN_, 16, TM_, TN_, WM_, WN_, GRID);              \
   } while (0)
   // Measured on MI355X over every conv shape of the net (tools/tune_igemm.py, phi = l, bs 8, 512 px): 64 x 64 tiles
   // (7 workgroups per CU) beat 128 x 128 (2 per CU) and 128 x 64 on 90 % of the shapes -- 21.4 vs 30.7 / 25.9 ms
@@ -646,6 +656,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
     VR_IGEMM(128, 32, 1, 1, 4, 1, grid);
   }
 #undef VR_IGEMM
+#undef VR_IGEMM_
   VR_LAUNCH_CHECK("conv2d");
   return VR_OK;
 }

@@ -8,10 +8,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = sys.argv[1:]
 res = {}
 WG = "--wgrad" in args
-if WG:
-    args.remove("--wgrad")
-for cfg in ((0, 1) if WG else (0, 1, 2)):
-    env = dict(os.environ, **({"VRNET_WGRAD_CFG": str(cfg)} if WG else {"VRNET_IGEMM_CFG": str(cfg)}))
+BKS = "--bk" in args           # cfg0 = BK 16, cfg1 = BK 32
+for f in ("--wgrad", "--bk"):
+    if f in args:
+        args.remove(f)
+for cfg in ((0, 1) if (WG or BKS) else (0, 1, 2)):
+    if BKS:
+        env = dict(os.environ, VRNET_IGEMM_BK=str(16 if cfg == 0 else 32))
+    else:
+        env = dict(os.environ, **({"VRNET_WGRAD_CFG": str(cfg)} if WG else {"VRNET_IGEMM_CFG": str(cfg)}))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_kernels.py")] + args, env=env,
                          capture_output=True, text=True).stdout
     for line in out.splitlines():
@@ -24,7 +29,7 @@ for cfg in ((0, 1) if WG else (0, 1, 2)):
         res.setdefault(key, {})[cfg] = (float(f[2]), int(f[1]), float(f[3]))
 rows = []
 for key, d in res.items():
-    if len(d) < (2 if WG else 3):
+    if len(d) < (2 if (WG or BKS) else 3):
         continue
     d.setdefault(2, d[0])
     best = min(d, key=lambda c: d[c][0])
