@@ -40,13 +40,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
   constexpr int KQ = BK / 4;            // k-quads per row
   constexpr int RPP = 256 / KQ;         // rows covered per pass of the transposing loaders
-  constexpr int AS_FLOATS = BK * (BM + 4), BS_FLOATS = BK * (BN + 4);
+  // LDS operand images, [k/8][k%2][row][(k%8)/2]: the four k values one MFMA lane-half needs for four
+  // consecutive MFMAs are 16 contiguous bytes, so one ds_read_b128 feeds 4 MFMAs per operand (and the
+  // transposing writers store 8-byte pairs).  Row pitch BM+2 / BN+2 keeps the two k-groups on different banks.
+  constexpr int LDA = BM + 2, LDB = BN + 2;
+  constexpr int AS_FLOATS = BK * LDA, BS_FLOATS = BK * LDB;
   constexpr int SM_FLOATS = (AS_FLOATS + BS_FLOATS) > 4 * 32 * STAGE_LD ? (AS_FLOATS + BS_FLOATS) : 4 * 32 * STAGE_LD;
   __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
   __shared__ unsigned tapmask_s;
   __shared__ unsigned char taps_s[32];
-  float (*As)[BM + 4] = reinterpret_cast<float (*)[BM + 4]>(smem);
-  float (*Bs)[BN + 4] = reinterpret_cast<float (*)[BN + 4]>(smem + AS_FLOATS);
+  float* As = smem;
+  float* Bs = smem + AS_FLOATS;
   constexpr int AROWS = BM / RPP;                     // A rows per thread
   constexpr int BROWS = (BN >= RPP) ? BN / RPP : 1;   // NK loader (MODE 0): rows per thread
   constexpr int BVEC = (BN * BK / 4 + 255) / 256;     // KN loader (MODE 1): float4 per thread
@@ -210,20 +214,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
   };
 
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   auto store_tiles = [&]() {
+    const int kg = kq >> 1, jb = (kq & 1) * 2;     // this thread's 4 k values: k = 8*kg + 2*(jb/2..) ...
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int r = rbase + RPP * i;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) As[4 * kq + j][r] = areg[i][j];
+      f32x2 e = {areg[i][0], areg[i][2]}, o = {areg[i][1], areg[i][3]};
+      *reinterpret_cast<f32x2*>(&As[((kg * 2 + 0) * LDA + r) * 4 + jb]) = e;
+      *reinterpret_cast<f32x2*>(&As[((kg * 2 + 1) * LDA + r) * 4 + jb]) = o;
     }
     if (MODE == 0) {
 #pragma unroll
       for (int i = 0; i < BSLOTS; ++i) {
         const int n = rbase + RPP * i;
         if (n < BN) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) Bs[4 * kq + j][n] = breg[i][j];
+          f32x2 e = {breg[i][0], breg[i][2]}, o = {breg[i][1], breg[i][3]};
+          *reinterpret_cast<f32x2*>(&Bs[((kg * 2 + 0) * LDB + n) * 4 + jb]) = e;
+          *reinterpret_cast<f32x2*>(&Bs[((kg * 2 + 1) * LDB + n) * 4 + jb]) = o;
         }
       }
     } else {
@@ -231,7 +239,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
       for (int i = 0; i < BSLOTS; ++i) {
         const int idx = tid + 256 * i;
         const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
-        if (kr < BK) *reinterpret_cast<f32x4*>(&Bs[kr][4 * cq]) = breg[i];
+        if (kr < BK) {
+          float* dst = &Bs[(((kr >> 3) * 2 + (kr & 1)) * LDB + 4 * cq) * 4 + ((kr & 7) >> 1)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[4 * e] = breg[i][e];
+        }
       }
     }
   };
@@ -254,17 +266,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     __syncthreads();
     if (s + 1 < nsteps) load_tiles();
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float af[TM], bf[TN];
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = As[2 * kk + khalf][arow + 32 * i];
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[((g * 2 + khalf) * LDA + arow + 32 * i) * 4]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[2 * kk + khalf][bcol + 32 * j];
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((g * 2 + khalf) * LDB + bcol + 32 * j) * 4]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -482,17 +496,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
       for (int k = 0; k < BK; ++k) bsum += As[k][tid];
     }
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float af[TM], bf[TN];
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = As[2 * kk + khalf][arow + 32 * i];
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[((g * 2 + khalf) * LDA + arow + 32 * i) * 4]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[2 * kk + khalf][bcol + 32 * j];
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((g * 2 + khalf) * LDB + bcol + 32 * j) * 4]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
