@@ -496,19 +496,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
       for (int k = 0; k < BK; ++k) bsum += As[k][tid];
     }
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      f32x4 af[TM], bf[TN];
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[((g * 2 + khalf) * LDA + arow + 32 * i) * 4]);
+      for (int i = 0; i < TM; ++i) af[i] = As[2 * kk + khalf][arow + 32 * i];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((g * 2 + khalf) * LDB + bcol + 32 * j) * 4]);
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[2 * kk + khalf][bcol + 32 * j];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
