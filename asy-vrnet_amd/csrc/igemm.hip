@@ -148,9 +148,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
   };
 
-  f32x4 areg[AROWS], breg[BSLOTS];
+  // Two register sets: the global loads of K-step s+2 are issued while step s computes, so a tile has two
+  // K-steps to land (the tail of a launch runs at low occupancy, where one step does not cover HBM latency).
+  f32x4 aregs[2][AROWS], bregs[2][BSLOTS];
   int ld_ti = 0, ld_kb = 0;        // (tap index, k block) of the NEXT tile to load
-  auto load_tiles = [&]() {
+  auto load_tiles = [&](f32x4 (&areg)[AROWS], f32x4 (&breg)[BSLOTS]) {
     if (ld_kb == 0) setup_tap(use_list ? (int)taps_s[ld_ti] : ld_ti);
     const int c0 = ld_kb * BK;
     const int kc = c0 + 4 * kq;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   };
 
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](const f32x4 (&areg)[AROWS], const f32x4 (&breg)[BSLOTS]) {
     const int kg = kq >> 1, jb = (kq & 1) * 2;     // this thread's 4 k values: k = 8*kg + 2*(jb/2..) ...
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
@@ -260,11 +262,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   const int bcol = wn * TN * 32 + (lane & 31);
   const int khalf = lane >> 5;
 
-  if (nsteps > 0) load_tiles();
-  for (int s = 0; s < nsteps; ++s) {
-    store_tiles();
-    __syncthreads();
-    if (s + 1 < nsteps) load_tiles();
+  auto compute = [&]() {
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       f32x4 af[TM], bf[TN];
@@ -280,7 +278,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
     }
+  };
+  if (nsteps > 0) load_tiles(aregs[0], bregs[0]);
+  if (nsteps > 1) load_tiles(aregs[1], bregs[1]);
+  for (int s = 0; s < nsteps; s += 2) {
+    store_tiles(aregs[0], bregs[0]);
     __syncthreads();
+    if (s + 2 < nsteps) load_tiles(aregs[0], bregs[0]);
+    compute();
+    __syncthreads();
+    if (s + 1 < nsteps) {
+      store_tiles(aregs[1], bregs[1]);
+      __syncthreads();
+      if (s + 3 < nsteps) load_tiles(aregs[1], bregs[1]);
+      compute();
+      __syncthreads();
+    }
   }
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
