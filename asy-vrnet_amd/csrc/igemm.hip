@@ -40,17 +40,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
   constexpr int KQ = BK / 4;            // k-quads per row
   constexpr int RPP = 256 / KQ;         // rows covered per pass of the transposing loaders
-  // LDS operand images, [k/8][k%2][row][(k%8)/2]: the four k values one MFMA lane-half needs for four
-  // consecutive MFMAs are 16 contiguous bytes, so one ds_read_b128 feeds 4 MFMAs per operand (and the
-  // transposing writers store 8-byte pairs).  Row pitch BM+2 / BN+2 keeps the two k-groups on different banks.
-  constexpr int LDA = BM + 2, LDB = BN + 2;
-  constexpr int AS_FLOATS = BK * LDA, BS_FLOATS = BK * LDB;
+  constexpr int AS_FLOATS = BK * (BM + 4), BS_FLOATS = BK * (BN + 4);
   constexpr int SM_FLOATS = (AS_FLOATS + BS_FLOATS) > 4 * 32 * STAGE_LD ? (AS_FLOATS + BS_FLOATS) : 4 * 32 * STAGE_LD;
   __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
   __shared__ unsigned tapmask_s;
   __shared__ unsigned char taps_s[32];
-  float* As = smem;
-  float* Bs = smem + AS_FLOATS;
+  float (*As)[BM + 4] = reinterpret_cast<float (*)[BM + 4]>(smem);
+  float (*Bs)[BN + 4] = reinterpret_cast<float (*)[BN + 4]>(smem + AS_FLOATS);
   constexpr int AROWS = BM / RPP;                     // A rows per thread
   constexpr int BROWS = (BN >= RPP) ? BN / RPP : 1;   // NK loader (MODE 0): rows per thread
   constexpr int BVEC = (BN * BK / 4 + 255) / 256;     // KN loader (MODE 1): float4 per thread
@@ -148,11 +144,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
   };
 
-  // Two register sets: the global loads of K-step s+2 are issued while step s computes, so a tile has two
-  // K-steps to land (the tail of a launch runs at low occupancy, where one step does not cover HBM latency).
-  f32x4 aregs[2][AROWS], bregs[2][BSLOTS];
+  f32x4 areg[AROWS], breg[BSLOTS];
   int ld_ti = 0, ld_kb = 0;        // (tap index, k block) of the NEXT tile to load
-  auto load_tiles = [&](f32x4 (&areg)[AROWS], f32x4 (&breg)[BSLOTS]) {
+  auto load_tiles = [&]() {
     if (ld_kb == 0) setup_tap(use_list ? (int)taps_s[ld_ti] : ld_ti);
     const int c0 = ld_kb * BK;
     const int kc = c0 + 4 * kq;
@@ -216,24 +210,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     }
   };
 
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  auto store_tiles = [&](const f32x4 (&areg)[AROWS], const f32x4 (&breg)[BSLOTS]) {
-    const int kg = kq >> 1, jb = (kq & 1) * 2;     // this thread's 4 k values: k = 8*kg + 2*(jb/2..) ...
+  auto store_tiles = [&]() {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int r = rbase + RPP * i;
-      f32x2 e = {areg[i][0], areg[i][2]}, o = {areg[i][1], areg[i][3]};
-      *reinterpret_cast<f32x2*>(&As[((kg * 2 + 0) * LDA + r) * 4 + jb]) = e;
-      *reinterpret_cast<f32x2*>(&As[((kg * 2 + 1) * LDA + r) * 4 + jb]) = o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) As[4 * kq + j][r] = areg[i][j];
     }
     if (MODE == 0) {
 #pragma unroll
       for (int i = 0; i < BSLOTS; ++i) {
         const int n = rbase + RPP * i;
         if (n < BN) {
-          f32x2 e = {breg[i][0], breg[i][2]}, o = {breg[i][1], breg[i][3]};
-          *reinterpret_cast<f32x2*>(&Bs[((kg * 2 + 0) * LDB + n) * 4 + jb]) = e;
-          *reinterpret_cast<f32x2*>(&Bs[((kg * 2 + 1) * LDB + n) * 4 + jb]) = o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Bs[4 * kq + j][n] = breg[i][j];
         }
       }
     } else {
@@ -241,11 +231,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
       for (int i = 0; i < BSLOTS; ++i) {
         const int idx = tid + 256 * i;
         const int kr = idx / (BN / 4), cq = idx - kr * (BN / 4);
-        if (kr < BK) {
-          float* dst = &Bs[(((kr >> 3) * 2 + (kr & 1)) * LDB + 4 * cq) * 4 + ((kr & 7) >> 1)];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dst[4 * e] = breg[i][e];
-        }
+        if (kr < BK) *reinterpret_cast<f32x4*>(&Bs[kr][4 * cq]) = breg[i];
       }
     }
   };
@@ -262,38 +248,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
   const int bcol = wn * TN * 32 + (lane & 31);
   const int khalf = lane >> 5;
 
-  auto compute = [&]() {
-#pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      f32x4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[((g * 2 + khalf) * LDA + arow + 32 * i) * 4]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((g * 2 + khalf) * LDB + bcol + 32 * j) * 4]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
-    }
-  };
-  if (nsteps > 0) load_tiles(aregs[0], bregs[0]);
-  if (nsteps > 1) load_tiles(aregs[1], bregs[1]);
-  for (int s = 0; s < nsteps; s += 2) {
-    store_tiles(aregs[0], bregs[0]);
+  if (nsteps > 0) load_tiles();
+  for (int s = 0; s < nsteps; ++s) {
+    store_tiles();
     __syncthreads();
-    if (s + 2 < nsteps) load_tiles(aregs[0], bregs[0]);
-    compute();
-    __syncthreads();
-    if (s + 1 < nsteps) {
-      store_tiles(aregs[1], bregs[1]);
-      __syncthreads();
-      if (s + 3 < nsteps) load_tiles(aregs[1], bregs[1]);
-      compute();
-      __syncthreads();
+    if (s + 1 < nsteps) load_tiles();
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[2 * kk + khalf][arow + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[2 * kk + khalf][bcol + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+    __syncthreads();
   }
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
