@@ -32,6 +32,25 @@ import torch.distributed as dist  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 
 
+def pmc_traffic_bytes(phi):
+    """Average HBM bytes per igemm launch from the committed rocprofv3 PMC passes (profiles/; FETCH_SIZE doubled
+    for gfx950 as the MI355X guide prescribes, separate --pmc passes).  None when no profile matches this run."""
+    import csv
+    import glob
+    if phi != "l":
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc_phi-l_bs8_512.csv")))
+    if not files:
+        return None
+    n, tot = 0, 0.0
+    for row in csv.DictReader(open(files[-1])):
+        if row["kernel"].startswith("igemm_kernel"):
+            k = int(row["launches"])
+            n += k
+            tot += k * float(row["avg_HBM_MB"]) * 1024 * 1024
+    return round(tot / n) if n else None
+
+
 def loss_of(det, seg):
     return sum((d * d).mean() for d in det) + (seg * seg).mean()
 
@@ -200,7 +219,9 @@ def main():
         ach = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32)",
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": pmc_traffic_bytes(args.phi) if (args.batch == 8 and args.size == 512) else None,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
                 "launches_per_step": n // args.steps, "avg_launch_us": round(1e3 * ms / n, 2),
                 "avg_launch_gflop": round(flops / n / 1e9, 3),
                 "share_of_step": round(ms / args.steps / ms_per_step, 3),
