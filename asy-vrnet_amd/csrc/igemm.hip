@@ -36,7 +36,7 @@ struct IgemmArgs {
 constexpr int STAGE_LD = 36;                       // epilogue staging tile: 32 rows x 36 floats per wave
 
 template <int BM, int BN, int BK, int TM, int TN, int WM, int WN, int MODE, bool VEC>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(256, (BM == 64 && BN == 64 && BK == 16) ? 8 : 1) void igemm_kernel(const IgemmArgs p) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
   constexpr int KQ = BK / 4;            // k-quads per row
   constexpr int RPP = 256 / KQ;         // rows covered per pass of the transposing loaders
@@ -369,7 +369,7 @@ struct WgradArgs {
 constexpr int BK = 16;   // wgrad contraction step
 
 template <int BM, int BN, int TM, int TN, int WM, int WN, bool IDENT, bool VEC>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(256, (BM == 64 && BN == 64) ? 8 : 1) void wgrad_kernel(const WgradArgs p) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
   __shared__ __attribute__((aligned(16))) float As[BK][BM + 4];   // dy tile, [m][n]
   __shared__ __attribute__((aligned(16))) float Bs[BK][BN + 4];   // gathered x tile, [m][c]

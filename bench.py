@@ -109,7 +109,7 @@ def cpu_baseline(phi, size, batch, seed_sd):
     from oracle import vrnet_oracle as O
     import asy_vrnet_amd as A
     try:                                        # cores this process may actually use (cgroup / affinity aware)
-        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0)))))
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0)), 32)))   # >32 threads slow it down
     except AttributeError:
         pass
     m = A.EfficientVRNet(4, 9, phi, img_size=size)

@@ -52,8 +52,8 @@ def compare_with_oracle(model, batch, size, iseed, check_grads=True, oracle_dtyp
         if check_grads and k in pnames and t.numel():
             t.requires_grad_(True)
         P[k] = t
-    xo = x.to(oracle_dtype).requires_grad_(check_grads)
-    ro = r.to(oracle_dtype).requires_grad_(check_grads)
+    xo = x.detach().clone().to(oracle_dtype).requires_grad_(check_grads)
+    ro = r.detach().clone().to(oracle_dtype).requires_grad_(check_grads)
     det_o, seg_o, ctx = O.forward(P, xo, ro, model.phi, model.training, forced_idx=forced)
     rep = {"flips": sum(v.get("mismatch", 0) for v in ctx.idx_report.values()),
            "points": sum(v.get("points", 0) for v in ctx.idx_report.values()),
@@ -75,7 +75,7 @@ def compare_with_oracle(model, batch, size, iseed, check_grads=True, oracle_dtyp
             if k in pnames and t.numel():
                 t.requires_grad_(True)
             P32[k] = t
-        x32, r32 = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        x32, r32 = x.detach().clone().requires_grad_(True), r.detach().clone().requires_grad_(True)
         det32, seg32, _ = O.forward(P32, x32, r32, model.phi, model.training, forced_idx=forced)
         O.synthetic_loss(det32, seg32).backward()
         rep["dx_err"] = rel_err(xg.grad, xo.grad)
