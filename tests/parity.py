@@ -48,7 +48,7 @@ def compare_with_oracle(model, batch, size, iseed, check_grads=True, oracle_dtyp
     pnames = {k for k, _ in model.named_parameters()}
     P = {}
     for k, v in sd0.items():
-        t = v.to(oracle_dtype) if v.dtype.is_floating_point else v
+        t = v.detach().clone().to(oracle_dtype) if v.dtype.is_floating_point else v
         if check_grads and k in pnames and t.numel():
             t.requires_grad_(True)
         P[k] = t
@@ -71,7 +71,7 @@ def compare_with_oracle(model, batch, size, iseed, check_grads=True, oracle_dtyp
         # the same computation in the reference's precision (fp32), same assignments: the noise yardstick
         P32 = {}
         for k, v in sd0.items():
-            t = v.clone()
+            t = v.detach().clone()
             if k in pnames and t.numel():
                 t.requires_grad_(True)
             P32[k] = t
