@@ -10,61 +10,63 @@ namespace {
 // ------------------------------------------------------------------------------------------ depthwise 3x3
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* x, long ldx, const float* w, float* y, long ldy,
                                                         int B, int H, int W, int C, int flip, int accumulate) {
-  const long total = (long)B * H * W * C;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+  const int total = B * H * W * C;          // < 2^31, checked by the launcher: 32-bit index math
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
     const int c = e % C;
-    const long pix = e / C;
+    const int pix = e / C;
     const int xx = pix % W;
-    const long q = pix / W;
+    const int q = pix / W;
     const int yy = q % H;
-    const long b = q / H;
+    const int b = q / H;
     float s = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int sy = yy + ky - 1;
       if (sy < 0 || sy >= H) continue;
+      const float* row = x + ((long)(b * H + sy) * W) * ldx + c;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int sx = xx + kx - 1;
         if (sx < 0 || sx >= W) continue;
         const int t = ky * 3 + kx;
-        s += x[((b * H + sy) * W + sx) * ldx + c] * w[c * 9 + (flip ? 8 - t : t)];
+        s += row[(long)sx * ldx] * w[c * 9 + (flip ? 8 - t : t)];
       }
     }
-    float* d = y + pix * ldy + c;
+    float* d = y + (long)pix * ldy + c;
     *d = accumulate ? *d + s : s;
   }
 }
 
-// partial[chunk][c][9]: dw[c][t] = sum_pix dy[pix, c] * x[pix + tap t, c]
+// partial[chunk][c][9]: dw[c][t] = sum_pix dy[pix, c] * x[pix + tap t, c].  A chunk is a run of image rows
+// (b, y); all index math is 32-bit and row-uniform.
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* x, long ldx, const float* dy, long lddy,
-                                                              int B, int H, int W, int C, long pix_per_chunk,
+                                                              int B, int H, int W, int C, long rows_per_chunk,
                                                               float* partial) {
   __shared__ float sm[256 * 9];
   const int TPR = min(256, C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256)));
   const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR, RP = 256 / TPR;
   const int c = blockIdx.y * TPR + tx;
-  const long npix = (long)B * H * W;
-  const long p0 = blockIdx.x * pix_per_chunk, p1 = min(npix, p0 + pix_per_chunk);
+  const int nrows = B * H;
+  const int r0 = (int)(blockIdx.x * rows_per_chunk), r1 = min(nrows, r0 + (int)rows_per_chunk);
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
   if (c < C) {
-    for (long pix = p0 + ty; pix < p1; pix += RP) {
-      const int xx = pix % W;
-      const long q = pix / W;
-      const int yy = q % H;
-      const long b = q / H;
-      const float g = dy[pix * lddy + c];
+    for (int row = r0; row < r1; ++row) {
+      const int b = row / H, yy = row - b * H;
+      for (int xx = ty; xx < W; xx += RP) {
+        const float g = dy[((long)row * W + xx) * lddy + c];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int sy = yy + ky - 1;
-        if (sy < 0 || sy >= H) continue;
+        for (int ky = 0; ky < 3; ++ky) {
+          const int sy = yy + ky - 1;
+          if (sy < 0 || sy >= H) continue;
+          const float* src = x + ((long)(b * H + sy) * W) * ldx + c;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int sx = xx + kx - 1;
-          if (sx < 0 || sx >= W) continue;
-          acc[ky * 3 + kx] += g * x[((b * H + sy) * W + sx) * ldx + c];
+          for (int kx = 0; kx < 3; ++kx) {
+            const int sx = xx + kx - 1;
+            if (sx < 0 || sx >= W) continue;
+            acc[ky * 3 + kx] += g * src[(long)sx * ldx];
+          }
         }
       }
     }
@@ -460,23 +462,25 @@ void sa_plan(long HW, int C, int* TPR, int* ncb, int* nchunks, long* rows) {
 extern "C" int vrnet_dwconv3x3_f32(const float* x, long ldx, const float* w, float* y, long ldy, int B, int H, int W,
                                    int C, int flip, int accumulate, void* stream) {
   VR_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && C > 0, "dwconv3x3: bad arguments");
+  VR_CHECK_ARG((long)B * H * W * C < (1L << 31), "dwconv3x3: tensor too large");
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, vr_stream(stream), x, ldx, w, y,
                      ldy, B, H, W, C, flip, accumulate);
   VR_LAUNCH_CHECK("dwconv3x3");
   return VR_OK;
 }
 
-static void dw_wgrad_plan(long npix, int C, int* nchunks, long* ppc) {
-  long nc = vr_cdiv(npix * C, 16384);
+static void dw_wgrad_plan(long nrows, int W, int C, int* nchunks, long* rpc) {   // chunks of whole image rows
+  long nc = vr_cdiv(nrows * W * C, 16384);
   if (nc < 1) nc = 1;
   if (nc > 512) nc = 512;
-  *ppc = vr_cdiv(npix, nc);
-  *nchunks = (int)vr_cdiv(npix, *ppc);
+  if (nc > nrows) nc = nrows;
+  *rpc = vr_cdiv(nrows, nc);
+  *nchunks = (int)vr_cdiv(nrows, *rpc);
 }
 extern "C" long vrnet_dwconv3x3_wgrad_workspace(int B, int H, int W, int C) {
   int nchunks;
   long ppc;
-  dw_wgrad_plan((long)B * H * W, C, &nchunks, &ppc);
+  dw_wgrad_plan((long)B * H, W, C, &nchunks, &ppc);
   return (long)nchunks * C * 9 * 4 + 256;
 }
 extern "C" int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, int B, int H,
@@ -485,7 +489,7 @@ extern "C" int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* 
   VR_CHECK_ARG(x && dy && dw && workspace, "dwconv3x3_wgrad: null tensor");
   int nchunks;
   long ppc;
-  dw_wgrad_plan((long)B * H * W, C, &nchunks, &ppc);
+  dw_wgrad_plan((long)B * H, W, C, &nchunks, &ppc);
   if (workspace_bytes < vrnet_dwconv3x3_wgrad_workspace(B, H, W, C)) {
     vr_set_error("dwconv3x3_wgrad: workspace too small");
     return VR_ERR_WORKSPACE;
