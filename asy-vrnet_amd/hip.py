@@ -99,20 +99,22 @@ def empty(*shape, dtype=torch.float32, like=None, device=None):
 
 
 class Workspace:
-    """Grow-only scratch arena (bytes) per device.  Outgrown arenas are retired, never freed: a captured
-    HIP graph may still reference them."""
+    """Grow-only scratch arena (bytes) per (device, stream): kernels on forked streams run concurrently and
+    must not share scratch.  Outgrown arenas are retired, never freed: a captured HIP graph may still
+    reference them."""
 
     def __init__(self):
         self.buf = {}
         self.retired = []
 
     def get(self, nbytes, device):
-        b = self.buf.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             if b is not None:
                 self.retired.append(b)
             b = torch.empty(max(int(nbytes) * 2, 8 << 20), dtype=torch.uint8, device=device)
-            self.buf[device] = b
+            self.buf[key] = b
         return b
 
 

@@ -47,6 +47,57 @@ class RT:
         self.idx_maps = {}
         self.on_param_grad = None
         self.bucketer = None        # parallel.GradBucketer: gradients are written into its flat buckets
+        self.det_grads, self.seg_grad = (None, None, None), None
+        self.concurrent = True      # fork independent chains (image / radar, seg / det, head levels) onto side streams
+
+    # ---- fork / join of independent chains -------------------------------------------------------------
+    _side_streams = {}
+
+    def _streams(self, n):
+        pool = RT._side_streams.setdefault(self.device, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(self.device))
+        return pool[:n]
+
+    def parallel(self, fns):
+        """Runs independent chains `fns` (callables issuing kernels) on forked HIP streams and joins them.
+        Each chain records its backward closures on its own sub-tape; one closure on the main tape replays the
+        sub-tapes concurrently.  Allocator safety: inside a chain the side stream is torch's current stream, so
+        its temporaries live in that stream's pool; buffers crossing the fork / join are ordered by the events
+        (wait_stream) on both sides.  Under hipGraph capture the fork / join become graph edges."""
+        if not self.concurrent or len(fns) < 2:
+            return [fn() for fn in fns]
+        cur = torch.cuda.current_stream(self.device)
+        streams = self._streams(len(fns))
+        main_tape, outs, subtapes = self.tape, [], []
+        for st, fn in zip(streams, fns):
+            st.wait_stream(cur)
+            self.tape = []
+            with torch.cuda.stream(st):
+                outs.append(fn())
+            subtapes.append(self.tape)
+        self.tape = main_tape
+        for st in streams:
+            cur.wait_stream(st)
+        if self.record:
+            def bwd():
+                cur_b = torch.cuda.current_stream(self.device)
+                hook, deferred = self.on_param_grad, []
+                if hook is not None:           # a bucket's all-reduce must not start before BOTH chains have joined
+                    self.on_param_grad = deferred.append
+                for st, sub in zip(streams, subtapes):
+                    st.wait_stream(cur_b)
+                    with torch.cuda.stream(st):
+                        for f in reversed(sub):
+                            f()
+                for st in streams:
+                    cur_b.wait_stream(st)
+                if hook is not None:
+                    self.on_param_grad = hook
+                    for prm in deferred:
+                        hook(prm)
+            main_tape.append(bwd)
+        return outs
 
     def new(self, B, H, W, C, need_grad=True):
         return Act(torch.empty((B, H, W, C), dtype=torch.float32, device=self.device), need_grad)
@@ -539,7 +590,15 @@ def coc_upsample(rt, x, m, nchw_out=None):
     B, H, W, C = lo.B, lo.H, lo.W, lo.C
     if nchw_out is not None:
         hip.upsample(lo.t, C, nchw_out, 0, B, H, W, C, s, out_nchw=1)
-        return lo                                                  # caller seeds lo.grad from the NCHW gradient
+
+        def bwd_nchw():                                            # gradient of the NCHW seg logits (rt.seg_grad)
+            g = rt.seg_grad
+            if g is None:
+                return
+            buf, acc = rt.grad_target(lo)
+            hip.upsample_bwd(g.contiguous(), 0, 1, buf, C, B, H, W, C, s, accumulate=acc)
+        rt.push(bwd_nchw)
+        return lo
     hi = rt.new(B, H * s, W * s, C)
     hip.upsample(lo.t, C, hi.t, C, B, H, W, C, s)
 
@@ -612,15 +671,15 @@ def aspp(rt, x, m):
 def backbone_forward(rt, bb, x, r):
     """VRCoC.forward_embeddings + forward_tokens (vr_coc.py:575-675)."""
     B, H, W = x.B, x.H, x.W
-    x = simple_conv(rt, x, bb.image_initial.proj)
-    r = simple_conv(rt, r, bb.radar_initial.proj)
+    x0, r0 = x, r
+    x, r = rt.parallel([lambda: simple_conv(rt, x0, bb.image_initial.proj),
+                        lambda: simple_conv(rt, r0, bb.radar_initial.proj)])
     x = image_enhance(rt, x, r, bb.image_enhance_by_radar1)
     r = radar_enhance(rt, x, r, bb.radar_enhance_by_image1)
     if tuple(bb.fea_pos.shape[:2]) != (H, W):
         raise RuntimeError(f"input {H}x{W} does not match fea_pos {tuple(bb.fea_pos.shape[:2])}: "
                            "construct EfficientVRNet(..., img_size=(H, W))")
-    embeds = []
-    for act, pe in ((x, bb.patch_embed), (r, bb.patch_embed_radar)):
+    def embed(act, pe):
         C = act.C
         cat = rt.new(B, H, W, C + 2)
         hip.copy_channels(act.t, act.ld, 1, cat.t, C + 2, 1, act.rows, C)
@@ -635,21 +694,29 @@ def backbone_forward(rt, bb, x, r):
                 buf, acc = rt.grad_target(act)
                 hip.copy_channels(g, C + 2, 1, buf, C, 1, act.rows, C, accumulate=acc)
         rt.push(bwd)
-        embeds.append(simple_conv(rt, cat, pe.proj))
-    x, r = embeds
+        return simple_conv(rt, cat, pe.proj)
+    xe, re_ = x, r
+    x, r = rt.parallel([lambda: embed(xe, bb.patch_embed), lambda: embed(re_, bb.patch_embed_radar)])
     outs, outs_r = [], []
+
+    def chain(act, blocks, prefix):
+        for j, blk in enumerate(blocks):
+            act = cluster_block(rt, act, blk, f"{prefix}.{j}.token_mixer")
+        return act
     for i in range(4):
-        for j, (blk, blk_r) in enumerate(zip(bb.network[3 * i], bb.network_radar[3 * i])):
-            x = cluster_block(rt, x, blk, f"backbone.backbone.network.{3 * i}.{j}.token_mixer")
-            r = cluster_block(rt, r, blk_r, f"backbone.backbone.network_radar.{3 * i}.{j}.token_mixer")
+        xi, ri = x, r
+        x, r = rt.parallel([
+            lambda: chain(xi, bb.network[3 * i], f"backbone.backbone.network.{3 * i}"),
+            lambda: chain(ri, bb.network_radar[3 * i], f"backbone.backbone.network_radar.{3 * i}")])
         x = image_enhance(rt, x, r, bb.network[3 * i + 1])
         r = radar_enhance(rt, x, r, bb.network_radar[3 * i + 1])
         if i in (0, 3):
             outs.append(x)
             outs_r.append(r)
         if i < 3:
-            x = simple_conv(rt, x, bb.network[3 * i + 2].proj)
-            r = simple_conv(rt, r, bb.network_radar[3 * i + 2].proj)
+            xf, rf = x, r
+            x, r = rt.parallel([lambda: simple_conv(rt, xf, bb.network[3 * i + 2].proj),
+                                lambda: simple_conv(rt, rf, bb.network_radar[3 * i + 2].proj)])
             if i < 2:
                 outs.append(x)
                 outs_r.append(r)
@@ -659,25 +726,32 @@ def backbone_forward(rt, bb, x, r):
 def neck_forward(rt, nk, x, r, seg_out):
     """CoCFpnDual.forward (coc_fpn_dual.py:184-224). seg_out: NCHW tensor for the seg logits."""
     (x2, x3, x4, x5), (r2, r3, r4, r5) = backbone_forward(rt, nk.backbone, x, r)
-    x5 = aspp(rt, x5, nk.aspp)
-    t = shuffle_attention(rt, cat2(rt, x4, coc_upsample(rt, x5, nk.upsample5_4), True), nk.sc_attn_seg4)
-    t = shuffle_attention(rt, cat2(rt, coc_upsample(rt, t, nk.upsample4_3), x3, True), nk.sc_attn_seg3)
-    t = shuffle_attention(rt, cat2(rt, coc_upsample(rt, t, nk.upsample3_2), x2, True), nk.sc_attn_seg2)
-    seg_lo = coc_upsample(rt, t, nk.upsample2_0, nchw_out=seg_out)
-    p5 = coc_conv(rt, r5, nk.p5_out_det, "backbone.p5_out_det.coc.token_mixer")
-    p4 = coc_conv(rt, cat2(rt, r4, coc_upsample(rt, p5, nk.p5_4_det), False), nk.p4_out_det,
-                  "backbone.p4_out_det.coc.token_mixer")
-    p3 = coc_conv(rt, cat2(rt, r3, coc_upsample(rt, p4, nk.p4_3_det), False), nk.p3_out_det,
-                  "backbone.p3_out_det.coc.token_mixer")
-    return (p3, p4, p5), seg_lo
+
+    def seg_branch():        # image-stream features only (coc_fpn_dual.py:193-209)
+        a5 = aspp(rt, x5, nk.aspp)
+        t = shuffle_attention(rt, cat2(rt, x4, coc_upsample(rt, a5, nk.upsample5_4), True), nk.sc_attn_seg4)
+        t = shuffle_attention(rt, cat2(rt, coc_upsample(rt, t, nk.upsample4_3), x3, True), nk.sc_attn_seg3)
+        t = shuffle_attention(rt, cat2(rt, coc_upsample(rt, t, nk.upsample3_2), x2, True), nk.sc_attn_seg2)
+        return coc_upsample(rt, t, nk.upsample2_0, nchw_out=seg_out)
+
+    def det_branch():        # radar-stream features only (coc_fpn_dual.py:213-221)
+        p5 = coc_conv(rt, r5, nk.p5_out_det, "backbone.p5_out_det.coc.token_mixer")
+        p4 = coc_conv(rt, cat2(rt, r4, coc_upsample(rt, p5, nk.p5_4_det), False), nk.p4_out_det,
+                      "backbone.p4_out_det.coc.token_mixer")
+        p3 = coc_conv(rt, cat2(rt, r3, coc_upsample(rt, p4, nk.p4_3_det), False), nk.p3_out_det,
+                      "backbone.p3_out_det.coc.token_mixer")
+        return (p3, p4, p5)
+    seg_lo, feats = rt.parallel([seg_branch, det_branch])
+    return feats, seg_lo
 
 
 def head_forward(rt, hd, feats, det_outs):
     """DecoupleHead.forward (decouplehead.py:42-88): the three prediction convs store straight into the
-    channel ranges [reg 0:4 | obj 4:5 | cls 5:] of the NCHW output (the reference's torch.cat)."""
+    channel ranges [reg 0:4 | obj 4:5 | cls 5:] of the NCHW output (the reference's torch.cat).  The three
+    pyramid levels are independent chains."""
     ctot = 5 + hd.num_classes
-    recs = []
-    for k, x in enumerate(feats):
+
+    def level(k, x):
         s = base_conv(rt, x, hd.stems[k])
         c = base_conv(rt, base_conv(rt, s, hd.cls_convs[k][0]), hd.cls_convs[k][1])
         g = base_conv(rt, base_conv(rt, s, hd.reg_convs[k][0]), hd.reg_convs[k][1])
@@ -685,22 +759,20 @@ def head_forward(rt, hd, feats, det_outs):
         conv_call(rt, g, hd.reg_preds[k], None, nchw=(out, ctot, 0))
         conv_call(rt, g, hd.obj_preds[k], None, nchw=(out, ctot, 4))
         conv_call(rt, c, hd.cls_preds[k], None, nchw=(out, ctot, 5))
-        recs.append((k, c, g))
-    return recs
 
-
-def head_backward(rt, hd, recs, det_grads):
-    ctot = 5 + hd.num_classes
-    for k, c, g in recs:
-        dg = det_grads[k]
-        if dg is None:
-            continue
-        B, _, h, w = dg.shape
-        d = rt.buf(B, h, w, ctot)
-        hip.nchw_to_nhwc(dg.contiguous(), d, ctot, B, ctot, h * w)
-        conv_backward(rt, g, hd.reg_preds[k], d, ctot)
-        conv_backward(rt, g, hd.obj_preds[k], d[..., 4:], ctot)
-        conv_backward(rt, c, hd.cls_preds[k], d[..., 5:], ctot)
+        def bwd():
+            dg = rt.det_grads[k]
+            if dg is None:
+                return
+            B, _, h, w = dg.shape
+            d = rt.buf(B, h, w, ctot)
+            hip.nchw_to_nhwc(dg.contiguous(), d, ctot, B, ctot, h * w)
+            conv_backward(rt, g, hd.reg_preds[k], d, ctot)
+            conv_backward(rt, g, hd.obj_preds[k], d[..., 4:], ctot)
+            conv_backward(rt, c, hd.cls_preds[k], d[..., 5:], ctot)
+        rt.push(bwd)
+        return None
+    rt.parallel([(lambda k=k, x=x: level(k, x)) for k, x in enumerate(feats)])
 
 
 class _VRNetFunction(torch.autograd.Function):
@@ -725,8 +797,8 @@ class _VRNetFunction(torch.autograd.Function):
         seg = torch.empty((B, ns, H, W), device=x.device)
         dets = [torch.empty((B, 5 + nc, H // s, W // s), device=x.device) for s in (8, 16, 32)]
         feats, seg_lo = neck_forward(rt, model.backbone, xa, ra, seg)
-        recs = head_forward(rt, model.head, feats, dets)
-        ctx.rt, ctx.recs, ctx.seg_lo, ctx.inputs = rt, recs, seg_lo, (xa, ra)
+        head_forward(rt, model.head, feats, dets)
+        ctx.rt, ctx.inputs = rt, (xa, ra)
         ctx.params = params
         ctx.model = model
         ctx.set_materialize_grads(False)
@@ -738,12 +810,7 @@ class _VRNetFunction(torch.autograd.Function):
         rt, model = ctx.rt, ctx.model
         if rt.tape is None:
             raise RuntimeError("EfficientVRNet backward called twice (activations are freed after the first pass)")
-        head_backward(rt, model.head, ctx.recs, (g0, g1, g2))
-        if gseg is not None:
-            lo = ctx.seg_lo
-            buf, acc = rt.grad_target(lo)
-            hip.upsample_bwd(gseg.contiguous(), 0, 1, buf, lo.C, lo.B, lo.H, lo.W, lo.C, model.backbone.upsample2_0.scale,
-                             accumulate=acc)
+        rt.det_grads, rt.seg_grad = (g0, g1, g2), gseg
         for fn in reversed(rt.tape):
             fn()
         rt.tape = None
@@ -775,7 +842,8 @@ class _VRNetFunction(torch.autograd.Function):
                         hip.add_(p.grad, g)
             outs.extend([None] * len(ctx.params))
         rt.pgrads.clear()
-        ctx.rt = ctx.recs = ctx.seg_lo = ctx.inputs = None
+        rt.det_grads = rt.seg_grad = None
+        ctx.rt = ctx.inputs = None
         return tuple(outs)
 
 
