@@ -48,16 +48,46 @@ class RT:
         self.on_param_grad = None
         self.bucketer = None        # parallel.GradBucketer: gradients are written into its flat buckets
         self.det_grads, self.seg_grad = (None, None, None), None
+        self._depth = 0
+        self._aside_pending = {}
+        self.aside_ok = True        # False with an eager data-parallel bucketer (its all-reduce needs one stream order)
         self.concurrent = True      # fork independent chains (image / radar, seg / det, head levels) onto side streams
 
     # ---- fork / join of independent chains -------------------------------------------------------------
     _side_streams = {}
+    _aux_streams = {}
 
     def _streams(self, n):
+        """n side streams for the current nesting depth (nested sections get their own streams)."""
         pool = RT._side_streams.setdefault(self.device, [])
-        while len(pool) < n:
+        lo = self._depth * 8
+        while len(pool) < lo + n:
             pool.append(torch.cuda.Stream(self.device))
-        return pool[:n]
+        return pool[lo:lo + n]
+
+    # ---- parameter-gradient kernels off the critical path ---------------------------------------------------
+    def aside(self, fn, keep):
+        """Runs `fn` (weight / parameter-gradient kernels, whose results no later backward kernel reads) on an
+        auxiliary stream forked from the current one, so the data-gradient chain continues meanwhile.  `keep`:
+        tensors `fn` reads; they are held until join_aside() so the allocator cannot recycle them early."""
+        if not self.concurrent or not self.aside_ok:
+            fn()
+            return
+        cur = torch.cuda.current_stream(self.device)
+        aux = RT._aux_streams.get(cur.cuda_stream)
+        if aux is None:
+            aux = RT._aux_streams[cur.cuda_stream] = torch.cuda.Stream(self.device)
+        aux.wait_stream(cur)
+        with torch.cuda.stream(aux):
+            fn()
+        self._aside_pending.setdefault(cur.cuda_stream, (cur, aux, []))[2].extend(keep)
+
+    def join_aside(self):
+        cur = torch.cuda.current_stream(self.device)
+        ent = self._aside_pending.pop(cur.cuda_stream, None)
+        if ent is not None:
+            cur.wait_stream(ent[1])
+            ent[2].clear()
 
     def parallel(self, fns):
         """Runs independent chains `fns` (callables issuing kernels) on forked HIP streams and joins them.
@@ -70,12 +100,14 @@ class RT:
         cur = torch.cuda.current_stream(self.device)
         streams = self._streams(len(fns))
         main_tape, outs, subtapes = self.tape, [], []
+        self._depth += 1
         for st, fn in zip(streams, fns):
             st.wait_stream(cur)
             self.tape = []
             with torch.cuda.stream(st):
                 outs.append(fn())
             subtapes.append(self.tape)
+        self._depth -= 1
         self.tape = main_tape
         for st in streams:
             cur.wait_stream(st)
@@ -85,11 +117,14 @@ class RT:
                 hook, deferred = self.on_param_grad, []
                 if hook is not None:           # a bucket's all-reduce must not start before BOTH chains have joined
                     self.on_param_grad = deferred.append
+                self._depth += 1
                 for st, sub in zip(streams, subtapes):
                     st.wait_stream(cur_b)
                     with torch.cuda.stream(st):
                         for f in reversed(sub):
                             f()
+                        self.join_aside()
+                self._depth -= 1
                 for st in streams:
                     cur_b.wait_stream(st)
                 if hook is not None:
@@ -204,12 +239,15 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
     if gw is not None or gb is not None:
         assert gb is None or gw is not None
         assert gb is None or accb == accw
-        hip.conv2d_wgrad(x.t, x.ld, dy, lddy, gw, gb, row_scale, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
-                         accumulate=accw)
-        if rt.on_param_grad:
-            rt.on_param_grad(conv.weight)
-            if gb is not None:
-                rt.on_param_grad(conv.bias)
+
+        def wgrad():
+            hip.conv2d_wgrad(x.t, x.ld, dy, lddy, gw, gb, row_scale, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
+                             accumulate=accw)
+            if rt.on_param_grad:
+                rt.on_param_grad(conv.weight)
+                if gb is not None:
+                    rt.on_param_grad(conv.bias)
+        rt.aside(wgrad, (x.t, dy))
     target = dx_to if dx_to is not None else (x if x.need_grad else None)
     if target is not None:
         if dx_to is not None:
@@ -389,6 +427,7 @@ def cluster_block(rt, x, m, name=None):
         conv_backward(rt, h, mlp.fc2, dx2, C, kscale=ls2, aux=u, row_scale=ls2, skip_bias=True, dx_to=du)
         dxn2 = rt.new(B, H, W, C)
         conv_backward(rt, xn2, mlp.fc1, du.t, hid, dx_to=dxn2)
+        rt.join_aside()                                          # fc2's wgrad (aside) still reads dx2
         gn_backward(rt, m.norm2, x1, ms2, dxn2.t, dx2, accumulate=1)          # dx2 now holds dx1
         # ---- Cluster branch
         ls1 = m.layer_scale_1
@@ -413,6 +452,7 @@ def cluster_block(rt, x, m, name=None):
         xn.grad = dxn.t                                          # fc_v accumulates onto fc1's dx
         xn.need_grad = True
         conv_backward(rt, xn, tm.fc_v, dv.t, ED)
+        rt.join_aside()                                          # token fc2's wgrad (aside) still reads dx2
         gn_backward(rt, m.norm1, x, ms1, take_grad(xn), dx2, accumulate=1)     # dx2 now holds dx
         rt.give_grad(x, dx2)
     rt.push(bwd)
@@ -622,22 +662,28 @@ def aspp(rt, x, m):
     B, H, W, C = x.B, x.H, x.W, x.C
     HW = H * W
     cat = rt.new(B, H, W, 5 * C)
-    saved = []
-    for k, br in enumerate((m.branch1, m.branch2, m.branch3, m.branch4)):
+
+    def conv_branch(k, br):
         conv, bn = br[0], br[1]
         z = rt.new(B, H, W, C)
         conv_call(rt, x, conv, z)
         sl = Act(cat.t[..., k * C:(k + 1) * C])
         _, ms = bn_forward(rt, z, bn, relu=True, out=sl)
-        saved.append((conv, bn, z, sl, ms))
-    # global-average branch: (B,1,1,C) "pixels"
-    gm = rt.new(B, 1, 1, C)
-    hip.moments_to_float(hip.moments(x.t, x.ld, B, HW, C), gm.t, B * C, 1.0 / HW)
-    z5 = rt.new(B, 1, 1, C)
-    conv_call(rt, gm, m.branch5_conv, z5)
-    q5, ms5 = bn_forward(rt, z5, m.branch5_bn, relu=True)
-    sl5 = cat.t[..., 4 * C:]
-    hip.affine(sl5, 5 * C, B, HW, C, D2=q5.t, bstride=C)           # bilinear from 1x1, align_corners: constant
+        return (conv, bn, z, sl, ms)
+
+    def pool_branch():      # global-average branch: (B,1,1,C) "pixels"
+        gm = rt.new(B, 1, 1, C)
+        hip.moments_to_float(hip.moments(x.t, x.ld, B, HW, C), gm.t, B * C, 1.0 / HW)
+        z5 = rt.new(B, 1, 1, C)
+        conv_call(rt, gm, m.branch5_conv, z5)
+        q5, ms5 = bn_forward(rt, z5, m.branch5_bn, relu=True)
+        hip.affine(cat.t[..., 4 * C:], 5 * C, B, HW, C, D2=q5.t, bstride=C)   # bilinear from 1x1, align_corners: constant
+        return gm, z5, q5, ms5
+    record, rt.record = rt.record, False          # one hand-written closure below covers all five branches
+    res = rt.parallel([(lambda k=k, br=br: conv_branch(k, br))
+                       for k, br in enumerate((m.branch1, m.branch2, m.branch3, m.branch4))] + [pool_branch])
+    rt.record = record
+    saved, (gm, z5, q5, ms5) = res[:4], res[4]
     convc, bnc = m.conv_cat[0], m.conv_cat[1]
     zc = rt.new(B, H, W, C)
     conv_call(rt, cat, convc, zc)
@@ -788,6 +834,7 @@ class _VRNetFunction(torch.autograd.Function):
         record = any(ctx.needs_input_grad)
         rt = RT(x.device, model.training, record)
         rt.bucketer = getattr(model, "_grad_bucketer", None)
+        rt.aside_ok = rt.bucketer is None or rt.bucketer.deferred
         rt.on_param_grad = getattr(model, "_on_param_grad", None) if rt.bucketer is not None else None
         xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=ctx.needs_input_grad[1])
         ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=ctx.needs_input_grad[2])
@@ -813,6 +860,7 @@ class _VRNetFunction(torch.autograd.Function):
         rt.det_grads, rt.seg_grad = (g0, g1, g2), gseg
         for fn in reversed(rt.tape):
             fn()
+            rt.join_aside()
         rt.tape = None
         xa, ra = ctx.inputs
         outs = [None]
