@@ -49,6 +49,7 @@ class RT:
         self.bucketer = None        # parallel.GradBucketer: gradients are written into its flat buckets
         self.det_grads, self.seg_grad = (None, None, None), None
         self._depth = 0
+        self._chain = "main"        # logical chain id: "main" or (depth, branch index)
         self._aside_pending = {}
         self.aside_ok = True        # False with an eager data-parallel bucketer (its all-reduce needs one stream order)
         self.concurrent = True      # fork independent chains (image / radar, seg / det, head levels) onto side streams
@@ -74,20 +75,22 @@ class RT:
             fn()
             return
         cur = torch.cuda.current_stream(self.device)
-        aux = RT._aux_streams.get(cur.cuda_stream)
+        # auxiliary streams are keyed by the LOGICAL position (main chain, or branch i at depth d), not by the
+        # stream handle: the same objects (created in warm-up) are then reused under hipGraph capture
+        key = (self.device, self._chain)
+        aux = RT._aux_streams.get(key)
         if aux is None:
-            aux = RT._aux_streams[cur.cuda_stream] = torch.cuda.Stream(self.device)
+            aux = RT._aux_streams[key] = torch.cuda.Stream(self.device)
         aux.wait_stream(cur)
         with torch.cuda.stream(aux):
             fn()
-        self._aside_pending.setdefault(cur.cuda_stream, (cur, aux, []))[2].extend(keep)
+        self._aside_pending.setdefault(self._chain, (aux, []))[1].extend(keep)
 
     def join_aside(self):
-        cur = torch.cuda.current_stream(self.device)
-        ent = self._aside_pending.pop(cur.cuda_stream, None)
+        ent = self._aside_pending.pop(self._chain, None)
         if ent is not None:
-            cur.wait_stream(ent[1])
-            ent[2].clear()
+            torch.cuda.current_stream(self.device).wait_stream(ent[0])
+            ent[1].clear()
 
     def parallel(self, fns):
         """Runs independent chains `fns` (callables issuing kernels) on forked HIP streams and joins them.
@@ -101,12 +104,15 @@ class RT:
         streams = self._streams(len(fns))
         main_tape, outs, subtapes = self.tape, [], []
         self._depth += 1
-        for st, fn in zip(streams, fns):
+        outer_chain = self._chain
+        for bi, (st, fn) in enumerate(zip(streams, fns)):
             st.wait_stream(cur)
             self.tape = []
+            self._chain = (self._depth, bi)
             with torch.cuda.stream(st):
                 outs.append(fn())
             subtapes.append(self.tape)
+        self._chain = outer_chain
         self._depth -= 1
         self.tape = main_tape
         for st in streams:
@@ -118,12 +124,15 @@ class RT:
                 if hook is not None:           # a bucket's all-reduce must not start before BOTH chains have joined
                     self.on_param_grad = deferred.append
                 self._depth += 1
-                for st, sub in zip(streams, subtapes):
+                outer = self._chain
+                for bi, (st, sub) in enumerate(zip(streams, subtapes)):
                     st.wait_stream(cur_b)
+                    self._chain = (self._depth, bi)
                     with torch.cuda.stream(st):
                         for f in reversed(sub):
                             f()
                         self.join_aside()
+                self._chain = outer
                 self._depth -= 1
                 for st in streams:
                     cur_b.wait_stream(st)
