@@ -9,6 +9,8 @@ flags) and parameter gradients are written once per parameter.  A single autogra
 exposes the whole network to torch.autograd, so `loss.backward()`, optimizers, EMA deep-copies
 and state_dict work exactly as with the reference module.
 """
+import os
+
 import torch
 
 from . import hip
@@ -51,6 +53,7 @@ class RT:
         self._depth = 0
         self._chain = "main"        # logical chain id: "main" or (depth, branch index)
         self._aside_pending = {}
+        self._deferred_wgrads = []
         self.aside_ok = True        # False with an eager data-parallel bucketer (its all-reduce needs one stream order)
         self.concurrent = True      # fork independent chains (image / radar, seg / det, head levels) onto side streams
 
@@ -67,30 +70,50 @@ class RT:
         return pool[lo:lo + n]
 
     # ---- parameter-gradient kernels off the critical path ---------------------------------------------------
+    # hipGraph capture on ROCm 7 only accepts a STAR of streams around the capturing stream: a dependency between two
+    # side streams crashes hipStreamEndCapture (tools/micro/graph_fork_probe.py).  Hence: on the main chain a weight
+    # gradient forks an auxiliary stream directly; inside a forked chain it is deferred and all deferred weight
+    # gradients of the section run, mutually concurrent, on the section's side streams once the chains have joined.
     def aside(self, fn, keep):
-        """Runs `fn` (weight / parameter-gradient kernels, whose results no later backward kernel reads) on an
-        auxiliary stream forked from the current one, so the data-gradient chain continues meanwhile.  `keep`:
-        tensors `fn` reads; they are held until join_aside() so the allocator cannot recycle them early."""
+        """`fn` launches weight / parameter-gradient kernels whose results no later backward kernel reads;
+        `keep`: tensors it reads (held until it has been ordered before their release)."""
         if not self.concurrent or not self.aside_ok:
             fn()
             return
+        if self._chain != "main":
+            self._deferred_wgrads.append((fn, keep))
+            return
         cur = torch.cuda.current_stream(self.device)
-        # auxiliary streams are keyed by the LOGICAL position (main chain, or branch i at depth d), not by the
-        # stream handle: the same objects (created in warm-up) are then reused under hipGraph capture
-        key = (self.device, self._chain)
+        key = (self.device, "aux")
         aux = RT._aux_streams.get(key)
         if aux is None:
             aux = RT._aux_streams[key] = torch.cuda.Stream(self.device)
         aux.wait_stream(cur)
         with torch.cuda.stream(aux):
             fn()
-        self._aside_pending.setdefault(self._chain, (aux, []))[1].extend(keep)
+        self._aside_pending.setdefault("main", (aux, []))[1].extend(keep)
 
     def join_aside(self):
-        ent = self._aside_pending.pop(self._chain, None)
+        if self._chain != "main":
+            return
+        ent = self._aside_pending.pop("main", None)
         if ent is not None:
             torch.cuda.current_stream(self.device).wait_stream(ent[0])
             ent[1].clear()
+
+    def _run_deferred_wgrads(self, cur):
+        work, self._deferred_wgrads = self._deferred_wgrads, []
+        if not work:
+            return
+        streams = self._streams(min(4, len(work)))
+        for st in streams:
+            st.wait_stream(cur)
+        for i, (fn, _) in enumerate(work):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                fn()
+        for st in streams:
+            cur.wait_stream(st)
+        work.clear()
 
     def parallel(self, fns):
         """Runs independent chains `fns` (callables issuing kernels) on forked HIP streams and joins them.
@@ -98,7 +121,7 @@ class RT:
         sub-tapes concurrently.  Allocator safety: inside a chain the side stream is torch's current stream, so
         its temporaries live in that stream's pool; buffers crossing the fork / join are ordered by the events
         (wait_stream) on both sides.  Under hipGraph capture the fork / join become graph edges."""
-        if not self.concurrent or len(fns) < 2:
+        if not self.concurrent or len(fns) < 2 or self._depth > 0:      # no nested forks (star topology only)
             return [fn() for fn in fns]
         cur = torch.cuda.current_stream(self.device)
         streams = self._streams(len(fns))
@@ -131,11 +154,11 @@ class RT:
                     with torch.cuda.stream(st):
                         for f in reversed(sub):
                             f()
-                        self.join_aside()
                 self._chain = outer
                 self._depth -= 1
                 for st in streams:
                     cur_b.wait_stream(st)
+                self._run_deferred_wgrads(cur_b)
                 if hook is not None:
                     self.on_param_grad = hook
                     for prm in deferred:
@@ -239,7 +262,8 @@ def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw
                    out_nchw=1, out_ctot=ctot, out_coff=coff)
 
 
-def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, skip_bias=False, dx_to=None):
+def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, skip_bias=False, dx_to=None,
+                  defer_ok=True):
     """Gradients of y = conv(x): weight/bias into the parameter table, dx accumulated into x.grad
     (or written to the Act `dx_to`).  dy: tensor whose data_ptr is the (0,0) element, row stride lddy."""
     co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, conv)
@@ -256,7 +280,10 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
                 rt.on_param_grad(conv.weight)
                 if gb is not None:
                     rt.on_param_grad(conv.bias)
-        rt.aside(wgrad, (x.t, dy))
+        if defer_ok:
+            rt.aside(wgrad, (x.t, dy))
+        else:                    # dy is updated in place later in this closure: the weight gradient must read it now
+            wgrad()
     target = dx_to if dx_to is not None else (x if x.need_grad else None)
     if target is not None:
         if dx_to is not None:
@@ -433,17 +460,16 @@ def cluster_block(rt, x, m, name=None):
         mom2 = hip.moments(dx2, C, B, H * W, C, x2=t2.t, ldx2=C)
         _ls_grads(rt, mom2, ls2, mlp.fc2.bias, B, C)
         du = rt.new(B, H, W, hid)
-        conv_backward(rt, h, mlp.fc2, dx2, C, kscale=ls2, aux=u, row_scale=ls2, skip_bias=True, dx_to=du)
+        conv_backward(rt, h, mlp.fc2, dx2, C, kscale=ls2, aux=u, row_scale=ls2, skip_bias=True, dx_to=du, defer_ok=False)
         dxn2 = rt.new(B, H, W, C)
         conv_backward(rt, xn2, mlp.fc1, du.t, hid, dx_to=dxn2)
-        rt.join_aside()                                          # fc2's wgrad (aside) still reads dx2
         gn_backward(rt, m.norm2, x1, ms2, dxn2.t, dx2, accumulate=1)          # dx2 now holds dx1
         # ---- Cluster branch
         ls1 = m.layer_scale_1
         mom2 = hip.moments(dx2, C, B, H * W, C, x2=t1.t, ldx2=C)
         _ls_grads(rt, mom2, ls1, tm.fc2.bias, B, C)
         do = rt.new(B, H, W, ED)
-        conv_backward(rt, o, tm.fc2, dx2, C, kscale=ls1, row_scale=ls1, skip_bias=True, dx_to=do)
+        conv_backward(rt, o, tm.fc2, dx2, C, kscale=ls1, row_scale=ls1, skip_bias=True, dx_to=do, defer_ok=False)
         df, dv = rt.new(B, H, W, ED), rt.new(B, H, W, ED)
         ga, acca = rt.pgrad(tm.sim_alpha)
         gb, _ = rt.pgrad(tm.sim_beta)
@@ -461,7 +487,6 @@ def cluster_block(rt, x, m, name=None):
         xn.grad = dxn.t                                          # fc_v accumulates onto fc1's dx
         xn.need_grad = True
         conv_backward(rt, xn, tm.fc_v, dv.t, ED)
-        rt.join_aside()                                          # token fc2's wgrad (aside) still reads dx2
         gn_backward(rt, m.norm1, x, ms1, take_grad(xn), dx2, accumulate=1)     # dx2 now holds dx
         rt.give_grad(x, dx2)
     rt.push(bwd)
