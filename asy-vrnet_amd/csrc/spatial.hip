@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* x, lo
                                                               int B, int H, int W, int C, long rows_per_chunk,
                                                               float* partial) {
   __shared__ float sm[256 * 9];
-  const int TPR = min(256, C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256)));
+  const int TPR = C <= 32 ? 32 : 64;        // 4-8 x positions in flight per channel: more workgroups, more ILP
   const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR, RP = 256 / TPR;
   const int c = blockIdx.y * TPR + tx;
   const int nrows = B * H;
@@ -494,7 +494,7 @@ extern "C" int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* 
     vr_set_error("dwconv3x3_wgrad: workspace too small");
     return VR_ERR_WORKSPACE;
   }
-  const int TPR = C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256));
+  const int TPR = C <= 32 ? 32 : 64;
   float* partial = reinterpret_cast<float*>(workspace);
   hipStream_t st = vr_stream(stream);
   hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(nchunks, vr_cdiv(C, TPR)), dim3(256), 0, st, x, ldx, dy, lddy, B, H, W,

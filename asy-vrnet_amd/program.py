@@ -867,6 +867,7 @@ class _VRNetFunction(torch.autograd.Function):
             raise RuntimeError(f"input size {H}x{W} must be a multiple of 64 (fold-2 Cluster on the H/32 map)")
         record = any(ctx.needs_input_grad)
         rt = RT(x.device, model.training, record)
+        rt.concurrent = bool(getattr(model, "concurrent", True))
         rt.bucketer = getattr(model, "_grad_bucketer", None)
         rt.aside_ok = rt.bucketer is None or rt.bucketer.deferred
         rt.on_param_grad = getattr(model, "_on_param_grad", None) if rt.bucketer is not None else None

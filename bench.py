@@ -11,9 +11,9 @@ before the timed region.  Rank 0 prints ONE JSON line.
 Extra objects in the line:
   roofline      dominant kernel class (implicit-GEMM conv fwd/dgrad on the fp32 MFMA): algorithmic FLOPs per
                 launch / average launch duration, measured with HIP events on the launch stream in an
-                instrumented replay of the timed steps (events around ~700 launches per step would perturb
-                `value`, so the timed region itself is un-instrumented); profiles/ holds the rocprofv3 summary
-                of the same command.
+                instrumented, serialised replay of the timed steps (the timed region itself runs as one captured
+                hipGraph with independent chains on concurrent streams, where an event pair would bracket several
+                overlapping kernels); profiles/ holds the rocprofv3 summary of the same command.
   cpu_baseline  the CPU oracle (pure-torch restatement, kind "port") timed on the host cores, N=1 only.
 """
 import argparse
@@ -211,11 +211,13 @@ def main():
 
     roof = None
     if not args.no_roofline:
+        model.concurrent = False      # serial launches: an event pair then brackets exactly one kernel
         with ConvTimer(hip) as ct:
             for i in range(args.steps):
                 eager_step(args.warmup + i)
             n, flops, ms = ct.summary("igemm")
             nw, fw, msw = ct.summary("wgrad")
+        model.concurrent = True
         ach = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32)",
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
