@@ -514,22 +514,41 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64) ? 8 : 1) void wgrad_ker
 }
 
 // dw (OIHW) = row_scale[n] * sum_s slab[s][t][n][c] (+ dw);  db[n] = row_scale[n] * sum_s bslab[s][n] (+ db)
-__global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, const float* row_scale, float* dw,
-                                    float* db, int S, int T, int Cout, int Cin, int accumulate) {
+template <int VEC>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, const float* bslab, const float* row_scale,
+                                                           float* dw, float* db, int S, int T, int Cout, int Cin,
+                                                           int accumulate) {
   const long per = (long)T * Cout * Cin;
+  const long nq = per / VEC;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < per) {
-    const int c = e % Cin;
-    const long q = e / Cin;
+  if (e < nq) {
+    const long idx = e * VEC;
+    const int c = idx % Cin;
+    const long q = idx / Cin;
     const int n = q % Cout;
     const int t = q / Cout;
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += slab[(long)k * per + e];
-    if (row_scale) s *= row_scale[n];
-    float* d = dw + ((long)n * Cin + c) * T + t;
-    *d = accumulate ? *d + s : s;
-  } else if (db && e < per + Cout) {
-    const int n = e - per;
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < S; ++k) {
+      if (VEC == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(slab + (long)k * per + idx);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s[j] += v[j];
+      } else {
+        s[0] += slab[(long)k * per + idx];
+      }
+    }
+    const float rs = row_scale ? row_scale[n] : 1.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float* d = dw + ((long)n * Cin + c + j) * T + t;
+      const float v = s[j] * rs;
+      *d = accumulate ? *d + v : v;
+    }
+  } else if (db && e < nq + Cout) {
+    const int n = e - nq;
     float s = 0.f;
     for (int k = 0; k < S; ++k) s += bslab[(long)k * Cout + n];
     if (row_scale) s *= row_scale[n];
@@ -754,9 +773,14 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   else VR_WGRAD(128, 32, 1, 1, 4, 1);
 #undef VR_WGRAD
   VR_LAUNCH_CHECK("conv2d_wgrad");
-  const long total = (long)T * Cout * Cin + (dbias ? Cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(vr_cdiv(total, 256)), dim3(256), 0, st, p.slab, p.bslab, row_scale, dw,
-                     dbias, S, T, Cout, Cin, accumulate);
+  const bool rvec = (Cin % 4 == 0);                 // slabs are 16-byte aligned (workspace arena), rows of Cin floats
+  const long total = (long)T * Cout * Cin / (rvec ? 4 : 1) + (dbias ? Cout : 0);
+  if (rvec)
+    hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3(vr_cdiv(total, 256)), dim3(256), 0, st, p.slab, p.bslab, row_scale,
+                       dw, dbias, S, T, Cout, Cin, accumulate);
+  else
+    hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(vr_cdiv(total, 256)), dim3(256), 0, st, p.slab, p.bslab, row_scale,
+                       dw, dbias, S, T, Cout, Cin, accumulate);
   VR_LAUNCH_CHECK("conv2d_wgrad_reduce");
   return VR_OK;
 }

@@ -101,16 +101,22 @@ class RT:
             torch.cuda.current_stream(self.device).wait_stream(ent[0])
             ent[1].clear()
 
-    def _run_deferred_wgrads(self, cur):
+    def _launch_deferred_wgrads(self, cur, streams):
+        """Issues the pending deferred weight gradients round-robin on `streams` (already forked from `cur`)."""
         work, self._deferred_wgrads = self._deferred_wgrads, []
-        if not work:
-            return
-        streams = self._streams(min(4, len(work)))
-        for st in streams:
-            st.wait_stream(cur)
         for i, (fn, _) in enumerate(work):
             with torch.cuda.stream(streams[i % len(streams)]):
                 fn()
+        return work          # keeps the tensors alive until the caller has joined the streams
+
+    def flush_deferred_wgrads(self):
+        if not self._deferred_wgrads:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        streams = self._streams(8)[4:8]
+        for st in streams:
+            st.wait_stream(cur)
+        work = self._launch_deferred_wgrads(cur, streams)
         for st in streams:
             cur.wait_stream(st)
         work.clear()
@@ -146,6 +152,11 @@ class RT:
                 hook, deferred = self.on_param_grad, []
                 if hook is not None:           # a bucket's all-reduce must not start before BOTH chains have joined
                     self.on_param_grad = deferred.append
+                # weight gradients deferred by the PREVIOUS section run beside this section's data-gradient chains
+                wstreams = self._streams(8)[4:8] if self._deferred_wgrads else []
+                for st in wstreams:
+                    st.wait_stream(cur_b)
+                held = self._launch_deferred_wgrads(cur_b, wstreams) if wstreams else []
                 self._depth += 1
                 outer = self._chain
                 for bi, (st, sub) in enumerate(zip(streams, subtapes)):
@@ -156,10 +167,10 @@ class RT:
                             f()
                 self._chain = outer
                 self._depth -= 1
-                for st in streams:
+                for st in list(streams) + list(wstreams):
                     cur_b.wait_stream(st)
-                self._run_deferred_wgrads(cur_b)
-                if hook is not None:
+                held.clear()
+                if hook is not None:           # (only with an eager bucketer, where nothing is deferred: aside_ok False)
                     self.on_param_grad = hook
                     for prm in deferred:
                         hook(prm)
@@ -896,6 +907,7 @@ class _VRNetFunction(torch.autograd.Function):
         for fn in reversed(rt.tape):
             fn()
             rt.join_aside()
+        rt.flush_deferred_wgrads()
         rt.tape = None
         xa, ra = ctx.inputs
         outs = [None]
