@@ -287,41 +287,45 @@ struct SaParams {
 };
 __device__ __forceinline__ int sa_dst(int q, int C) { return q < C / 2 ? 2 * q : 2 * (q - C / 2) + 1; }
 
-__global__ void sa_coef_fwd_kernel(const double* mom, SaParams sp, int B, long HW, int C, int G, float* P, float* Q) {
+__global__ void sa_coef_fwd_kernel(const double* mom, SaParams sp, int B, long HW, int C, int G, float* P, float* Q,
+                                   float* Mn) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)B * C) return;
   const int q = e % C, cp = C / (2 * G);
   const int rem = q % (2 * cp), half = rem / cp, i = rem % cp;
   const double mean = mom[2 * e] / (double)HW;
-  if (half == 0) {
+  if (half == 0) {                       // gate = sigmoid(P * (x - Mn) + Q)
     P[e] = 0.f;
     Q[e] = (float)((double)sp.cw[i] * mean + (double)sp.cb[i]);
+    Mn[e] = 0.f;
   } else {
     double var = mom[2 * e + 1] / (double)HW - mean * mean;
     if (var < 0) var = 0;
     const double r = 1.0 / sqrt(var + 1e-5);
     P[e] = (float)((double)sp.sw[i] * sp.gnw[i] * r);
-    Q[e] = (float)((double)sp.sw[i] * ((double)sp.gnb[i] - (double)sp.gnw[i] * mean * r) + (double)sp.sb[i]);
+    Q[e] = (float)((double)sp.sw[i] * (double)sp.gnb[i] + (double)sp.sb[i]);
+    Mn[e] = (float)mean;
   }
 }
 
-__global__ __launch_bounds__(256) void sa_apply_kernel(const float* x, long ldx, const float* P, const float* Q, float* y,
-                                                       long ldy, long HW, int C) {
+__global__ __launch_bounds__(256) void sa_apply_kernel(const float* x, long ldx, const float* P, const float* Q,
+                                                       const float* Mn, float* y, long ldy, long HW, int C) {
   const long b = blockIdx.y;
   const long total = HW * C;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long r = e / C;
     const int q = e - r * C;
     const float xv = x[(b * HW + r) * ldx + q];
-    const float z = P[b * C + q] * xv + Q[b * C + q];
+    const float z = P[b * C + q] * (xv - Mn[b * C + q]) + Q[b * C + q];
     y[(b * HW + r) * ldy + sa_dst(q, C)] = xv * vr_sigmoid(z);
   }
 }
 
 // per (b,q): T1 = sum dz, T2 = sum dz*x with dz = dy[dst(q)] * x * sig'(z); one workgroup per (row chunk, b)
 __global__ __launch_bounds__(256) void sa_bwd_reduce_kernel(const float* dy, long lddy, const float* x, long ldx,
-                                                            const float* P, const float* Q, long HW, int C, int TPR,
-                                                            long rows_per_chunk, int nchunks, double* partial) {
+                                                            const float* P, const float* Q, const float* Mn, long HW,
+                                                            int C, int TPR, long rows_per_chunk, int nchunks,
+                                                            double* partial) {
   extern __shared__ double smd[];   // [256][2]
   const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR, RP = 256 / TPR;
   const int chunk = blockIdx.x;
@@ -330,11 +334,11 @@ __global__ __launch_bounds__(256) void sa_bwd_reduce_kernel(const float* dy, lon
   const long r0 = chunk * rows_per_chunk, r1 = min(HW, r0 + rows_per_chunk);
   double t1 = 0, t2 = 0;
   if (q < C) {
-    const float pq = P[b * C + q], qq = Q[b * C + q];
+    const float pq = P[b * C + q], qq = Q[b * C + q], mq = Mn[b * C + q];
     const int dq = sa_dst(q, C);
     for (long r = r0 + ty; r < r1; r += RP) {
       const float xv = x[(b * HW + r) * ldx + q];
-      const float sg = vr_sigmoid(pq * xv + qq);
+      const float sg = vr_sigmoid(pq * (xv - mq) + qq);
       const double dz = (double)(dy[(b * HW + r) * lddy + dq] * xv * sg * (1.f - sg));
       t1 += dz;
       t2 += dz * (double)xv;
@@ -383,8 +387,8 @@ __global__ __launch_bounds__(256) void sa_coef_bwd_kernel(const double* T, const
       const double r = 1.0 / sqrt(var + 1e-5);
       const double k = (double)sp.sw[i] * sp.gnw[i];
       const double m1 = k * t1 / (double)HW, m2 = k * r * (t2 - mean * t1) / (double)HW;
-      E[e] = (float)(-r * r * m2);
-      F[e] = (float)(-r * m1 + r * r * m2 * mean);
+      E[e] = (float)(-r * r * m2);           // dx = dy * (...) + E * (x - Mn) + F
+      F[e] = (float)(-r * m1);
     }
   } else {
     for (int i = threadIdx.x; i < cp; i += 256) {
@@ -422,18 +426,19 @@ __global__ __launch_bounds__(256) void sa_coef_bwd_kernel(const double* T, const
 }
 
 __global__ __launch_bounds__(256) void sa_bwd_apply_kernel(const float* dy, long lddy, const float* x, long ldx,
-                                                           const float* P, const float* Q, const float* E, const float* F,
-                                                           float* dx, long lddx, long HW, int C, int accumulate) {
+                                                           const float* P, const float* Q, const float* Mn, const float* E,
+                                                           const float* F, float* dx, long lddx, long HW, int C,
+                                                           int accumulate) {
   const long b = blockIdx.y;
   const long total = HW * C;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long r = e / C;
     const int q = e - r * C;
     const float xv = x[(b * HW + r) * ldx + q];
-    const float pq = P[b * C + q];
-    const float sg = vr_sigmoid(pq * xv + Q[b * C + q]);
+    const float pq = P[b * C + q], mq = Mn[b * C + q];
+    const float sg = vr_sigmoid(pq * (xv - mq) + Q[b * C + q]);
     const float g = dy[(b * HW + r) * lddy + sa_dst(q, C)];
-    const float v = g * (sg + xv * sg * (1.f - sg) * pq) + E[b * C + q] * xv + F[b * C + q];
+    const float v = g * (sg + xv * sg * (1.f - sg) * pq) + E[b * C + q] * (xv - mq) + F[b * C + q];
     float* d = dx + (b * HW + r) * lddx + q;
     *d = accumulate ? *d + v : v;
   }
@@ -566,21 +571,21 @@ extern "C" int vrnet_enhance_bwd_f32(const float* dt, const float* x, const floa
 
 extern "C" int vrnet_sa_coef_fwd(const double* mom, const float* cw, const float* cb, const float* sw, const float* sb,
                                  const float* gnw, const float* gnb, int B, long HW, int C, int G, float* P, float* Q,
-                                 void* stream) {
-  VR_CHECK_ARG(mom && cw && cb && sw && sb && gnw && gnb && P && Q, "sa_coef_fwd: null tensor");
+                                 float* Mn, void* stream) {
+  VR_CHECK_ARG(mom && cw && cb && sw && sb && gnw && gnb && P && Q && Mn, "sa_coef_fwd: null tensor");
   VR_CHECK_ARG(G > 0 && C % (2 * G) == 0 && C / (2 * G) > 0, "sa_coef_fwd: channels %d not divisible by 2*G=%d", C, 2 * G);
   SaParams sp{cw, cb, sw, sb, gnw, gnb};
   hipLaunchKernelGGL(sa_coef_fwd_kernel, dim3(vr_cdiv((long)B * C, 256)), dim3(256), 0, vr_stream(stream), mom, sp, B, HW,
-                     C, G, P, Q);
+                     C, G, P, Q, Mn);
   VR_LAUNCH_CHECK("sa_coef_fwd");
   return VR_OK;
 }
 
-extern "C" int vrnet_sa_apply_f32(const float* x, long ldx, const float* P, const float* Q, float* y, long ldy, int B,
-                                  long HW, int C, void* stream) {
-  VR_CHECK_ARG(x && P && Q && y && C % 2 == 0, "sa_apply: bad arguments");
-  hipLaunchKernelGGL(sa_apply_kernel, dim3(grid_for(HW * C), B), dim3(256), 0, vr_stream(stream), x, ldx, P, Q, y, ldy, HW,
-                     C);
+extern "C" int vrnet_sa_apply_f32(const float* x, long ldx, const float* P, const float* Q, const float* Mn, float* y,
+                                  long ldy, int B, long HW, int C, void* stream) {
+  VR_CHECK_ARG(x && P && Q && Mn && y && C % 2 == 0, "sa_apply: bad arguments");
+  hipLaunchKernelGGL(sa_apply_kernel, dim3(grid_for(HW * C), B), dim3(256), 0, vr_stream(stream), x, ldx, P, Q, Mn, y, ldy,
+                     HW, C);
   VR_LAUNCH_CHECK("sa_apply");
   return VR_OK;
 }
@@ -593,12 +598,12 @@ extern "C" long vrnet_sa_bwd_workspace(int B, long HW, int C) {
 }
 
 extern "C" int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long ldx, const float* P, const float* Q,
-                                const double* mom, const float* cw, const float* cb, const float* sw, const float* sb,
+                                const float* Mn, const double* mom, const float* cw, const float* cb, const float* sw, const float* sb,
                                 const float* gnw, const float* gnb, float* dx, long lddx, float* dcw, float* dcb,
                                 float* dsw, float* dsb, float* dgnw, float* dgnb, float* EF /*[2][B][C] scratch*/, int B,
                                 long HW, int C, int G, int accumulate_dx, int accumulate_params, void* workspace,
                                 long workspace_bytes, void* stream) {
-  VR_CHECK_ARG(dy && x && P && Q && mom && dx && EF && workspace, "sa_bwd: null tensor");
+  VR_CHECK_ARG(dy && x && P && Q && Mn && mom && dx && EF && workspace, "sa_bwd: null tensor");
   VR_CHECK_ARG(workspace_bytes >= vrnet_sa_bwd_workspace(B, HW, C), "sa_bwd: workspace too small");
   int TPR, ncb, nchunks;
   long rows;
@@ -607,7 +612,7 @@ extern "C" int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long
   double* T = partial + (long)B * nchunks * C * 2;
   hipStream_t st = vr_stream(stream);
   hipLaunchKernelGGL(sa_bwd_reduce_kernel, dim3(nchunks, B, ncb), dim3(256), 256 * 2 * sizeof(double), st, dy, lddy, x,
-                     ldx, P, Q, HW, C, TPR, rows, nchunks, partial);
+                     ldx, P, Q, Mn, HW, C, TPR, rows, nchunks, partial);
   VR_LAUNCH_CHECK("sa_bwd_reduce");
   hipLaunchKernelGGL(sa_reduce_chunks_kernel, dim3(vr_cdiv((long)B * C * 2, 256)), dim3(256), 0, st, partial, T, B,
                      nchunks, C);
@@ -619,7 +624,7 @@ extern "C" int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long
   hipLaunchKernelGGL(sa_coef_bwd_kernel, dim3(nb1 + 1), dim3(256), 0, st, T, mom, sp, B, HW, C, G, nb1, E, F, dcw, dcb,
                      dsw, dsb, dgnw, dgnb, accumulate_params);
   VR_LAUNCH_CHECK("sa_coef_bwd");
-  hipLaunchKernelGGL(sa_bwd_apply_kernel, dim3(grid_for(HW * C), B), dim3(256), 0, st, dy, lddy, x, ldx, P, Q, E, F, dx,
+  hipLaunchKernelGGL(sa_bwd_apply_kernel, dim3(grid_for(HW * C), B), dim3(256), 0, st, dy, lddy, x, ldx, P, Q, Mn, E, F, dx,
                      lddx, HW, C, accumulate_dx);
   VR_LAUNCH_CHECK("sa_bwd_apply");
   return VR_OK;

@@ -94,9 +94,9 @@ __global__ void moments_reduce_kernel(const double* partial, double* out, int B,
 
 // ------------------------------------------------------------------------------------------ affine
 struct AffineArgs {
-  const float* x1; long ld1; const float* A; const float* D1;
+  const float* x1; long ld1; const float* A; const float* D1; const float* S1;
   const float* masky; long ldm;
-  const float* x2; long ld2; const float* E; const float* D2;
+  const float* x2; long ld2; const float* E; const float* D2; const float* S2;
   float* out; long ldo;
   long HW; int C; long bstride; int pre; int accumulate;
 };
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void affine_kernel(const AffineArgs p) {
         a[0] = p.x1[row * p.ld1 + c];
       }
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] += (p.A ? p.A[cb + c + j] : 1.f) * a[j];
+      for (int j = 0; j < VEC; ++j) v[j] += (p.A ? p.A[cb + c + j] : 1.f) * (a[j] - (p.S1 ? p.S1[cb + c + j] : 0.f));
     }
     if (p.pre == 1) {
 #pragma unroll
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void affine_kernel(const AffineArgs p) {
     }
     if (p.x2) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] += (p.E ? p.E[cb + c + j] : 1.f) * p.x2[row * p.ld2 + c + j];
+      for (int j = 0; j < VEC; ++j)
+        v[j] += (p.E ? p.E[cb + c + j] : 1.f) * (p.x2[row * p.ld2 + c + j] - (p.S2 ? p.S2[cb + c + j] : 0.f));
     }
     if (p.D2) {
 #pragma unroll
@@ -170,7 +171,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 
 __global__ __launch_bounds__(256) void gn_coef_fwd_kernel(const double* mom, const float* gamma, const float* beta,
                                                           float eps, long HW, int C, float* A, float* D,
-                                                          float* mean_rstd) {
+                                                          float* S, float* mean_rstd) {
   __shared__ double red[4];
   const int b = blockIdx.x;
   double s1 = 0, s2 = 0;
@@ -186,9 +187,9 @@ __global__ __launch_bounds__(256) void gn_coef_fwd_kernel(const double* mom, con
   if (var < 0) var = 0;
   const double rstd = 1.0 / sqrt(var + (double)eps);
   for (int c = threadIdx.x; c < C; c += 256) {
-    const double a = rstd * gamma[c];
-    A[(long)b * C + c] = (float)a;
-    D[(long)b * C + c] = (float)((double)beta[c] - mean * a);
+    A[(long)b * C + c] = (float)(rstd * gamma[c]);      // y = A * (x - S) + D: the subtraction comes first, as in
+    D[(long)b * C + c] = beta[c];                         // torch (A*x + (beta - mean*A) cancels when |mean| >> std)
+    S[(long)b * C + c] = (float)mean;
   }
   if (threadIdx.x == 0) {
     mean_rstd[2 * b] = (float)mean;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void gn_coef_fwd_kernel(const double* mom, con
 // blocks [0, B): per-sample dx coefficients; blocks [B, ...): per-channel dgamma / dbeta
 __global__ __launch_bounds__(256) void gn_coef_bwd_kernel(const double* mom2, const float* mean_rstd,
                                                           const float* gamma, int B, long HW, int C, float* A,
-                                                          float* E, float* D, float* dgamma, float* dbeta,
+                                                          float* E, float* D, float* S, float* dgamma, float* dbeta,
                                                           int accumulate) {
   __shared__ double red[4];
   if ((int)blockIdx.x < B) {
@@ -215,11 +216,12 @@ __global__ __launch_bounds__(256) void gn_coef_bwd_kernel(const double* mom2, co
     t2 = block_sum(t2, red);
     const double n = (double)HW * C;
     const double m1 = t1 / n, m2 = r * t2 / n;
-    const float e = (float)(-r * r * m2), d = (float)(-r * m1 + r * r * m2 * mu);
+    const float e = (float)(-r * r * m2), d = (float)(-r * m1);     // dx = A*dy + E*(x - S) + D
     for (int c = threadIdx.x; c < C; c += 256) {
       A[(long)b * C + c] = (float)(r * gamma[c]);
       E[(long)b * C + c] = e;
       D[(long)b * C + c] = d;
+      S[(long)b * C + c] = (float)mu;
     }
   } else {
     const int c = (blockIdx.x - B) * 256 + threadIdx.x;
@@ -238,7 +240,8 @@ __global__ __launch_bounds__(256) void gn_coef_bwd_kernel(const double* mom2, co
 
 __global__ void bn_coef_fwd_kernel(const double* mom, const float* gamma, const float* beta, float eps,
                                    float momentum, float* running_mean, float* running_var, long long* nbt,
-                                   int training, int B, long HW, int C, float* A, float* D, float* mean_rstd) {
+                                   int training, int B, long HW, int C, float* A, float* D, float* S,
+                                   float* mean_rstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && training && nbt) *nbt += 1;
   if (c >= C) return;
@@ -260,16 +263,16 @@ __global__ void bn_coef_fwd_kernel(const double* mom, const float* gamma, const 
     var = running_var[c];
   }
   const double rstd = 1.0 / sqrt(var + (double)eps);
-  const double a = rstd * gamma[c];
-  A[c] = (float)a;
-  D[c] = (float)((double)beta[c] - mean * a);
+  A[c] = (float)(rstd * gamma[c]);     // y = A * (z - S) + D
+  D[c] = beta[c];
+  S[c] = (float)mean;
   mean_rstd[2 * c] = (float)mean;
   mean_rstd[2 * c + 1] = (float)rstd;
 }
 
 __global__ void bn_coef_bwd_kernel(const double* mom2, const float* mean_rstd, const float* gamma, int training,
-                                   int B, long HW, int C, float* A, float* E, float* D, float* dgamma, float* dbeta,
-                                   int accumulate) {
+                                   int B, long HW, int C, float* A, float* E, float* D, float* S, float* dgamma,
+                                   float* dbeta, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s1 = 0, s2 = 0;
@@ -283,12 +286,13 @@ __global__ void bn_coef_bwd_kernel(const double* mom2, const float* mean_rstd, c
   A[c] = (float)(g * r);
   if (training) {
     const double m1 = s1 / n, m2 = dxh / n;
-    E[c] = (float)(-g * r * r * m2);
-    D[c] = (float)(-g * r * m1 + g * r * r * m2 * mu);
+    E[c] = (float)(-g * r * r * m2);     // dz = A*dy' + E*(z - S) + D
+    D[c] = (float)(-g * r * m1);
   } else {
     E[c] = 0.f;
     D[c] = 0.f;
   }
+  S[c] = (float)mu;
   dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dxh;
   dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
 }
@@ -477,13 +481,13 @@ extern "C" int vrnet_moments_f32(const float* x, long ldx, const float* x2, long
   return VR_OK;
 }
 
-extern "C" int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1, int pre,
+extern "C" int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1, const float* S1, int pre,
                                 const float* masky, long ldm, const float* x2, long ld2, const float* E,
-                                const float* D2, long coef_bstride, float* out, long ldo, int B, long HW, int C,
-                                int accumulate, void* stream) {
+                                const float* D2, const float* S2, long coef_bstride, float* out, long ldo, int B,
+                                long HW, int C, int accumulate, void* stream) {
   VR_CHECK_ARG(out && B > 0 && HW > 0 && C > 0, "affine: bad arguments");
   VR_CHECK_ARG(pre != 2 || masky, "affine: mask mode without mask tensor");
-  AffineArgs p{x1, ld1, A, D1, masky, ldm, x2, ld2, E, D2, out, ldo, HW, C, coef_bstride, pre, accumulate};
+  AffineArgs p{x1, ld1, A, D1, S1, masky, ldm, x2, ld2, E, D2, S2, out, ldo, HW, C, coef_bstride, pre, accumulate};
   bool vec = (C % 4 == 0) && (ldo % 4 == 0) && vr_aligned16(out) && (coef_bstride % 4 == 0);
   if (x1) vec = vec && (ld1 % 4 == 0) && vr_aligned16(x1);
   long blocks = vr_cdiv(HW * (C / (vec ? 4 : 1)), 256 * 4);
@@ -497,43 +501,43 @@ extern "C" int vrnet_affine_f32(const float* x1, long ld1, const float* A, const
 }
 
 extern "C" int vrnet_gn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, int B, long HW,
-                                 int C, float* A, float* D, float* mean_rstd, void* stream) {
-  VR_CHECK_ARG(mom && gamma && beta && A && D && mean_rstd, "gn_coef_fwd: null tensor");
-  hipLaunchKernelGGL(gn_coef_fwd_kernel, dim3(B), dim3(256), 0, vr_stream(stream), mom, gamma, beta, eps, HW, C, A, D,
+                                 int C, float* A, float* D, float* S, float* mean_rstd, void* stream) {
+  VR_CHECK_ARG(mom && gamma && beta && A && D && S && mean_rstd, "gn_coef_fwd: null tensor");
+  hipLaunchKernelGGL(gn_coef_fwd_kernel, dim3(B), dim3(256), 0, vr_stream(stream), mom, gamma, beta, eps, HW, C, A, D, S,
                      mean_rstd);
   VR_LAUNCH_CHECK("gn_coef_fwd");
   return VR_OK;
 }
 
 extern "C" int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int B, long HW, int C,
-                                 float* A, float* E, float* D, float* dgamma, float* dbeta, int accumulate,
+                                 float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,
                                  void* stream) {
-  VR_CHECK_ARG(mom2 && mean_rstd && gamma && A && E && D && dgamma && dbeta, "gn_coef_bwd: null tensor");
+  VR_CHECK_ARG(mom2 && mean_rstd && gamma && A && E && D && S && dgamma && dbeta, "gn_coef_bwd: null tensor");
   hipLaunchKernelGGL(gn_coef_bwd_kernel, dim3(B + vr_cdiv(C, 256)), dim3(256), 0, vr_stream(stream), mom2, mean_rstd,
-                     gamma, B, HW, C, A, E, D, dgamma, dbeta, accumulate);
+                     gamma, B, HW, C, A, E, D, S, dgamma, dbeta, accumulate);
   VR_LAUNCH_CHECK("gn_coef_bwd");
   return VR_OK;
 }
 
 extern "C" int vrnet_bn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, float momentum,
                                  float* running_mean, float* running_var, long long* num_batches_tracked,
-                                 int training, int B, long HW, int C, float* A, float* D, float* mean_rstd,
+                                 int training, int B, long HW, int C, float* A, float* D, float* S, float* mean_rstd,
                                  void* stream) {
-  VR_CHECK_ARG(gamma && beta && running_mean && running_var && A && D && mean_rstd, "bn_coef_fwd: null tensor");
+  VR_CHECK_ARG(gamma && beta && running_mean && running_var && A && D && S && mean_rstd, "bn_coef_fwd: null tensor");
   VR_CHECK_ARG(!training || mom, "bn_coef_fwd: training mode needs batch moments");
   VR_CHECK_ARG(!training || (long)B * HW > 1, "Expected more than 1 value per channel when training");
   hipLaunchKernelGGL(bn_coef_fwd_kernel, dim3(vr_cdiv(C, 128)), dim3(128), 0, vr_stream(stream), mom, gamma, beta, eps,
-                     momentum, running_mean, running_var, num_batches_tracked, training, B, HW, C, A, D, mean_rstd);
+                     momentum, running_mean, running_var, num_batches_tracked, training, B, HW, C, A, D, S, mean_rstd);
   VR_LAUNCH_CHECK("bn_coef_fwd");
   return VR_OK;
 }
 
 extern "C" int vrnet_bn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int training, int B,
-                                 long HW, int C, float* A, float* E, float* D, float* dgamma, float* dbeta,
+                                 long HW, int C, float* A, float* E, float* D, float* S, float* dgamma, float* dbeta,
                                  int accumulate, void* stream) {
-  VR_CHECK_ARG(mom2 && mean_rstd && gamma && A && E && D && dgamma && dbeta, "bn_coef_bwd: null tensor");
+  VR_CHECK_ARG(mom2 && mean_rstd && gamma && A && E && D && S && dgamma && dbeta, "bn_coef_bwd: null tensor");
   hipLaunchKernelGGL(bn_coef_bwd_kernel, dim3(vr_cdiv(C, 128)), dim3(128), 0, vr_stream(stream), mom2, mean_rstd, gamma,
-                     training, B, HW, C, A, E, D, dgamma, dbeta, accumulate);
+                     training, B, HW, C, A, E, D, S, dgamma, dbeta, accumulate);
   VR_LAUNCH_CHECK("bn_coef_bwd");
   return VR_OK;
 }

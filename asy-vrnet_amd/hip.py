@@ -31,11 +31,11 @@ _SIGS = {
     "vrnet_pack_weight_f32": ([P, P, I, I, I, I, P], I),
     "vrnet_moments_workspace": ([I, L, I], L),
     "vrnet_moments_f32": ([P, L, P, L, P, L, I, L, I, P, P, L, P], I),
-    "vrnet_affine_f32": ([P, L, P, P, I, P, L, P, L, P, P, L, P, L, I, L, I, I, P], I),
-    "vrnet_gn_coef_fwd": ([P, P, P, F, I, L, I, P, P, P, P], I),
-    "vrnet_gn_coef_bwd": ([P, P, P, I, L, I, P, P, P, P, P, I, P], I),
-    "vrnet_bn_coef_fwd": ([P, P, P, F, F, P, P, P, I, I, L, I, P, P, P, P], I),
-    "vrnet_bn_coef_bwd": ([P, P, P, I, I, L, I, P, P, P, P, P, I, P], I),
+    "vrnet_affine_f32": ([P, L, P, P, P, I, P, L, P, L, P, P, P, L, P, L, I, L, I, I, P], I),
+    "vrnet_gn_coef_fwd": ([P, P, P, F, I, L, I, P, P, P, P, P], I),
+    "vrnet_gn_coef_bwd": ([P, P, P, I, L, I, P, P, P, P, P, P, I, P], I),
+    "vrnet_bn_coef_fwd": ([P, P, P, F, F, P, P, P, I, I, L, I, P, P, P, P, P], I),
+    "vrnet_bn_coef_bwd": ([P, P, P, I, I, L, I, P, P, P, P, P, P, I, P], I),
     "vrnet_eca_coef_fwd": ([P, P, I, I, L, I, P, P], I),
     "vrnet_eca_coef_bwd": ([P, P, P, P, I, I, L, I, P, P, I, P], I),
     "vrnet_ls_coef_bwd": ([P, P, I, I, P, P, I, P], I),
@@ -57,10 +57,10 @@ _SIGS = {
     "vrnet_minmax_f32": ([P, L, P, P, L, P], I),
     "vrnet_enhance_mul_f32": ([P, P, P, P, L, P], I),
     "vrnet_enhance_bwd_f32": ([P, P, P, P, P, P, L, I, P, L, P], I),
-    "vrnet_sa_coef_fwd": ([P] * 7 + [I, L, I, I, P, P, P], I),
-    "vrnet_sa_apply_f32": ([P, L, P, P, P, L, I, L, I, P], I),
+    "vrnet_sa_coef_fwd": ([P] * 7 + [I, L, I, I, P, P, P, P], I),
+    "vrnet_sa_apply_f32": ([P, L, P, P, P, P, L, I, L, I, P], I),
     "vrnet_sa_bwd_workspace": ([I, L, I], L),
-    "vrnet_sa_bwd_f32": ([P, L, P, L, P, P, P] + [P] * 6 + [P, L] + [P] * 6 + [P, I, L, I, I, I, I, P, L, P], I),
+    "vrnet_sa_bwd_f32": ([P, L, P, L, P, P, P, P] + [P] * 6 + [P, L] + [P] * 6 + [P, I, L, I, I, I, I, P, L, P], I),
 }
 for _name, (_args, _res) in _SIGS.items():
     _fn = getattr(_lib, _name)          # AttributeError here = header/library mismatch
@@ -154,29 +154,30 @@ def moments(x, ldx, B, HW, C, x2=None, ldx2=0, mask=None, ldm=0, out=None):
 
 
 def affine(out, ldo, B, HW, C, x1=None, ld1=0, A=None, D1=None, pre=0, masky=None, ldm=0, x2=None, ld2=0, E=None,
-           D2=None, bstride=0, accumulate=0):
-    _check(_lib.vrnet_affine_f32(ptr(x1), ld1, ptr(A), ptr(D1), pre, ptr(masky), ldm, ptr(x2), ld2, ptr(E), ptr(D2),
-                                 bstride, ptr(out), ldo, B, HW, C, accumulate, stream()), "affine")
+           D2=None, bstride=0, accumulate=0, S1=None, S2=None):
+    _check(_lib.vrnet_affine_f32(ptr(x1), ld1, ptr(A), ptr(D1), ptr(S1), pre, ptr(masky), ldm, ptr(x2), ld2, ptr(E),
+                                 ptr(D2), ptr(S2), bstride, ptr(out), ldo, B, HW, C, accumulate, stream()), "affine")
 
 
-def gn_coef_fwd(mom, gamma, beta, eps, B, HW, C, A, Dc, mean_rstd):
-    _check(_lib.vrnet_gn_coef_fwd(ptr(mom), ptr(gamma), ptr(beta), eps, B, HW, C, ptr(A), ptr(Dc), ptr(mean_rstd),
-                                  stream()), "gn_coef_fwd")
+def gn_coef_fwd(mom, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd):
+    _check(_lib.vrnet_gn_coef_fwd(ptr(mom), ptr(gamma), ptr(beta), eps, B, HW, C, ptr(A), ptr(Dc), ptr(S),
+                                  ptr(mean_rstd), stream()), "gn_coef_fwd")
 
 
-def gn_coef_bwd(mom2, mean_rstd, gamma, B, HW, C, A, E, Dc, dgamma, dbeta, accumulate):
-    _check(_lib.vrnet_gn_coef_bwd(ptr(mom2), ptr(mean_rstd), ptr(gamma), B, HW, C, ptr(A), ptr(E), ptr(Dc),
+def gn_coef_bwd(mom2, mean_rstd, gamma, B, HW, C, A, E, Dc, S, dgamma, dbeta, accumulate):
+    _check(_lib.vrnet_gn_coef_bwd(ptr(mom2), ptr(mean_rstd), ptr(gamma), B, HW, C, ptr(A), ptr(E), ptr(Dc), ptr(S),
                                   ptr(dgamma), ptr(dbeta), accumulate, stream()), "gn_coef_bwd")
 
 
-def bn_coef_fwd(mom, gamma, beta, eps, momentum, rm, rv, nbt, training, B, HW, C, A, Dc, mean_rstd):
+def bn_coef_fwd(mom, gamma, beta, eps, momentum, rm, rv, nbt, training, B, HW, C, A, Dc, S, mean_rstd):
     _check(_lib.vrnet_bn_coef_fwd(ptr(mom), ptr(gamma), ptr(beta), eps, momentum, ptr(rm), ptr(rv), ptr(nbt),
-                                  int(training), B, HW, C, ptr(A), ptr(Dc), ptr(mean_rstd), stream()), "bn_coef_fwd")
+                                  int(training), B, HW, C, ptr(A), ptr(Dc), ptr(S), ptr(mean_rstd), stream()),
+           "bn_coef_fwd")
 
 
-def bn_coef_bwd(mom2, mean_rstd, gamma, training, B, HW, C, A, E, Dc, dgamma, dbeta, accumulate):
+def bn_coef_bwd(mom2, mean_rstd, gamma, training, B, HW, C, A, E, Dc, S, dgamma, dbeta, accumulate):
     _check(_lib.vrnet_bn_coef_bwd(ptr(mom2), ptr(mean_rstd), ptr(gamma), int(training), B, HW, C, ptr(A), ptr(E),
-                                  ptr(Dc), ptr(dgamma), ptr(dbeta), accumulate, stream()), "bn_coef_bwd")
+                                  ptr(Dc), ptr(S), ptr(dgamma), ptr(dbeta), accumulate, stream()), "bn_coef_bwd")
 
 
 def eca_coef_fwd(mom, wk, k, B, HW, C, gate):
@@ -266,17 +267,19 @@ def enhance_bwd(dt, x, p, mm, dx, dp, n, accumulate_dx=0):
                                       ws.numel(), stream()), "enhance_bwd")
 
 
-def sa_coef_fwd(mom, cw, cb, sw, sb, gnw, gnb, B, HW, C, G, Pq, Qq):
+def sa_coef_fwd(mom, cw, cb, sw, sb, gnw, gnb, B, HW, C, G, Pq, Qq, Mn):
     _check(_lib.vrnet_sa_coef_fwd(ptr(mom), ptr(cw), ptr(cb), ptr(sw), ptr(sb), ptr(gnw), ptr(gnb), B, HW, C, G, ptr(Pq),
-                                  ptr(Qq), stream()), "sa_coef_fwd")
+                                  ptr(Qq), ptr(Mn), stream()), "sa_coef_fwd")
 
 
-def sa_apply(x, ldx, Pq, Qq, y, ldy, B, HW, C):
-    _check(_lib.vrnet_sa_apply_f32(ptr(x), ldx, ptr(Pq), ptr(Qq), ptr(y), ldy, B, HW, C, stream()), "sa_apply")
+def sa_apply(x, ldx, Pq, Qq, Mn, y, ldy, B, HW, C):
+    _check(_lib.vrnet_sa_apply_f32(ptr(x), ldx, ptr(Pq), ptr(Qq), ptr(Mn), ptr(y), ldy, B, HW, C, stream()), "sa_apply")
 
 
-def sa_bwd(dy, lddy, x, ldx, Pq, Qq, mom, params, dx, lddx, grads, EF, B, HW, C, G, accumulate_dx, accumulate_params):
+def sa_bwd(dy, lddy, x, ldx, Pq, Qq, Mn, mom, params, dx, lddx, grads, EF, B, HW, C, G, accumulate_dx,
+           accumulate_params):
     ws = _ws.get(_lib.vrnet_sa_bwd_workspace(B, HW, C), x.device)
-    _check(_lib.vrnet_sa_bwd_f32(ptr(dy), lddy, ptr(x), ldx, ptr(Pq), ptr(Qq), ptr(mom), *[ptr(t) for t in params],
+    _check(_lib.vrnet_sa_bwd_f32(ptr(dy), lddy, ptr(x), ldx, ptr(Pq), ptr(Qq), ptr(Mn), ptr(mom),
+                                 *[ptr(t) for t in params],
                                  ptr(dx), lddx, *[ptr(t) for t in grads], ptr(EF), B, HW, C, G, accumulate_dx,
                                  accumulate_params, ptr(ws), ws.numel(), stream()), "sa_bwd")

@@ -325,12 +325,12 @@ def simple_conv(rt, x, conv, out=None):
 def bn_forward(rt, z, bn, relu, out=None, residual=None):
     """y = [relu](BN(z)) [+ residual].  Returns (y, ctx) where ctx feeds bn_backward."""
     B, HW, C = z.B, z.HW, z.C
-    A, D, ms = rt.buf(C), rt.buf(C), rt.buf(C, 2)
+    A, D, S, ms = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C, 2)
     mom = hip.moments(z.t, z.ld, B, HW, C) if rt.training else None
     hip.bn_coef_fwd(mom, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                    bn.num_batches_tracked, rt.training, B, HW, C, A, D, ms)
+                    bn.num_batches_tracked, rt.training, B, HW, C, A, D, S, ms)
     y = out if out is not None else rt.new(z.B, z.H, z.W, C)
-    hip.affine(y.t, y.ld, B, HW, C, x1=z.t, ld1=z.ld, A=A, D1=D, pre=1 if relu else 0,
+    hip.affine(y.t, y.ld, B, HW, C, x1=z.t, ld1=z.ld, A=A, D1=D, S1=S, pre=1 if relu else 0,
                x2=None if residual is None else residual.t, ld2=0 if residual is None else residual.ld)
     return y, ms
 
@@ -340,29 +340,30 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
     B, HW, C = z.B, z.HW, z.C
     mom2 = hip.moments(dy, lddy, B, HW, C, x2=z.t, ldx2=z.ld, mask=None if mask is None else mask.t,
                        ldm=0 if mask is None else mask.ld)
-    A, E, D = rt.buf(C), rt.buf(C), rt.buf(C)
+    A, E, D, S = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C)
     gw, accw = rt.pgrad(bn.weight)
     gb, accb = rt.pgrad(bn.bias)
     if gw is None:
         gw, accw = rt.buf(C), 0
     if gb is None:
         gb = rt.buf(C)
-    hip.bn_coef_bwd(mom2, ms, bn.weight, rt.training, B, HW, C, A, E, D, gw, gb, accw)
+    hip.bn_coef_bwd(mom2, ms, bn.weight, rt.training, B, HW, C, A, E, D, S, gw, gb, accw)
     if rt.on_param_grad:
         rt.on_param_grad(bn.weight)
         rt.on_param_grad(bn.bias)
     dz = dz_out if dz_out is not None else rt.buf(z.B, z.H, z.W, C)
     hip.affine(dz, C, B, HW, C, x1=dy, ld1=lddy, A=A, pre=2 if mask is not None else 0,
-               masky=None if mask is None else mask.t, ldm=0 if mask is None else mask.ld, x2=z.t, ld2=z.ld, E=E, D2=D)
+               masky=None if mask is None else mask.t, ldm=0 if mask is None else mask.ld, x2=z.t, ld2=z.ld, E=E, D2=D,
+               S2=S)
     return dz
 
 
 def gn_forward(rt, x, gn):
     B, HW, C = x.B, x.HW, x.C
-    A, D, ms = rt.buf(B, C), rt.buf(B, C), rt.buf(B, 2)
-    hip.gn_coef_fwd(hip.moments(x.t, x.ld, B, HW, C), gn.weight, gn.bias, gn.eps, B, HW, C, A, D, ms)
+    A, D, S, ms = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C), rt.buf(B, 2)
+    hip.gn_coef_fwd(hip.moments(x.t, x.ld, B, HW, C), gn.weight, gn.bias, gn.eps, B, HW, C, A, D, S, ms)
     y = rt.new(x.B, x.H, x.W, C)
-    hip.affine(y.t, C, B, HW, C, x1=x.t, ld1=x.ld, A=A, D2=D, bstride=C)
+    hip.affine(y.t, C, B, HW, C, x1=x.t, ld1=x.ld, A=A, D1=D, S1=S, bstride=C)
     return y, ms
 
 
@@ -370,18 +371,18 @@ def gn_backward(rt, gn, x, ms, dy, out, accumulate):
     """out (+)= dx of y = GN(x) given contiguous dy."""
     B, HW, C = x.B, x.HW, x.C
     mom2 = hip.moments(dy, C, B, HW, C, x2=x.t, ldx2=x.ld)
-    A, E, D = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C)
+    A, E, D, S = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C), rt.buf(B, C)
     gw, accw = rt.pgrad(gn.weight)
     gb, _ = rt.pgrad(gn.bias)
     if gw is None:
         gw, accw = rt.buf(C), 0
     if gb is None:
         gb = rt.buf(C)
-    hip.gn_coef_bwd(mom2, ms, gn.weight, B, HW, C, A, E, D, gw, gb, accw)
+    hip.gn_coef_bwd(mom2, ms, gn.weight, B, HW, C, A, E, D, S, gw, gb, accw)
     if rt.on_param_grad:
         rt.on_param_grad(gn.weight)
         rt.on_param_grad(gn.bias)
-    hip.affine(out, C, B, HW, C, x1=dy, ld1=C, A=A, x2=x.t, ld2=x.ld, E=E, D2=D, bstride=C, accumulate=accumulate)
+    hip.affine(out, C, B, HW, C, x1=dy, ld1=C, A=A, x2=x.t, ld2=x.ld, E=E, D2=D, S2=S, bstride=C, accumulate=accumulate)
 
 
 # ----------------------------------------------------------------------------------------- BaseConv
@@ -553,10 +554,10 @@ def shuffle_attention(rt, x, m):
     B, HW, C, G = x.B, x.HW, x.C, m.G
     params = [t.reshape(-1) for t in (m.cweight, m.cbias, m.sweight, m.sbias, m.gn.weight, m.gn.bias)]
     mom = hip.moments(x.t, x.ld, B, HW, C)
-    P, Q = rt.buf(B, C), rt.buf(B, C)
-    hip.sa_coef_fwd(mom, *params, B, HW, C, G, P, Q)
+    P, Q, Mn = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C)
+    hip.sa_coef_fwd(mom, *params, B, HW, C, G, P, Q, Mn)
     y = rt.new(x.B, x.H, x.W, C)
-    hip.sa_apply(x.t, x.ld, P, Q, y.t, C, B, HW, C)
+    hip.sa_apply(x.t, x.ld, P, Q, Mn, y.t, C, B, HW, C)
 
     def bwd():
         g = take_grad(y)
@@ -574,7 +575,7 @@ def shuffle_attention(rt, x, m):
             dxb, accx = rt.grad_target(x)
         else:
             dxb, accx = rt.buf(x.B, x.H, x.W, C), 0
-        hip.sa_bwd(g, C, x.t, x.ld, P, Q, mom, params, dxb, C, grads, rt.buf(2, B, C), B, HW, C, G, accx, acc)
+        hip.sa_bwd(g, C, x.t, x.ld, P, Q, Mn, mom, params, dxb, C, grads, rt.buf(2, B, C), B, HW, C, G, accx, acc)
         if rt.on_param_grad:
             for prm in plist:
                 rt.on_param_grad(prm)

@@ -65,29 +65,33 @@ long vrnet_moments_workspace(int B, long HW, int C);
 int vrnet_moments_f32(const float* x, long ldx, const float* x2, long ldx2, const float* mask, long ldm, int B,
                       long HW, int C, double* out, void* workspace, long workspace_bytes, void* stream);
 
-/* out = pre(A*x1 + D1) + E*x2 + D2; pre: 0 none, 1 ReLU, 2 keep where masky > 0.  Coefficients are indexed
- * [b*coef_bstride + c] (0 = per channel, C = per sample and channel); NULL A/E = 1, NULL D1/D2 = 0,
- * NULL x1/x2 = term absent.  The apply step of GroupNorm / BatchNorm(+ReLU, + residual) forward AND backward,
+/* out = pre(A*(x1 - S1) + D1) + E*(x2 - S2) + D2; pre: 0 none, 1 ReLU, 2 keep where masky > 0.  Coefficients are
+ * indexed [b*coef_bstride + c] (0 = per channel, C = per sample and channel); NULL A/E = 1, NULL D1/D2/S1/S2 = 0,
+ * NULL x1/x2 = term absent.  The shifts keep normalisation in torch's (x - mean) * scale order: the algebraically
+ * equal A*x + (beta - mean*A) cancels catastrophically when |mean| >> std.  The apply step of GroupNorm / BatchNorm(+ReLU, + residual) forward AND backward,
  * ECA gating (eca.py:22), global-feature broadcast (coc_fpn_dual.py:96). */
-int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1, int pre, const float* masky,
-                     long ldm, const float* x2, long ld2, const float* E, const float* D2, long coef_bstride,
-                     float* out, long ldo, int B, long HW, int C, int accumulate, void* stream);
+int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1, const float* S1, int pre,
+                     const float* masky, long ldm, const float* x2, long ld2, const float* E, const float* D2,
+                     const float* S2, long coef_bstride, float* out, long ldo, int B, long HW, int C, int accumulate,
+                     void* stream);
 
 /* Coefficient kernels: moments -> affine coefficients, saved statistics, parameter gradients. */
-/* GroupNorm(1,C), eps 1e-5 (vr_coc.py:105-111): A,D [B][C]; mean_rstd [B][2]. */
+/* GroupNorm(1,C), eps 1e-5 (vr_coc.py:105-111): y = A*(x - S) + D with A,D,S [B][C]; mean_rstd [B][2]. */
 int vrnet_gn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, int B, long HW, int C,
-                      float* A, float* D, float* mean_rstd, void* stream);
-/* mom2 = moments(dy, x2 = x): dx = A*dy + E*x + D with A,E,D [B][C]; dgamma, dbeta [C]. */
+                      float* A, float* D, float* S, float* mean_rstd, void* stream);
+/* mom2 = moments(dy, x2 = x): dx = A*dy + E*(x - S) + D with A,E,D,S [B][C]; dgamma, dbeta [C]. */
 int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int B, long HW, int C,
-                      float* A, float* E, float* D, float* dgamma, float* dbeta, int accumulate, void* stream);
+                      float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,
+                      void* stream);
 /* nn.BatchNorm2d: batch statistics + running-stat update (unbiased var, momentum) + num_batches_tracked += 1
- * when training, running statistics otherwise.  A,D [C]; mean_rstd [C][2]. */
+ * when training, running statistics otherwise.  y = A*(z - S) + D with A,D,S [C]; mean_rstd [C][2]. */
 int vrnet_bn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, float momentum,
                       float* running_mean, float* running_var, long long* num_batches_tracked, int training, int B,
-                      long HW, int C, float* A, float* D, float* mean_rstd, void* stream);
-/* mom2 = moments(dy, x2 = z, mask = relu output): dz = A*dy' + E*z + D with A,E,D [C]. */
+                      long HW, int C, float* A, float* D, float* S, float* mean_rstd, void* stream);
+/* mom2 = moments(dy, x2 = z, mask = relu output): dz = A*dy' + E*(z - S) + D with A,E,D,S [C]. */
 int vrnet_bn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int training, int B, long HW,
-                      int C, float* A, float* E, float* D, float* dgamma, float* dbeta, int accumulate, void* stream);
+                      int C, float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,
+                      void* stream);
 /* eca_block (backbone/attention_modules/eca.py:16-22): gate[b][c] = sigmoid(conv1d_k(mean_hw x)). */
 int vrnet_eca_coef_fwd(const double* mom, const float* wk, int k, int B, long HW, int C, float* gate, void* stream);
 /* mom2 = moments(dy, x2 = x): dx = gate*dy + F[b][c]; dwk [k]. */
@@ -149,17 +153,17 @@ int vrnet_enhance_bwd_f32(const float* dt, const float* x, const float* p, const
                           long n, int accumulate_dx, void* workspace, long workspace_bytes, void* stream);
 
 /* ---- ShuffleAttention (backbone/attention_modules/shuffle_attention.py:48-72) ---------------------------
- * mom = moments(x).  y[dst(q)] = x[q] * sigmoid(P[b][q]*x[q] + Q[b][q]); dst() is the final 2-group channel
+ * mom = moments(x).  y[dst(q)] = x[q] * sigmoid(P[b][q]*(x[q] - Mn[b][q]) + Q[b][q]); dst() is the final 2-group channel
  * shuffle; the G-group split and the channel/spatial halves are index arithmetic on q.
  * Parameters: cweight, cbias, sweight, sbias, gn.weight, gn.bias, each [C/(2G)]. */
 int vrnet_sa_coef_fwd(const double* mom, const float* cw, const float* cb, const float* sw, const float* sb,
-                      const float* gnw, const float* gnb, int B, long HW, int C, int G, float* P, float* Q,
+                      const float* gnw, const float* gnb, int B, long HW, int C, int G, float* P, float* Q, float* Mn,
                       void* stream);
-int vrnet_sa_apply_f32(const float* x, long ldx, const float* P, const float* Q, float* y, long ldy, int B, long HW,
-                       int C, void* stream);
+int vrnet_sa_apply_f32(const float* x, long ldx, const float* P, const float* Q, const float* Mn, float* y, long ldy,
+                       int B, long HW, int C, void* stream);
 long vrnet_sa_bwd_workspace(int B, long HW, int C);
 int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long ldx, const float* P, const float* Q,
-                     const double* mom, const float* cw, const float* cb, const float* sw, const float* sb,
+                     const float* Mn, const double* mom, const float* cw, const float* cb, const float* sw, const float* sb,
                      const float* gnw, const float* gnb, float* dx, long lddx, float* dcw, float* dcb, float* dsw,
                      float* dsb, float* dgnw, float* dgnb, float* EF /* [2][B][C] scratch */, int B, long HW, int C,
                      int G, int accumulate_dx, int accumulate_params, void* workspace, long workspace_bytes,
