@@ -373,6 +373,268 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming variant for regions that do not fit the register-resident kernel (N > 256 points: neck p3 at
+// 512 px, every backbone stage at 1024 px, neck p3 at 1024 px with N = 4096).  Same arithmetic, same
+// reduction order per chunk; the points are re-read from L2/HBM in chunks of 64 (512 threads, 8 lanes per
+// point) instead of being held in registers: forward reads f, v twice; backward reads f 4x, v 3x, g 2x and
+// keeps one float per point (d cos) in a scratch map.  p.wgt: forward = similarity map (required),
+// backward = the per-point scratch map.
+template <bool BWD>
+__global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p) {
+  __shared__ float sm[SM_TOTAL];
+  const int T = 512, tid = threadIdx.x, sub = tid & 7, pip = tid >> 3, PP = T >> 3;
+  int rid = blockIdx.x;
+  const int fold = p.fold;
+  const int f2 = rid % fold; rid /= fold;
+  const int f1 = rid % fold; rid /= fold;
+  const int e = rid % p.E;
+  const int b = rid / p.E;
+  const int h = p.H / fold, w = p.W / fold, N = h * w;
+  const int y0 = f1 * h, x0 = f2 * w;
+  const int D = p.D;
+  const bool dim_ok = 4 * sub < D;
+  const int hh = (h + 1) / 2, hl = h / 2, wh = (w + 1) / 2, wl = w / 2;
+  const float invq = 1.f / (float)(hh * wh);
+  const float alpha = p.alpha[0], beta = p.beta[0];
+  const int coff = e * D + 4 * sub;
+
+  auto locate = [&](int n, long& row, unsigned& inq) -> bool {
+    const bool ok = n < N;
+    const int i = ok ? n / w : 0, j = ok ? n - i * w : 0;
+    row = ((long)(b * p.H + y0 + i) * p.W + x0 + j);
+    const unsigned r0 = i < hh, r1 = i >= hl, c0 = j < wh, c1 = j >= wl;
+    inq = ok ? ((r0 & c0) | ((r0 & c1) << 1) | ((r1 & c0) << 2) | ((r1 & c1) << 3)) : 0u;
+    return ok;
+  };
+  auto load4 = [&](const float* base, long ld, long row, bool ok, float (&o)[4]) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (ok && dim_ok) a = *reinterpret_cast<const f32x4*>(base + row * ld + coff);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = a[q];
+  };
+
+  // ---- pass 1: centres of f and v
+  {
+    float cs[16], vs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cs[i] = vs[i] = 0.f;
+    for (int n0 = 0; n0 < N; n0 += PP) {
+      long row; unsigned inq;
+      const bool ok = locate(n0 + pip, row, inq);
+      float f[4], v[4];
+      load4(p.f, p.ld, row, ok, f);
+      load4(p.v, p.ld, row, ok, v);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (inq & (1u << m)) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { cs[m * 4 + q] += f[q]; vs[m * 4 + q] += v[q]; }
+        }
+    }
+    reduce_md(cs, sm + SM_PART, sm + SM_CEN, invq, tid, T);
+    reduce_md(vs, sm + SM_PART, sm + SM_VCEN, invq, tid, T);
+  }
+  float cl[4][4], cnorm[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { cl[m][q] = sm[SM_CEN + m * 32 + 4 * sub + q]; s2 += cl[m][q] * cl[m][q]; }
+    cnorm[m] = fmaxf(sqrtf(group8_sum(s2)), 1e-12f);
+  }
+  // similarity of one point (all 8 lanes of its group get the same values)
+  auto assign = [&](const float (&f)[4], bool ok, long row, float& nf, float& wgt, float& cosk) -> int {
+    float n2 = 0.f, dt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      n2 += f[q] * f[q];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) dt[m] += f[q] * cl[m][q];
+    }
+    n2 = group8_sum(n2);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dt[m] = group8_sum(dt[m]);
+    nf = fmaxf(sqrtf(n2), 1e-12f);
+    float best = -1.f, bc = 0.f;
+    int k = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float c = dt[m] / (nf * cnorm[m]);
+      const float sg = vr_sigmoid(beta + alpha * c);
+      if (sg > best) { best = sg; k = m; bc = c; }
+    }
+    if (BWD) {
+      if (ok) k = p.idx[row * p.E + e];
+      bc = 0.f; best = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (k == m) { bc = dt[m] / (nf * cnorm[m]); best = vr_sigmoid(beta + alpha * bc); }
+    }
+    wgt = best; cosk = bc;
+    return k;
+  };
+
+  // ---- pass 2: assignment, aggregate (and, backward, da = sum w g)
+  {
+    float ag[16], da[16], cnt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ag[i] = da[i] = 0.f;
+    for (int n0 = 0; n0 < N; n0 += PP) {
+      long row; unsigned inq;
+      const bool ok = locate(n0 + pip, row, inq);
+      float f[4], v[4], g[4], nf, wg, ck;
+      load4(p.f, p.ld, row, ok, f);
+      load4(p.v, p.ld, row, ok, v);
+      if (BWD) load4(p.g, p.ldg, row, ok, g);
+      const int k = assign(f, ok, row, nf, wg, ck);
+      if (ok) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (k == m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ag[m * 4 + q] += wg * v[q]; if (BWD) da[m * 4 + q] += wg * g[q]; }
+            if (sub == 0) cnt[m] += 1.f;
+          }
+        if (!BWD && sub == 0) {
+          p.idx[row * p.E + e] = (unsigned char)k;
+          p.wgt[row * p.E + e] = wg;
+        }
+      }
+    }
+    reduce_md(ag, sm + SM_PART, sm + SM_AGG, 1.f, tid, T);
+    reduce4(cnt, sm + SM_PART, sm + SM_MISC, tid, T);
+    if (BWD) reduce_md(da, sm + SM_PART, sm + SM_T1, 1.f, tid, T);
+    for (int i = tid; i < 128; i += T) {
+      const float den = sm[SM_MISC + (i >> 5)] + 1.f;
+      sm[SM_AFIN + i] = (sm[SM_AGG + i] + sm[SM_VCEN + i]) / den;
+      if (BWD) sm[SM_T1 + i] = sm[SM_T1 + i] / den;
+    }
+    __syncthreads();
+  }
+
+  if (!BWD) {   // ---- pass 3: dispatch
+    for (int n0 = 0; n0 < N; n0 += PP) {
+      long row; unsigned inq;
+      const bool ok = locate(n0 + pip, row, inq);
+      if (ok && dim_ok) {
+        const int k = p.idx[row * p.E + e];
+        const float wg = p.wgt[row * p.E + e];
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = wg * sm[SM_AFIN + k * 32 + 4 * sub + q];
+        *reinterpret_cast<f32x4*>(p.out + row * p.ldo + coff) = o;
+      }
+    }
+    return;
+  }
+
+  // ---- backward pass 3: dw, dz, d cos (to scratch), dv, d c_hat
+  float dal = 0.f, dbe = 0.f;
+  {
+    float dch[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dch[i] = 0.f;
+    for (int n0 = 0; n0 < N; n0 += PP) {
+      long row; unsigned inq;
+      const bool ok = locate(n0 + pip, row, inq);
+      float f[4], v[4], g[4], nf, wg, ck;
+      load4(p.f, p.ld, row, ok, f);
+      load4(p.v, p.ld, row, ok, v);
+      load4(p.g, p.ldg, row, ok, g);
+      const int k = assign(f, ok, row, nf, wg, ck);
+      float at[4], ak[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        at[q] = sm[SM_T1 + k * 32 + 4 * sub + q];
+        ak[q] = sm[SM_AFIN + k * 32 + 4 * sub + q];
+      }
+      float dwp = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dwp += g[q] * ak[q] + at[q] * v[q];
+      const float dw = group8_sum(dwp);
+      const float dz = dw * wg * (1.f - wg);
+      const float dc = alpha * dz;
+      if (ok) {
+        if (sub == 0) {
+          dbe += dz;
+          dal += dz * ck;
+          p.wgt[row * p.E + e] = dc;
+        }
+        if (dim_ok) {
+          f32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = wg * at[q];
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            if (inq & (1u << m)) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] += invq * sm[SM_T1 + m * 32 + 4 * sub + q];
+            }
+          *reinterpret_cast<f32x4*>(p.dv + row * p.lddf + coff) = o;
+        }
+        const float inv_nf = 1.f / nf;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (k == m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dch[m * 4 + q] += dc * f[q] * inv_nf;
+          }
+      }
+    }
+    reduce_md(dch, sm + SM_PART, sm + SM_T2, 1.f, tid, T);
+  }
+  float dcen[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    float dh[4], dot = 0.f;
+    const float inv_cn = 1.f / cnorm[m];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { dh[q] = sm[SM_T2 + m * 32 + 4 * sub + q]; dot += cl[m][q] * inv_cn * dh[q]; }
+    dot = group8_sum(dot);
+    const bool clamped = cnorm[m] <= 1e-12f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dcen[m][q] = clamped ? dh[q] * inv_cn : (dh[q] - cl[m][q] * inv_cn * dot) * inv_cn;
+  }
+  // ---- backward pass 4: df
+  for (int n0 = 0; n0 < N; n0 += PP) {
+    long row; unsigned inq;
+    const bool ok = locate(n0 + pip, row, inq);
+    float f[4], nf, wg, ck;
+    load4(p.f, p.ld, row, ok, f);
+    const int k = assign(f, ok, row, nf, wg, ck);
+    if (!ok || !dim_ok) continue;
+    const float dc = p.wgt[row * p.E + e];
+    const float inv_nf = 1.f / nf;
+    const bool clamped = nf <= 1e-12f;
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float ckq = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (k == m) ckq = cl[m][q] / cnorm[m];
+      const float fh = f[q] * inv_nf;
+      o[q] = clamped ? dc * ckq * inv_nf : dc * (ckq - fh * ck) * inv_nf;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (inq & (1u << m)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] += invq * dcen[m][q];
+      }
+    *reinterpret_cast<f32x4*>(p.df + row * p.lddf + coff) = o;
+  }
+  {
+    float ab[4] = {dal, dbe, 0.f, 0.f};
+    reduce4(ab, sm + SM_PART, sm + SM_MISC + 8, tid, T);
+    if (tid == 0) {
+      p.ab_partial[2 * (long)blockIdx.x] = sm[SM_MISC + 8];
+      p.ab_partial[2 * (long)blockIdx.x + 1] = sm[SM_MISC + 9];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void cluster_ab_reduce_kernel(const float* partial, long blocks, float* dalpha,
                                                                 float* dbeta, int accumulate) {
   __shared__ double red[8];
@@ -396,6 +658,11 @@ __global__ __launch_bounds__(256) void cluster_ab_reduce_kernel(const float* par
 }
 
 int cluster_plan(int N, int* T, int* npt) {
+  if (N > 256) {      // streaming kernel (points re-read in chunks): any region size
+    *T = 0;
+    *npt = 0;
+    return 0;
+  }
   int t = ((N + 63) / 64) * 64;
   if (t < 64) t = 64;
   if (t > 1024) t = 1024;
@@ -409,6 +676,10 @@ int cluster_plan(int N, int* T, int* npt) {
 
 template <bool BWD>
 int cluster_launch(const ClusterArgs& p, int T, int npt, long blocks, hipStream_t st) {
+  if (T == 0) {
+    hipLaunchKernelGGL((cluster_stream_kernel<BWD>), dim3(blocks), dim3(512), 0, st, p);
+    return 0;
+  }
   dim3 grid(blocks), block(T);
   if (T <= 256) {   // registers: up to 512 / (T/256) per lane; the 1024-thread variant is capped at 128
     switch (npt) {
@@ -432,7 +703,7 @@ int cluster_check(const char* name, const void* f, const void* v, long ld, int B
                "Ensure the feature map size (%d*%d) can be divided by fold %d*%d", H, W, fold, fold);
   VR_CHECK_ARG(ld % 4 == 0 && vr_aligned16(f) && vr_aligned16(v), "%s: rows must be 16-byte aligned", name);
   const int N = (H / fold) * (W / fold);
-  VR_CHECK_ARG(cluster_plan(N, T, npt) == 0, "%s: region of %d points exceeds the 1024-point kernel limit", name, N);
+  VR_CHECK_ARG(cluster_plan(N, T, npt) == 0, "%s: unsupported region of %d points", name, N);
   return VR_OK;
 }
 
@@ -445,6 +716,7 @@ extern "C" int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, co
   int rc = cluster_check("cluster_fwd", f, v, ld, B, H, W, E, D, fold, &T, &npt);
   if (rc) return rc;
   VR_CHECK_ARG(out && idx && alpha && beta && ldo % 4 == 0 && vr_aligned16(out), "cluster_fwd: bad output");
+  VR_CHECK_ARG(T != 0 || wgt, "cluster_fwd: regions of more than 256 points need the similarity map `wgt` (B,H,W,E)");
   ClusterArgs p{};
   p.f = f; p.v = v; p.ld = ld; p.alpha = alpha; p.beta = beta; p.out = out; p.ldo = ldo; p.idx = idx; p.wgt = wgt;
   p.B = B; p.H = H; p.W = W; p.E = E; p.D = D; p.fold = fold;
@@ -453,6 +725,10 @@ extern "C" int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, co
   return VR_OK;
 }
 
+// partial (alpha, beta) sums per workgroup + (streaming kernel) one float per point and head
+extern "C" long vrnet_cluster_bwd_workspace2(int B, int H, int W, int E, int fold) {
+  return ((long)B * E * fold * fold * 2 + (long)B * H * W * E) * 4 + 512;
+}
 extern "C" long vrnet_cluster_bwd_workspace(int B, int E, int fold) { return (long)B * E * fold * fold * 2 * 4 + 256; }
 
 extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
@@ -466,14 +742,16 @@ extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, co
   VR_CHECK_ARG(lddo % 4 == 0 && lddf % 4 == 0 && vr_aligned16(dout) && vr_aligned16(df) && vr_aligned16(dv),
                "cluster_bwd: rows must be 16-byte aligned");
   const long blocks = (long)B * E * fold * fold;
-  if (workspace_bytes < vrnet_cluster_bwd_workspace(B, E, fold)) {
-    vr_set_error("cluster_bwd: workspace too small");
+  const long need = T == 0 ? vrnet_cluster_bwd_workspace2(B, H, W, E, fold) : vrnet_cluster_bwd_workspace(B, E, fold);
+  if (workspace_bytes < need) {
+    vr_set_error("cluster_bwd: workspace %ld < %ld bytes", workspace_bytes, need);
     return VR_ERR_WORKSPACE;
   }
   ClusterArgs p{};
   p.f = f; p.v = v; p.ld = ld; p.alpha = alpha; p.beta = beta; p.idx = const_cast<unsigned char*>(idx);
   p.g = dout; p.ldg = lddo; p.df = df; p.dv = dv; p.lddf = lddf;
   p.ab_partial = reinterpret_cast<float*>(workspace);
+  p.wgt = p.ab_partial + ((blocks * 2 + 63) / 64) * 64;       // streaming kernel: per-point d cos scratch
   p.B = B; p.H = H; p.W = W; p.E = E; p.D = D; p.fold = fold;
   hipStream_t st = vr_stream(stream);
   cluster_launch<true>(p, T, npt, blocks, st);

@@ -47,6 +47,7 @@ _SIGS = {
     "vrnet_fill_f32": ([P, F, L, P], I),
     "vrnet_cluster_fwd_f32": ([P, P, L, P, P, P, L, P, P, I, I, I, I, I, I, P], I),
     "vrnet_cluster_bwd_workspace": ([I, I, I], L),
+    "vrnet_cluster_bwd_workspace2": ([I, I, I, I, I], L),
     "vrnet_cluster_bwd_f32": ([P, P, L, P, P, P, P, L, P, P, L, P, P, I, I, I, I, I, I, I, P, L, P], I),
     "vrnet_dwconv3x3_f32": ([P, L, P, P, L, I, I, I, I, I, I, P], I),
     "vrnet_dwconv3x3_wgrad_workspace": ([I, I, I, I], L),
@@ -225,7 +226,7 @@ def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold)
 
 def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, dbeta, accumulate_ab, B, H, W, E, Dh,
                 fold):
-    ws = _ws.get(_lib.vrnet_cluster_bwd_workspace(B, E, fold), f.device)
+    ws = _ws.get(_lib.vrnet_cluster_bwd_workspace2(B, H, W, E, fold), f.device)
     _check(_lib.vrnet_cluster_bwd_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(idx), ptr(dout), lddo, ptr(df),
                                       ptr(dv), lddf, ptr(dalpha), ptr(dbeta), accumulate_ab, B, H, W, E, Dh, fold,
                                       ptr(ws), ws.numel(), stream()), "cluster_bwd")

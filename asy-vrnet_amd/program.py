@@ -448,7 +448,9 @@ def cluster_block(rt, x, m, name=None):
     conv_call(rt, xn, tm.fc_v, v)
     o = rt.new(B, H, W, ED)
     idx = rt.buf(B, H, W, E, dtype=torch.uint8)
-    hip.cluster_fwd(f.t, v.t, ED, tm.sim_alpha, tm.sim_beta, o.t, ED, idx, None, B, H, W, E, Dh, fold)
+    big = (H // max(fold, 1)) * (W // max(fold, 1)) > 256       # streaming kernel keeps the similarity map
+    hip.cluster_fwd(f.t, v.t, ED, tm.sim_alpha, tm.sim_beta, o.t, ED, idx, rt.buf(B, H, W, E) if big else None,
+                    B, H, W, E, Dh, fold)
     if name is not None:
         rt.idx_maps[name] = idx
     t1 = rt.new(B, H, W, C) if rt.record else None

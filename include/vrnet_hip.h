@@ -115,13 +115,15 @@ int vrnet_fill_f32(float* dst, float value, long n, void* stream);
 /* ---- Context-Cluster core ---------------------------------------------------------------------------
  * Replaces Cluster.forward between fc1/fc_v and fc2 (vr_coc.py:158-190; pairwise_cos_sim :114-125) and its
  * autograd.  f, v, out: (B,H,W,E*D) NHWC; head e owns channels [e*D,(e+1)*D); regions are the fold x fold
- * tiles of the map (fold = 1: the whole map), at most 1024 points per region, D % 4 == 0, D <= 32.
+ * tiles of the map (fold = 1: the whole map), D % 4 == 0, D <= 32.  Regions of <= 256 points (every backbone
+ * stage at 512 px) stay in registers; larger ones (neck p3 at 512 px, everything at 1024 px) use a streaming kernel.
  * idx: (B,H,W,E) u8 hard assignment (first maximum, as torch.max(dim)); wgt: (B,H,W,E) similarity of the
- * assigned centre (optional).  alpha, beta: device scalars (sim_alpha, sim_beta, :148-149). */
+ * assigned centre (optional for regions of <= 256 points, required above).  alpha, beta: device scalars (sim_alpha, sim_beta, :148-149). */
 int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                           float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E, int D,
                           int fold, void* stream);
-long vrnet_cluster_bwd_workspace(int B, int E, int fold);
+long vrnet_cluster_bwd_workspace(int B, int E, int fold);                          /* regions of <= 256 points */
+long vrnet_cluster_bwd_workspace2(int B, int H, int W, int E, int fold);            /* any region size */
 /* Recomputes the forward from f, v with the saved assignment idx; df, dv share row stride lddf. */
 int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                           const unsigned char* idx, const float* dout, long lddo, float* df, float* dv, long lddf,

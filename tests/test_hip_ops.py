@@ -236,6 +236,9 @@ CLUSTER_CASES = [
     (2, 4, 32, 4, 4, 2),       # N = 4
     (2, 4, 24, 2, 2, 2),       # N = 1: all four centres coincide -> ties -> index 0
     (1, 4, 32, 128, 128, 8),   # fold 8 (stage 0)
+    (1, 4, 24, 128, 128, 2),   # N = 4096 (neck p3 at 1024 px): streaming kernel
+    (1, 2, 32, 34, 30, 2),     # N = 255 odd (register kernel, ragged last pass) / 17x15 regions
+    (1, 2, 32, 36, 30, 2),     # N = 270: smallest streaming case, odd windows
 ]
 
 
@@ -251,6 +254,9 @@ def test_cluster_core(hip, case):
     idx = torch.empty(B, H, W, E, dtype=torch.uint8, device="cuda")
     wgt = torch.empty(B, H, W, E, device="cuda")
     hip.cluster_fwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), out, E * D, idx, wgt, B, H, W, E, D, fold)
+    if (H // fold) * (W // fold) > 256:
+        with pytest.raises(RuntimeError, match="similarity map"):
+            hip.cluster_fwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), out, E * D, idx, None, B, H, W, E, D, fold)
     idx_cpu = idx.permute(0, 3, 1, 2).contiguous().cpu().long()
     rep = {}
     ref, ref_idx = O.cluster_core(f, v, alpha, beta, E, fold, forced_idx=idx_cpu, report=rep)

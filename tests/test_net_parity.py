@@ -36,6 +36,18 @@ def test_against_oracle(A, phi, size, batch, training):
     assert rep["ok"], rep
 
 
+def test_1024_forward_against_oracle(A):
+    """BASELINE config 5's input size: 32x32-point regions in every backbone stage, 64x64 (4096 points) in neck p3
+    (streaming Cluster kernel); needs EfficientVRNet(..., img_size=1024) as the reference's fea_pos is 512-only."""
+    from tests.parity import compare_with_oracle
+    m = build(A, "nano", 1024, 13, False)
+    rep = compare_with_oracle(m, 1, 1024, iseed=17, check_grads=False, oracle_dtype=torch.float32)
+    print(rep)
+    assert rep["ok"], rep
+    with pytest.raises(RuntimeError, match="fea_pos"):
+        build(A, "nano", 512, 13, False)(torch.zeros(1, 3, 1024, 1024, device="cuda"), torch.zeros(1, 4, 1024, 1024, device="cuda"))
+
+
 def test_512_bs2_against_oracle(A):
     from tests.parity import compare_with_oracle
     m = build(A, "nano", 512, 3, True)
