@@ -70,12 +70,12 @@ class ConvTimer:
 
     def __init__(self, hip):
         self.hip = hip
-        self.rec = {"igemm": [], "wgrad": []}
-        self.orig = (hip.conv2d, hip.conv2d_wgrad)
+        self.rec = {"igemm": [], "wgrad": [], "cluster_fwd": [], "cluster_bwd": []}
+        self.orig = (hip.conv2d, hip.conv2d_wgrad, hip.cluster_fwd, hip.cluster_bwd)
 
     def __enter__(self):
         hip, rec = self.hip, self.rec
-        o_conv, o_wgrad = self.orig
+        o_conv, o_wgrad, o_cf, o_cb = self.orig
 
         def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -90,11 +90,24 @@ class ConvTimer:
             o_wgrad(x, ldx, dy, lddy, dw, db, rs, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_)
             e1.record()
             rec["wgrad"].append((2.0 * B * OH * OW * Cout * Cin * kh * kw, e0, e1))
-        hip.conv2d, hip.conv2d_wgrad = conv2d, conv2d_wgrad
+        def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_cf(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold)
+            e1.record()
+            rec["cluster_fwd"].append((3.0 * B * H * W * E * Dh * 4, e0, e1))      # read f, v; write out
+
+        def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, da, db, acc, B, H, W, E, Dh, fold):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_cb(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, da, db, acc, B, H, W, E, Dh, fold)
+            e1.record()
+            rec["cluster_bwd"].append((5.0 * B * H * W * E * Dh * 4, e0, e1))      # read f, v, g; write df, dv
+        hip.conv2d, hip.conv2d_wgrad, hip.cluster_fwd, hip.cluster_bwd = conv2d, conv2d_wgrad, cluster_fwd, cluster_bwd
         return self
 
     def __exit__(self, *a):
-        self.hip.conv2d, self.hip.conv2d_wgrad = self.orig
+        self.hip.conv2d, self.hip.conv2d_wgrad, self.hip.cluster_fwd, self.hip.cluster_bwd = self.orig
 
     def summary(self, key):
         torch.cuda.synchronize()
@@ -217,6 +230,8 @@ def main():
                 eager_step(args.warmup + i)
             n, flops, ms = ct.summary("igemm")
             nw, fw, msw = ct.summary("wgrad")
+            ncf, bcf, mscf = ct.summary("cluster_fwd")
+            ncb, bcb, mscb = ct.summary("cluster_bwd")
         model.concurrent = True
         ach = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32)",
@@ -228,7 +243,14 @@ def main():
                 "avg_launch_gflop": round(flops / n / 1e9, 3),
                 "share_of_step": round(ms / args.steps / ms_per_step, 3),
                 "wgrad": {"achieved": round(fw / (msw * 1e-3) / 1e12, 2), "launches_per_step": nw // args.steps,
-                          "share_of_step": round(msw / args.steps / ms_per_step, 3)}}
+                          "share_of_step": round(msw / args.steps / ms_per_step, 3)},
+                # the HBM-bound Context-Cluster kernels: algorithmic bytes (3 resp. 5 tensors of B*P*E*D fp32) / time
+                "cluster_hbm": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+                                "fwd_achieved": round(bcf / (mscf * 1e-3) / 1e9, 1),
+                                "bwd_achieved": round(bcb / (mscb * 1e-3) / 1e9, 1),
+                                "frac": round((bcf + bcb) / ((mscf + mscb) * 1e-3) / 8e12, 4),
+                                "launches_per_step": (ncf + ncb) // args.steps,
+                                "avg_launch_mbytes": round((bcf + bcb) / (ncf + ncb) / 1e6, 1)}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.phi, args.size, args.cpu_batch, 0)
