@@ -25,60 +25,109 @@ struct ClusterArgs {
 
 constexpr int MAXW = 16;   // waves per workgroup
 
+// Cross-lane moves use DPP modifiers (one VALU op, no LDS crossbar trip as ds_bpermute needs):
+//   0xB1 quad_perm[1,0,3,2] (= xor 1), 0x4E quad_perm[2,3,0,1] (= xor 2), 0x141 row_half_mirror (lane i <-> 7-i of
+//   each 8), 0x140 row_mirror (i <-> 15-i of each 16), 0x128 row_ror:8 (= xor 8 within a row of 16).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
+}
+
 // Sum vals[m*4+q] (this lane's 4 dims of centre m) over every point of the workgroup.
-// Result: dst[m*32 + d] * scale.  part: [NW][128] scratch.
+// Result: dst[m*32 + d] * scale.  part: [NW*4][128] scratch (one partial per 16-lane row).
 __device__ __forceinline__ void reduce_md(float (&vals)[16], float* part, float* dst, float scale, int tid, int T) {
-  const int lane = tid & 63, wave = tid >> 6, NW = T >> 6;
+  const int lane = tid & 63, NR = T >> 4;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    float x = vals[i];
-    x += __shfl_xor(x, 8, 64);
-    x += __shfl_xor(x, 16, 64);
-    x += __shfl_xor(x, 32, 64);
-    vals[i] = x;
-  }
-  if (lane < 8) {
+  for (int i = 0; i < 16; ++i) vals[i] += dpp_f<0x128>(vals[i]);
+  if ((lane & 15) < 8) {
+    float* dstp = part + (tid >> 4) * 128 + 4 * (lane & 7);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) part[wave * 128 + m * 32 + 4 * lane + q] = vals[m * 4 + q];
+    for (int m = 0; m < 4; ++m) {
+      f32x4 o = {vals[m * 4], vals[m * 4 + 1], vals[m * 4 + 2], vals[m * 4 + 3]};
+      *reinterpret_cast<f32x4*>(dstp + m * 32) = o;
+    }
   }
   __syncthreads();
   for (int i = tid; i < 128; i += T) {
     float s = 0.f;
-    for (int w = 0; w < NW; ++w) s += part[w * 128 + i];
+    for (int r = 0; r < NR; ++r) s += part[r * 128 + i];
     dst[i] = s * scale;
   }
   __syncthreads();
 }
 
-// Sum 4 per-lane scalars over the workgroup -> dst[0..3].  part: [NW][4] scratch.
+// Sum 4 per-lane scalars over the workgroup -> dst[0..3].  part: [NW*4][4] scratch.
 __device__ __forceinline__ void reduce4(float (&vals)[4], float* part, float* dst, int tid, int T) {
-  const int lane = tid & 63, wave = tid >> 6, NW = T >> 6;
+  const int NR = T >> 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) vals[i] = wave_sum(vals[i]);
-  if (lane == 0) {
+  for (int i = 0; i < 4; ++i) {
+    float x = vals[i];
+    x += dpp_f<0xB1>(x);
+    x += dpp_f<0x4E>(x);
+    x += dpp_f<0x141>(x);
+    x += dpp_f<0x140>(x);
+    vals[i] = x;
+  }
+  if ((tid & 15) == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) part[wave * 4 + i] = vals[i];
+    for (int i = 0; i < 4; ++i) part[(tid >> 4) * 4 + i] = vals[i];
   }
   __syncthreads();
   if (tid < 4) {
     float s = 0.f;
-    for (int w = 0; w < NW; ++w) s += part[w * 4 + tid];
+    for (int r = 0; r < NR; ++r) s += part[r * 4 + tid];
     dst[tid] = s;
   }
   __syncthreads();
 }
 
+// Hard assignment of one point (vr_coc.py:171-176).  All 8 lanes of the point's group hold the 4 dot products dt[]
+// and the point norm; lane (sub & 3) evaluates centre m = sub & 3 only (one sigmoid per lane instead of four),
+// then the 4 candidates are combined with two shuffles: larger similarity wins, ties go to the LOWER centre
+// index (torch.max(dim) returns the first maximum).  Returns k; wgt = similarity, cosk = cosine of centre k.
+__device__ __forceinline__ int assign4(const float (&dt)[4], float inv_nf, const float (&inv_cn)[4], float alpha,
+                                       float beta, int sub, float& wgt, float& cosk) {
+  const int m = sub & 3;
+  const float d = m == 0 ? dt[0] : (m == 1 ? dt[1] : (m == 2 ? dt[2] : dt[3]));
+  const float ic = m == 0 ? inv_cn[0] : (m == 1 ? inv_cn[1] : (m == 2 ? inv_cn[2] : inv_cn[3]));
+  float c = d * inv_nf * ic;
+  float sg = vr_sigmoid(beta + alpha * c);
+  int k = m;
+#pragma unroll
+  for (int o = 1; o <= 2; o <<= 1) {
+    const float s2 = o == 1 ? dpp_f<0xB1>(sg) : dpp_f<0x4E>(sg), c2 = o == 1 ? dpp_f<0xB1>(c) : dpp_f<0x4E>(c);
+    const int k2 = o == 1 ? dpp_i<0xB1>(k) : dpp_i<0x4E>(k);
+    const bool take = s2 > sg || (s2 == sg && k2 < k);
+    sg = take ? s2 : sg;
+    c = take ? c2 : c;
+    k = take ? k2 : k;
+  }
+  wgt = sg;
+  cosk = c;
+  return k;
+}
+// similarity of a GIVEN centre k (backward replay of the saved assignment)
+__device__ __forceinline__ void sim_of(const float (&dt)[4], int k, float inv_nf, const float (&inv_cn)[4], float alpha,
+                                       float beta, float& wgt, float& cosk) {
+  const float d = k == 0 ? dt[0] : (k == 1 ? dt[1] : (k == 2 ? dt[2] : dt[3]));
+  const float ic = k == 0 ? inv_cn[0] : (k == 1 ? inv_cn[1] : (k == 2 ? inv_cn[2] : inv_cn[3]));
+  cosk = d * inv_nf * ic;
+  wgt = vr_sigmoid(beta + alpha * cosk);
+}
+
 __device__ __forceinline__ float group8_sum(float x) {
-  x += __shfl_xor(x, 1, 64);
-  x += __shfl_xor(x, 2, 64);
-  x += __shfl_xor(x, 4, 64);
+  x += dpp_f<0xB1>(x);
+  x += dpp_f<0x4E>(x);
+  x += dpp_f<0x141>(x);   // both quads already hold their own sum, so the mirror partner supplies the other quad's
   return x;
 }
 
-// LDS carve (floats): part[MAXW*128] | cen[128] | vcen[128] | agg[128] | afin[128] | t1[128] | t2[128] | misc[32]
-constexpr int SM_PART = 0, SM_CEN = MAXW * 128, SM_VCEN = SM_CEN + 128, SM_AGG = SM_VCEN + 128,
+// LDS carve (floats): part[MAXW*4*128] | cen[128] | vcen[128] | agg[128] | afin[128] | t1[128] | t2[128] | misc[32]
+constexpr int SM_PART = 0, SM_CEN = MAXW * 4 * 128, SM_VCEN = SM_CEN + 128, SM_AGG = SM_VCEN + 128,
               SM_AFIN = SM_AGG + 128, SM_T1 = SM_AFIN + 128, SM_T2 = SM_T1 + 128, SM_MISC = SM_T2 + 128,
               SM_TOTAL = SM_MISC + 32;
 
@@ -132,14 +181,14 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
 #pragma unroll
     for (int s = 0; s < NPT; ++s)
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
-        if (inq[s] & (1u << m)) {
+      for (int m = 0; m < 4; ++m) {
+        const float pw = (inq[s] >> m) & 1u ? 1.f : 0.f;   // 0/1 weight instead of a branch: straight-line FMAs
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            cs[m * 4 + q] += f[s][q];
-            vs[m * 4 + q] += v[s][q];
-          }
+        for (int q = 0; q < 4; ++q) {
+          cs[m * 4 + q] += pw * f[s][q];
+          vs[m * 4 + q] += pw * v[s][q];
         }
+      }
     reduce_md(cs, sm + SM_PART, sm + SM_CEN, invq, tid, T);
     reduce_md(vs, sm + SM_PART, sm + SM_VCEN, invq, tid, T);
   }
@@ -150,9 +199,16 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       cl[m][q] = sm[SM_CEN + m * 32 + 4 * sub + q];
-      s2 += cl[m][q] * cl[m][q];
+      s2 = __builtin_fmaf(cl[m][q], cl[m][q], s2);
     }
     cnorm[m] = fmaxf(sqrtf(group8_sum(s2)), 1e-12f);
+  }
+  float inv_cn[4], chat[4][4];   // 1/|c_m| and the unit centres c_m/|c_m|
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    inv_cn[m] = 1.f / cnorm[m];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) chat[m][q] = cl[m][q] * inv_cn[m];
   }
 
   // ---- similarity, hard assignment
@@ -163,37 +219,24 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
     float n2 = 0.f, dt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      n2 += f[s][q] * f[s][q];
+      n2 = __builtin_fmaf(f[s][q], f[s][q], n2);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) dt[m] += f[s][q] * cl[m][q];
+      for (int m = 0; m < 4; ++m) dt[m] = __builtin_fmaf(f[s][q], cl[m][q], dt[m]);   // explicit: identical centres must
+                                                                                    // give bit-identical dots (ties)
     }
     n2 = group8_sum(n2);
 #pragma unroll
     for (int m = 0; m < 4; ++m) dt[m] = group8_sum(dt[m]);
     const float nf = fmaxf(sqrtf(n2), 1e-12f);
-    fn[s] = nf;
-    float best = -1.f, bc = 0.f;
-    int k = 0;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const float c = dt[m] / (nf * cnorm[m]);
-      const float sg = vr_sigmoid(beta + alpha * c);
-      if (sg > best) {   // strict: first maximum wins, as torch.max(dim)
-        best = sg;
-        k = m;
-        bc = c;
-      }
-    }
-    if (BWD && ok[s]) k = p.idx[row[s] * p.E + e];   // replay the forward's assignment
+    const float inv_nf = 1.f / nf;
+    fn[s] = inv_nf;   // 1/max(|f_n|, eps); the clamp is active iff inv_nf >= 1e12
+    float best, bc;
+    int k;
     if (BWD) {
-      bc = 0.f;
-      best = 0.f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        if (k == m) {
-          bc = dt[m] / (nf * cnorm[m]);
-          best = vr_sigmoid(beta + alpha * bc);
-        }
+      k = ok[s] ? (int)p.idx[row[s] * p.E + e] : 0;     // replay the forward's assignment
+      sim_of(dt, k, inv_nf, inv_cn, alpha, beta, best, bc);
+    } else {
+      k = assign4(dt, inv_nf, inv_cn, alpha, beta, sub, best, bc);
     }
     wg[s] = best;
     kk[s] = k;
@@ -207,14 +250,13 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
     for (int i = 0; i < 16; ++i) ag[i] = 0.f;
 #pragma unroll
     for (int s = 0; s < NPT; ++s)
-      if (ok[s]) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (kk[s] == m) {
+      for (int m = 0; m < 4; ++m) {
+        const bool mine = ok[s] && kk[s] == m;
+        const float wk = mine ? wg[s] : 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ag[m * 4 + q] += wg[s] * v[s][q];
-            if (sub == 0) cnt[m] += 1.f;
-          }
+        for (int q = 0; q < 4; ++q) ag[m * 4 + q] += wk * v[s][q];
+        cnt[m] += (mine && sub == 0) ? 1.f : 0.f;
       }
     reduce_md(ag, sm + SM_PART, sm + SM_AGG, 1.f, tid, T);
     reduce4(cnt, sm + SM_PART, sm + SM_MISC, tid, T);
@@ -256,13 +298,11 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
     for (int i = 0; i < 16; ++i) da[i] = 0.f;
 #pragma unroll
     for (int s = 0; s < NPT; ++s)
-      if (ok[s]) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (kk[s] == m) {
+      for (int m = 0; m < 4; ++m) {
+        const float wk = (ok[s] && kk[s] == m) ? wg[s] : 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) da[m * 4 + q] += wg[s] * g[s][q];
-          }
+        for (int q = 0; q < 4; ++q) da[m * 4 + q] += wk * g[s][q];
       }
     reduce_md(da, sm + SM_PART, sm + SM_T1, 1.f, tid, T);
     for (int i = tid; i < 128; i += T) sm[SM_T1 + i] = sm[SM_T1 + i] / (sm[SM_MISC + (i >> 5)] + 1.f);
@@ -272,14 +312,16 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
   float dcs[NPT];
   float dal = 0.f, dbe = 0.f;
   {
-    float dch[16];
+    float dch[16], atq[4][4];   // atq: this lane's 4 dims of at_m, all 4 centres
 #pragma unroll
     for (int i = 0; i < 16; ++i) dch[i] = 0.f;
 #pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atq[m][q] = sm[SM_T1 + m * 32 + 4 * sub + q];
+#pragma unroll
     for (int s = 0; s < NPT; ++s) {
-      dcs[s] = 0.f;
-      if (!ok[s]) continue;      // whole 8-lane groups share ok[s]: shuffles below stay converged per group
-      const int k = kk[s];
+      const int k = kk[s];     // padded points (!ok) run the same straight-line code with zero weights
       float at[4], ak[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -291,33 +333,32 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
       for (int q = 0; q < 4; ++q) dwp += g[s][q] * ak[q] + at[q] * v[s][q];
       const float dw = group8_sum(dwp);
       const float dz = dw * wg[s] * (1.f - wg[s]);
-      if (sub == 0) {
-        dbe += dz;
-        dal += dz * cosk[s];
-      }
-      const float dc = alpha * dz;
+      const float live = (ok[s] && sub == 0) ? 1.f : 0.f;
+      dbe += live * dz;
+      dal += live * dz * cosk[s];
+      const float dc = ok[s] ? alpha * dz : 0.f;
       dcs[s] = dc;
       // dv_n = w_n * at_k + sum_{m: n in Q_m} at_m / |Q_m|
-      if (dim_ok) {
+      {
         f32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = wg[s] * at[q];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (inq[s] & (1u << m)) {
+        for (int m = 0; m < 4; ++m) {
+          const float pw = (inq[s] >> m) & 1u ? invq : 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] += invq * sm[SM_T1 + m * 32 + 4 * sub + q];
-          }
-        *reinterpret_cast<f32x4*>(p.dv + row[s] * p.lddf + e * D + 4 * sub) = o;
+          for (int q = 0; q < 4; ++q) o[q] += pw * atq[m][q];
+        }
+        if (ok[s] && dim_ok) *reinterpret_cast<f32x4*>(p.dv + row[s] * p.lddf + e * D + 4 * sub) = o;
       }
       // d c_hat_k += dcos * f_hat_n
-      const float inv_nf = 1.f / fn[s];
+      const float dcn = dc * fn[s];
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
-        if (k == m) {
+      for (int m = 0; m < 4; ++m) {
+        const float wk = k == m ? dcn : 0.f;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) dch[m * 4 + q] += dc * f[s][q] * inv_nf;
-        }
+        for (int q = 0; q < 4; ++q) dch[m * 4 + q] += wk * f[s][q];
+      }
     }
     reduce_md(dch, sm + SM_PART, sm + SM_T2, 1.f, tid, T);
   }
@@ -326,41 +367,36 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     float dh[4], dot = 0.f;
-    const float inv_cn = 1.f / cnorm[m];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       dh[q] = sm[SM_T2 + m * 32 + 4 * sub + q];
-      dot += cl[m][q] * inv_cn * dh[q];
+      dot += chat[m][q] * dh[q];
     }
     dot = group8_sum(dot);
     const bool clamped = cnorm[m] <= 1e-12f;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      dcen[m][q] = clamped ? dh[q] * inv_cn : (dh[q] - cl[m][q] * inv_cn * dot) * inv_cn;
+      dcen[m][q] = clamped ? dh[q] * inv_cn[m] : (dh[q] - chat[m][q] * dot) * inv_cn[m];
   }
 #pragma unroll
   for (int s = 0; s < NPT; ++s) {
-    if (!ok[s] || !dim_ok) continue;
     const int k = kk[s];
-    const float inv_nf = 1.f / fn[s];
-    const bool clamped = fn[s] <= 1e-12f;
+    const float inv_nf = fn[s];
+    const bool clamped = inv_nf >= 1e12f;
+    const float dn = dcs[s] * inv_nf, proj = clamped ? 0.f : inv_nf * cosk[s];
     f32x4 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float ck = 0.f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        if (k == m) ck = cl[m][q] / cnorm[m];
-      const float fh = f[s][q] * inv_nf;
-      o[q] = clamped ? dcs[s] * ck * inv_nf : dcs[s] * (ck - fh * cosk[s]) * inv_nf;
+      const float ck = k == 0 ? chat[0][q] : (k == 1 ? chat[1][q] : (k == 2 ? chat[2][q] : chat[3][q]));
+      o[q] = dn * (ck - f[s][q] * proj);
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-      if (inq[s] & (1u << m)) {
+    for (int m = 0; m < 4; ++m) {
+      const float pw = (inq[s] >> m) & 1u ? invq : 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] += invq * dcen[m][q];
-      }
-    *reinterpret_cast<f32x4*>(p.df + row[s] * p.lddf + e * D + 4 * sub) = o;
+      for (int q = 0; q < 4; ++q) o[q] += pw * dcen[m][q];
+    }
+    if (ok[s] && dim_ok) *reinterpret_cast<f32x4*>(p.df + row[s] * p.lddf + e * D + 4 * sub) = o;
   }
   // d alpha, d beta partials of this workgroup
   {
@@ -426,11 +462,11 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
       load4(p.f, p.ld, row, ok, f);
       load4(p.v, p.ld, row, ok, v);
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
-        if (inq & (1u << m)) {
+      for (int m = 0; m < 4; ++m) {
+        const float pw = (inq >> m) & 1u ? 1.f : 0.f;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { cs[m * 4 + q] += f[q]; vs[m * 4 + q] += v[q]; }
-        }
+        for (int q = 0; q < 4; ++q) { cs[m * 4 + q] += pw * f[q]; vs[m * 4 + q] += pw * v[q]; }
+      }
     }
     reduce_md(cs, sm + SM_PART, sm + SM_CEN, invq, tid, T);
     reduce_md(vs, sm + SM_PART, sm + SM_VCEN, invq, tid, T);
@@ -440,36 +476,37 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
   for (int m = 0; m < 4; ++m) {
     float s2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { cl[m][q] = sm[SM_CEN + m * 32 + 4 * sub + q]; s2 += cl[m][q] * cl[m][q]; }
+    for (int q = 0; q < 4; ++q) { cl[m][q] = sm[SM_CEN + m * 32 + 4 * sub + q]; s2 = __builtin_fmaf(cl[m][q], cl[m][q], s2); }
     cnorm[m] = fmaxf(sqrtf(group8_sum(s2)), 1e-12f);
+  }
+  float inv_cn[4], chat[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    inv_cn[m] = 1.f / cnorm[m];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) chat[m][q] = cl[m][q] * inv_cn[m];
   }
   // similarity of one point (all 8 lanes of its group get the same values)
   auto assign = [&](const float (&f)[4], bool ok, long row, float& nf, float& wgt, float& cosk) -> int {
     float n2 = 0.f, dt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      n2 += f[q] * f[q];
+      n2 = __builtin_fmaf(f[q], f[q], n2);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) dt[m] += f[q] * cl[m][q];
+      for (int m = 0; m < 4; ++m) dt[m] = __builtin_fmaf(f[q], cl[m][q], dt[m]);
     }
     n2 = group8_sum(n2);
 #pragma unroll
     for (int m = 0; m < 4; ++m) dt[m] = group8_sum(dt[m]);
-    nf = fmaxf(sqrtf(n2), 1e-12f);
-    float best = -1.f, bc = 0.f;
-    int k = 0;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const float c = dt[m] / (nf * cnorm[m]);
-      const float sg = vr_sigmoid(beta + alpha * c);
-      if (sg > best) { best = sg; k = m; bc = c; }
-    }
+    const float inv_nf = 1.f / fmaxf(sqrtf(n2), 1e-12f);
+    nf = inv_nf;   // callers get 1/max(|f_n|, eps)
+    float best, bc;
+    int k;
     if (BWD) {
-      if (ok) k = p.idx[row * p.E + e];
-      bc = 0.f; best = 0.f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        if (k == m) { bc = dt[m] / (nf * cnorm[m]); best = vr_sigmoid(beta + alpha * bc); }
+      k = ok ? (int)p.idx[row * p.E + e] : 0;
+      sim_of(dt, k, inv_nf, inv_cn, alpha, beta, best, bc);
+    } else {
+      k = assign4(dt, inv_nf, inv_cn, alpha, beta, sub, best, bc);
     }
     wgt = best; cosk = bc;
     return k;
@@ -488,18 +525,17 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
       load4(p.v, p.ld, row, ok, v);
       if (BWD) load4(p.g, p.ldg, row, ok, g);
       const int k = assign(f, ok, row, nf, wg, ck);
-      if (ok) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (k == m) {
+      for (int m = 0; m < 4; ++m) {
+        const bool mine = ok && k == m;
+        const float wk = mine ? wg : 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { ag[m * 4 + q] += wg * v[q]; if (BWD) da[m * 4 + q] += wg * g[q]; }
-            if (sub == 0) cnt[m] += 1.f;
-          }
-        if (!BWD && sub == 0) {
-          p.idx[row * p.E + e] = (unsigned char)k;
-          p.wgt[row * p.E + e] = wg;
-        }
+        for (int q = 0; q < 4; ++q) { ag[m * 4 + q] += wk * v[q]; if (BWD) da[m * 4 + q] += wk * g[q]; }
+        cnt[m] += (mine && sub == 0) ? 1.f : 0.f;
+      }
+      if (!BWD && ok && sub == 0) {
+        p.idx[row * p.E + e] = (unsigned char)k;
+        p.wgt[row * p.E + e] = wg;
       }
     }
     reduce_md(ag, sm + SM_PART, sm + SM_AGG, 1.f, tid, T);
@@ -573,13 +609,13 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
             }
           *reinterpret_cast<f32x4*>(p.dv + row * p.lddf + coff) = o;
         }
-        const float inv_nf = 1.f / nf;
+        const float dcn = dc * nf;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (k == m) {
+        for (int m = 0; m < 4; ++m) {
+          const float wk = k == m ? dcn : 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dch[m * 4 + q] += dc * f[q] * inv_nf;
-          }
+          for (int q = 0; q < 4; ++q) dch[m * 4 + q] += wk * f[q];
+        }
       }
     }
     reduce_md(dch, sm + SM_PART, sm + SM_T2, 1.f, tid, T);
@@ -588,13 +624,12 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     float dh[4], dot = 0.f;
-    const float inv_cn = 1.f / cnorm[m];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { dh[q] = sm[SM_T2 + m * 32 + 4 * sub + q]; dot += cl[m][q] * inv_cn * dh[q]; }
+    for (int q = 0; q < 4; ++q) { dh[q] = sm[SM_T2 + m * 32 + 4 * sub + q]; dot += chat[m][q] * dh[q]; }
     dot = group8_sum(dot);
     const bool clamped = cnorm[m] <= 1e-12f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dcen[m][q] = clamped ? dh[q] * inv_cn : (dh[q] - cl[m][q] * inv_cn * dot) * inv_cn;
+    for (int q = 0; q < 4; ++q) dcen[m][q] = clamped ? dh[q] * inv_cn[m] : (dh[q] - chat[m][q] * dot) * inv_cn[m];
   }
   // ---- backward pass 4: df
   for (int n0 = 0; n0 < N; n0 += PP) {
@@ -605,17 +640,14 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
     const int k = assign(f, ok, row, nf, wg, ck);
     if (!ok || !dim_ok) continue;
     const float dc = p.wgt[row * p.E + e];
-    const float inv_nf = 1.f / nf;
-    const bool clamped = nf <= 1e-12f;
+    const float inv_nf = nf;
+    const bool clamped = inv_nf >= 1e12f;
+    const float dn = dc * inv_nf, proj = clamped ? 0.f : inv_nf * ck;
     f32x4 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float ckq = 0.f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        if (k == m) ckq = cl[m][q] / cnorm[m];
-      const float fh = f[q] * inv_nf;
-      o[q] = clamped ? dc * ckq * inv_nf : dc * (ckq - fh * ck) * inv_nf;
+      const float ckq = k == 0 ? chat[0][q] : (k == 1 ? chat[1][q] : (k == 2 ? chat[2][q] : chat[3][q]));
+      o[q] = dn * (ckq - f[q] * proj);
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)

@@ -82,27 +82,27 @@ class ConvTimer:
             e0.record()
             o_conv(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_)
             e1.record()
-            rec["igemm"].append((2.0 * B * OH * OW * Cout * Cin * kh * kw, e0, e1))
+            rec["igemm"].append((2.0 * B * OH * OW * Cout * Cin * kh * kw, e0, e1, f"M{B*OH*OW} N{Cout} K{Cin}x{kh}x{kw}"))
 
         def conv2d_wgrad(x, ldx, dy, lddy, dw, db, rs, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             o_wgrad(x, ldx, dy, lddy, dw, db, rs, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_)
             e1.record()
-            rec["wgrad"].append((2.0 * B * OH * OW * Cout * Cin * kh * kw, e0, e1))
+            rec["wgrad"].append((2.0 * B * OH * OW * Cout * Cin * kh * kw, e0, e1, f"M{B*OH*OW} N{Cout} K{Cin}x{kh}x{kw}"))
         def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             o_cf(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold)
             e1.record()
-            rec["cluster_fwd"].append((3.0 * B * H * W * E * Dh * 4, e0, e1))      # read f, v; write out
+            rec["cluster_fwd"].append((3.0 * B * H * W * E * Dh * 4, e0, e1, f"{H}x{W} E{E} D{Dh} fold{fold}"))      # read f, v; write out
 
         def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, da, db, acc, B, H, W, E, Dh, fold):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             o_cb(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, da, db, acc, B, H, W, E, Dh, fold)
             e1.record()
-            rec["cluster_bwd"].append((5.0 * B * H * W * E * Dh * 4, e0, e1))      # read f, v, g; write df, dv
+            rec["cluster_bwd"].append((5.0 * B * H * W * E * Dh * 4, e0, e1, f"{H}x{W} E{E} D{Dh} fold{fold}"))      # read f, v, g; write df, dv
         hip.conv2d, hip.conv2d_wgrad, hip.cluster_fwd, hip.cluster_bwd = conv2d, conv2d_wgrad, cluster_fwd, cluster_bwd
         return self
 
@@ -112,9 +112,21 @@ class ConvTimer:
     def summary(self, key):
         torch.cuda.synchronize()
         r = self.rec[key]
-        flops = sum(f for f, _, _ in r)
-        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in r)
+        flops = sum(x[0] for x in r)
+        ms = sum(x[1].elapsed_time(x[2]) for x in r)
         return len(r), flops, ms
+
+    def detail(self, key, unit_scale, unit):
+        """Per-shape breakdown (stderr aid for tuning): launches, total ms, achieved rate."""
+        torch.cuda.synchronize()
+        agg = {}
+        for work, e0, e1, tag in self.rec[key]:
+            a = agg.setdefault(tag, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += work
+            a[2] += e0.elapsed_time(e1)
+        for tag, (n, work, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+            print(f"  {key:12s} {tag:28s} x{n:3d} {ms:8.3f} ms  {work / ms * 1e3 / unit_scale:9.1f} {unit}", file=sys.stderr)
 
 
 def cpu_baseline(phi, size, batch, seed_sd):
@@ -156,6 +168,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="per-shape kernel breakdown on stderr (tuning aid)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     args = ap.parse_args()
 
@@ -232,6 +245,11 @@ def main():
             nw, fw, msw = ct.summary("wgrad")
             ncf, bcf, mscf = ct.summary("cluster_fwd")
             ncb, bcb, mscb = ct.summary("cluster_bwd")
+            if args.detail:
+                ct.detail("igemm", 1e12, "TFLOP/s")
+                ct.detail("wgrad", 1e12, "TFLOP/s")
+                ct.detail("cluster_fwd", 1e9, "GB/s")
+                ct.detail("cluster_bwd", 1e9, "GB/s")
         model.concurrent = True
         ach = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32)",
