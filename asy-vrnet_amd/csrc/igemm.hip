@@ -35,6 +35,97 @@ struct IgemmArgs {
 
 constexpr int STAGE_LD = 36;                       // epilogue staging tile: 32 rows x 36 floats per wave
 
+// Epilogue shared by the igemm kernels.  C/D map of the 32x32 MFMA: col = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  `smem` must hold 4 * 32 * STAGE_LD floats and no wave may
+// still be reading operand images from it (callers end their main loop with a barrier).
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int khalf = lane >> 5;
+  const long hw = (long)p.MH * p.MW;
+  if (p.e_vec) {
+    // Row-contiguous float4 epilogue: each wave transposes one 32x32 accumulator tile through its private
+    // LDS staging tile, then 8 lanes cover one 128-byte output row segment (aux / residual loads and all
+    // stores are whole lines).  The main loop ended with a barrier, so the operand images can be reused.
+    float* stage = smem + wave * (32 * STAGE_LD);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * STAGE_LD + (lane & 31)] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int q = lane + 64 * t;
+          const int row = q >> 3, c4 = (q & 7) * 4;
+          const int m = m0 + wm * TM * 32 + i * 32 + row;
+          const int n = n0 + wn * TN * 32 + j * 32 + c4;
+          if (m < p.M && n < p.CN) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * STAGE_LD + c4]);
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.aux) {
+              const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.ldaux + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= vr_gelu_grad(a[e]);
+            }
+            if (p.ypre) *reinterpret_cast<f32x4*>(p.ypre + (long)m * p.ldypre + n) = v;
+            if (p.act == 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.act == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = vr_gelu(v[e]);
+            }
+            if (p.res) {
+              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (long)m * p.ldres + n);
+              if (p.res_scale) v = rv + *reinterpret_cast<const f32x4*>(p.res_scale + n) * v;
+              else v = rv + v;
+            }
+            f32x4* dst = reinterpret_cast<f32x4*>(p.y + (long)m * p.ldy + n);
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+    if (n >= p.CN) continue;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const float rsc = (p.res && p.res_scale) ? p.res_scale[n] : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bias;
+        if (p.aux) v *= vr_gelu_grad(p.aux[(long)m * p.ldaux + n]);
+        if (p.ypre) p.ypre[(long)m * p.ldypre + n] = v;
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        else if (p.act == 2) v = vr_gelu(v);
+        if (p.res) v = p.res[(long)m * p.ldres + n] + rsc * v;
+        float* dst;
+        if (p.out_nchw) {
+          const long b = m / hw, pix = m - b * hw;
+          dst = p.y + ((b * p.out_ctot + p.out_coff + n) * hw + pix);
+        } else {
+          dst = p.y + (long)m * p.ldy + n;
+        }
+        if (p.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int BK, int TM, int TN, int WM, int WN, int MODE, bool VEC>
 __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && BK == 16) ? 8 : 1) void igemm_kernel(const IgemmArgs p) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
@@ -269,88 +360,218 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && BK == 16) ? 8 : 1) vo
     __syncthreads();
   }
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const long hw = (long)p.MH * p.MW;
-  if (p.e_vec) {
-    // Row-contiguous float4 epilogue: each wave transposes one 32x32 accumulator tile through its private
-    // LDS staging tile, then 8 lanes cover one 128-byte output row segment (aux / residual loads and all
-    // stores are whole lines).  The main loop ended with a barrier, so the operand images can be reused.
-    float* stage = smem + wave * (32 * STAGE_LD);
+  igemm_epilogue<TM, TN, WM, WN>(p, acc, smem, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the same implicit GEMM (64 x 64 x 32 tile, 4 waves, one 32x32 accumulator per wave) for
+// the vector-aligned layers (all of the backbone / neck 1x1 and kxk convs): operand tiles go global -> LDS by
+// `global_load_lds_dwordx4` into a ring of NST stage buffers with NST-1 stages in flight across the (raw) barrier
+// of each K step, so a workgroup keeps 2 x 16 KB of loads outstanding without spending a register on them; the
+// register-staged kernel above has one 8 KB tile in flight and needs ~8 workgroups per CU to cover HBM latency,
+// which the small-M layers (M = 2048 / 8192 pixels: <= 3 waves per SIMD over the whole chip) never reach.
+//   * K-contiguous operands (A always; B = w[n][k] in mode 0) are stored as rows of 8 quads (32 floats, one
+//     128-B line), slot (r, q ^ ((r >> 1) & 7)): the XOR is applied to the per-lane SOURCE address (the DMA's LDS
+//     destination is lane-linear) and again on the read, which makes every fragment ds_read_b128 conflict-free.
+//     Lane (row, h) owns k = 16 h .. 16 h + 15 of the 32-deep stage; MFMA step i contracts k = i and k = 16 + i.
+//   * mode 1's B = w[k][c] (contraction-major rows, contiguous output channels) is stored linearly as [32][64]
+//     and read with conflict-free ds_read_b32; kscale (layer scale) is applied to those fragments from an LDS copy.
+//   * out-of-range rows / taps / channel quads read a zero page instead of being masked (a masked DMA lane would
+//     leave stale LDS behind).
+//   * workgroup -> tile map: the NT column tiles of one row tile are consecutive on ONE XCD (ids b, b + 8, ...
+//     share an XCD), so the A rows are fetched into a single L2 once.
+__device__ __attribute__((aligned(128))) float vr_zero_page[64];
+
+template <int MODE, int NST>
+__global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p, int MT, int NT) {
+  constexpr int BM = 64, BN = 64, BK = 32;
+  constexpr int A_FLOATS = BM * BK, ST_FLOATS = A_FLOATS + BN * BK;
+  constexpr int RING = NST * ST_FLOATS;
+  constexpr int KS_MAX = 1024;                      // kscale copy (mode 1)
+  static_assert(RING >= 4 * 32 * STAGE_LD, "epilogue staging must fit the ring");
+  // one LDS object only: a second __shared__ beside a DMA staging array makes hipcc drain vmcnt before ds_reads
+  __shared__ __attribute__((aligned(16))) float smem[RING + 16 + (MODE == 1 ? KS_MAX : 0)];
+  unsigned* tapmask_s = reinterpret_cast<unsigned*>(smem + RING);
+  unsigned char* taps_s = reinterpret_cast<unsigned char*>(smem + RING + 4);     // 32 bytes
+  float* ks_s = smem + RING + 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int L = blockIdx.x, jj = L >> 3;
+  const int nt = jj % NT, mt = (jj / NT) * 8 + (L & 7);
+  if (mt >= MT) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nkb = (p.CK + BK - 1) / BK;
+  const int T = p.kh * p.kw;
+
+  // ---- loader roles: two 16-B slots of the A image and two of the B image per thread and stage
+  int a_q[2], a_b[2], a_y[2], a_x[2];
+  bool a_ok[2];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < 2; ++i) {
+    const int sl = (wave * 2 + i) * 64 + lane, r = sl >> 3;
+    a_q[i] = (sl & 7) ^ ((r >> 1) & 7);
+    const int m = m0 + r;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    a_x[i] = mm % p.MW;
+    const int q = mm / p.MW;
+    a_y[i] = q % p.MH;
+    a_b[i] = q / p.MH;
+  }
+  auto src_of = [&](int i, int ky, int kx, int& sy, int& sx) -> bool {
+    bool ok = a_ok[i];
+    if (MODE == 0) {
+      sy = a_y[i] * p.stride - p.pad + ky * p.dil;
+      sx = a_x[i] * p.stride - p.pad + kx * p.dil;
+    } else {
+      const int ty = a_y[i] + p.pad - ky * p.dil, tx = a_x[i] + p.pad - kx * p.dil;
+      ok = ok && ty >= 0 && tx >= 0 && (ty % p.stride) == 0 && (tx % p.stride) == 0;
+      sy = ty / p.stride;
+      sx = tx / p.stride;
+    }
+    return ok && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
+  };
+  int ntaps = T;
+  const bool use_list = T > 1 && T <= 32;
+  if (use_list) {      // block-uniform list of the taps that are live for at least one row of this tile
+    if (tid == 0) *tapmask_s = 0u;
+    __syncthreads();
+    unsigned mine = 0u;
+    for (int t = 0; t < T; ++t) {
+      const int ky = t / p.kw, kx = t - ky * p.kw;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * STAGE_LD + (lane & 31)] = acc[i][j][r];
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int q = lane + 64 * t;
-          const int row = q >> 3, c4 = (q & 7) * 4;
-          const int m = m0 + wm * TM * 32 + i * 32 + row;
-          const int n = n0 + wn * TN * 32 + j * 32 + c4;
-          if (m < p.M && n < p.CN) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * STAGE_LD + c4]);
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.aux) {
-              const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.ldaux + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] *= vr_gelu_grad(a[e]);
-            }
-            if (p.ypre) *reinterpret_cast<f32x4*>(p.ypre + (long)m * p.ldypre + n) = v;
-            if (p.act == 1) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (p.act == 2) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = vr_gelu(v[e]);
-            }
-            if (p.res) {
-              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (long)m * p.ldres + n);
-              if (p.res_scale) v = rv + *reinterpret_cast<const f32x4*>(p.res_scale + n) * v;
-              else v = rv + v;
-            }
-            f32x4* dst = reinterpret_cast<f32x4*>(p.y + (long)m * p.ldy + n);
-            if (p.accumulate) v += *dst;
-            *dst = v;
-          }
-        }
-        __syncthreads();
+      for (int i = 0; i < 2; ++i) {
+        int sy, sx;
+        if (src_of(i, ky, kx, sy, sx)) mine |= 1u << t;
       }
     }
-    return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine |= (unsigned)__shfl_xor((int)mine, o, 64);
+    if (lane == 0 && mine) atomicOr(tapmask_s, mine);
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned mk = *tapmask_s;
+      int c = 0;
+      for (int t = 0; t < T; ++t)
+        if (mk & (1u << t)) taps_s[c++] = (unsigned char)t;
+    }
+    __syncthreads();
+    ntaps = __popc(*tapmask_s);
   }
+  if (MODE == 1 && p.kscale) {
+    for (int i = tid; i < p.CK; i += 256) ks_s[i] = p.kscale[i];
+    __syncthreads();     // ordinary loads retire here, before the first DMA is issued
+  }
+  const int nsteps = ntaps * nkb;
+
+  const float* a_ptr[2];
+  const float* b_ptr[2];
+  int b_k[2];
+  auto setup_tap = [&](int t) {
+    const int ky = t / p.kw, kx = t - ky * p.kw;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-    if (n >= p.CN) continue;
-    const float bias = p.bias ? p.bias[n] : 0.f;
-    const float rsc = (p.res && p.res_scale) ? p.res_scale[n] : 1.f;
+    for (int i = 0; i < 2; ++i) {
+      int sy, sx;
+      const bool ok = src_of(i, ky, kx, sy, sx);
+      a_ptr[i] = ok ? p.a + ((long)(a_b[i] * p.SH + sy) * p.SW + sx) * p.lda + 4 * a_q[i] : nullptr;
+    }
+    const float* wt = p.w + (long)t * p.wtap;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bias;
-        if (p.aux) v *= vr_gelu_grad(p.aux[(long)m * p.ldaux + n]);
-        if (p.ypre) p.ypre[(long)m * p.ldypre + n] = v;
-        if (p.act == 1) v = fmaxf(v, 0.f);
-        else if (p.act == 2) v = vr_gelu(v);
-        if (p.res) v = p.res[(long)m * p.ldres + n] + rsc * v;
-        float* dst;
-        if (p.out_nchw) {
-          const long b = m / hw, pix = m - b * hw;
-          dst = p.y + ((b * p.out_ctot + p.out_coff + n) * hw + pix);
-        } else {
-          dst = p.y + (long)m * p.ldy + n;
-        }
-        if (p.accumulate) v += *dst;
-        *dst = v;
+    for (int i = 0; i < 2; ++i) {
+      const int sl = (wave * 2 + i) * 64 + lane;
+      if (MODE == 0) {           // rows n, contiguous contraction: same image as A
+        const int r = sl >> 3, q = (sl & 7) ^ ((r >> 1) & 7);
+        b_ptr[i] = (n0 + r < p.CN) ? wt + (long)(n0 + r) * p.Cin + 4 * q : nullptr;
+        b_k[i] = 4 * q;
+      } else {                   // rows = contraction index, contiguous output channels: linear [32][64]
+        const int kr = sl >> 4, col = n0 + 4 * (sl & 15);
+        b_ptr[i] = (col < p.CN) ? wt + (long)kr * p.Cin + col : nullptr;
+        b_k[i] = kr;
       }
     }
+  };
+
+  int ld_ti = 0, ld_kb = 0, ld_buf = 0;       // (tap index, k block, ring slot) of the NEXT stage to issue
+  auto issue = [&]() {
+    if (ld_kb == 0) setup_tap(use_list ? (int)taps_s[ld_ti] : ld_ti);
+    const int c0 = ld_kb * BK;
+    float* stage = smem + ld_buf * ST_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* src = (a_ptr[i] != nullptr && c0 + 4 * a_q[i] < p.CK) ? a_ptr[i] + c0 : vr_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + (wave * 2 + i) * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* src;
+      if (MODE == 0) src = (b_ptr[i] != nullptr && c0 + b_k[i] < p.CK) ? b_ptr[i] + c0 : vr_zero_page;
+      else src = (b_ptr[i] != nullptr && c0 + b_k[i] < p.CK) ? b_ptr[i] + (long)c0 * p.Cin : vr_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + A_FLOATS + (wave * 2 + i) * 256),
+                                       16, 0, 0);
+    }
+    if (++ld_kb == nkb) {
+      ld_kb = 0;
+      ++ld_ti;
+    }
+    if (++ld_buf == NST) ld_buf = 0;
+  };
+
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  const int h = lane >> 5;
+  const int ra = wm * 32 + (lane & 31), rb = wn * 32 + (lane & 31);
+  const int a_off = ra * 32, a_swz = (ra >> 1) & 7;
+  const int b_off = MODE == 0 ? rb * 32 : rb, b_swz = (rb >> 1) & 7;
+
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < nsteps) issue();
+  int cur = 0, kb = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    // stage s has landed once at most the (NST - 2) younger stages (4 DMAs each) are still outstanding
+    if (NST == 3) {
+      if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + NST - 1 < nsteps) issue();      // into the slot every wave finished reading before this barrier
+    const float* As = smem + cur * ST_FLOATS;
+    const float* Bs = As + A_FLOATS;
+    f32x4 af[4], bq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(As + a_off + 4 * ((4 * h + j) ^ a_swz));
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const f32x4*>(Bs + b_off + 4 * ((4 * h + j) ^ b_swz));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[j][e] = Bs[(16 * h + 4 * j + e) * 64 + b_off];
+      if (p.kscale) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = kb * BK + 16 * h + 4 * j;     // CK % 4 == 0: a quad is inside the stash or all-zero data
+          if (k < p.CK) bq[j] *= *reinterpret_cast<const f32x4*>(ks_s + k);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], bq[j][e], acc[0][0], 0, 0, 0);
+    if (++cur == NST) cur = 0;
+    if (++kb == nkb) kb = 0;
   }
+  __syncthreads();
+  igemm_epilogue<1, 1, 2, 2>(p, acc, smem, m0, n0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -513,25 +734,131 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64) ? 8 : 1) void wgrad_ker
   if (do_bias && tid < BM && n0 + tid < p.Cout) p.bslab[(long)split * p.Cout + n0 + tid] = bsum;
 }
 
+// LDS-DMA variant of the weight gradient (64 x 64 tile of dW, 32 contraction rows per stage, ring of 3 stages with
+// two in flight): both operand tiles are [32 rows m][64 channels] images, lane-linear, read by conflict-free
+// ds_read_b32 (lanes = consecutive channels).  The split-over-rows grids of the small weight matrices put only
+// 1-3 workgroups on a CU, which the one-tile-in-flight kernel above cannot turn into HBM bandwidth.
+template <bool IDENT>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradArgs p) {
+  constexpr int BKD = 32, NST = 3, T_FLOATS = BKD * 64, ST_FLOATS = 2 * T_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[NST * ST_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bid = blockIdx.x;
+  const int ct = bid % p.c_tiles; bid /= p.c_tiles;
+  const int nt = bid % p.n_tiles; bid /= p.n_tiles;
+  const int t = bid;
+  const int ky = t / p.kw, kx = t - ky * p.kw;
+  const int n0 = nt * 64, c0 = ct * 64;
+  const int split = blockIdx.y;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const bool do_bias = p.bslab != nullptr && ct == 0 && t == 0;
+  float bsum = 0.f;
+  int s_kr[2], s_cq[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int sl = (wave * 2 + i) * 64 + lane;
+    s_kr[i] = sl >> 4;
+    s_cq[i] = 4 * (sl & 15);
+  }
+  int ld_m = m_begin, ld_buf = 0;
+  auto issue = [&]() {
+    float* stage = smem + ld_buf * ST_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = ld_m + s_kr[i];
+      const float* src = (m < m_end && n0 + s_cq[i] < p.Cout) ? p.dy + (long)m * p.lddy + n0 + s_cq[i] : vr_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + (wave * 2 + i) * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = ld_m + s_kr[i];
+      const float* src = vr_zero_page;
+      if (m < m_end && c0 + s_cq[i] < p.Cin) {
+        if (IDENT) {
+          src = p.x + (long)m * p.ldx + c0 + s_cq[i];
+        } else {
+          const int ox = m % p.OW;
+          const int q = m / p.OW;
+          const int oy = q % p.OH, b = q / p.OH;
+          const int sy = oy * p.stride - p.pad + ky * p.dil, sx = ox * p.stride - p.pad + kx * p.dil;
+          if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
+            src = p.x + ((long)(b * p.H + sy) * p.W + sx) * p.ldx + c0 + s_cq[i];
+        }
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + T_FLOATS + (wave * 2 + i) * 256),
+                                       16, 0, 0);
+    }
+    ld_m += BKD;
+    if (++ld_buf == NST) ld_buf = 0;
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int h = lane >> 5;
+  const int arow = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31);
+  const int nsteps = (m_end - m_begin + BKD - 1) / BKD;
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < nsteps) issue();
+  int cur = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + NST - 1 < nsteps) issue();
+    const float* As = smem + cur * ST_FLOATS;
+    const float* Bs = As + T_FLOATS;
+    if (do_bias && tid < 64) {
+#pragma unroll
+      for (int k = 0; k < BKD; ++k) bsum += As[k * 64 + tid];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float af = As[(16 * h + i) * 64 + arow], bf = Bs[(16 * h + i) * 64 + bcol];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+    }
+    if (++cur == NST) cur = 0;
+  }
+  const long T = (long)p.kh * p.kw;
+  float* slab = p.slab + ((long)split * T + t) * p.Cout * p.Cin;
+  const int c = c0 + bcol;
+  if (c < p.Cin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (n < p.Cout) slab[(long)n * p.Cin + c] = acc[r];
+    }
+  }
+  if (do_bias && tid < 64 && n0 + tid < p.Cout) p.bslab[(long)split * p.Cout + n0 + tid] = bsum;
+}
+
 // dw (OIHW) = row_scale[n] * sum_s slab[s][t][n][c] (+ dw);  db[n] = row_scale[n] * sum_s bslab[s][n] (+ db)
-template <int VEC>
+// SL lanes share one output (quad): lane sl sums slabs sl, sl + SL, ...; the SL partials are then added in lane
+// order through LDS (fixed order: deterministic).  Small weight matrices are split over up to 256 row ranges, and
+// a one-thread-per-output loop over that many slabs is a serial chain of dependent-latency loads.
+template <int VEC, int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, const float* bslab, const float* row_scale,
                                                            float* dw, float* db, int S, int T, int Cout, int Cin,
                                                            int accumulate) {
+  constexpr int OUTS = 256 / SL;
+  __shared__ float red[SL][OUTS][VEC];
   const long per = (long)T * Cout * Cin;
   const long nq = per / VEC;
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < nq) {
-    const long idx = e * VEC;
-    const int c = idx % Cin;
-    const long q = idx / Cin;
-    const int n = q % Cout;
-    const int t = q / Cout;
-    float s[VEC];
+  const int o = threadIdx.x % OUTS, sl = threadIdx.x / OUTS;
+  const long e = (long)blockIdx.x * OUTS + o;
+  const long idx = e * VEC;
+  float s[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+  for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+  if (e < nq) {
 #pragma unroll 4
-    for (int k = 0; k < S; ++k) {
+    for (int k = sl; k < S; k += SL) {
       if (VEC == 4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(slab + (long)k * per + idx);
 #pragma unroll
@@ -540,6 +867,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, co
         s[0] += slab[(long)k * per + idx];
       }
     }
+  } else if (db && e < nq + Cout) {
+    for (int k = sl; k < S; k += SL) s[0] += bslab[(long)k * Cout + (e - nq)];
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[sl][o][j] = s[j];
+  __syncthreads();
+  if (sl != 0) return;
+#pragma unroll
+  for (int k = 1; k < SL; ++k)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] += red[k][o][j];
+  if (e < nq) {
+    const int c = idx % Cin;
+    const long q = idx / Cin;
+    const int n = q % Cout;
+    const int t = q / Cout;
     const float rs = row_scale ? row_scale[n] : 1.f;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -549,14 +892,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, co
     }
   } else if (db && e < nq + Cout) {
     const int n = e - nq;
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += bslab[(long)k * Cout + n];
-    if (row_scale) s *= row_scale[n];
-    db[n] = accumulate ? db[n] + s : s;
+    float v = s[0];
+    if (row_scale) v *= row_scale[n];
+    db[n] = accumulate ? db[n] + v : v;
   }
 }
 
-// OIHW -> [T][Cout][Cin]
 __global__ void pack_weight_kernel(const float* w, float* out, int Cout, int Cin, int T) {
   const long total = (long)T * Cout * Cin;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -656,6 +997,20 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   // (7 workgroups per CU) beat 128 x 128 (2 per CU) and 128 x 64 on 90 % of the shapes -- 21.4 vs 30.7 / 25.9 ms
   // per step over all forward + data-gradient launches; the exceptions are within 10 %.
   (void)blocks128;
+  static const int use_dma = getenv("VRNET_IGEMM_DMA") ? atoi(getenv("VRNET_IGEMM_DMA")) : 1;   // tuning aid
+  // Measured per shape (bench.py --detail): the DMA ring wins where the grid cannot fill the chip with 8 workgroups
+  // per CU (M <= 8192 pixels: +5..40 %) and on long contractions; the register-staged kernel keeps the large-M,
+  // short-K layers (2048 row tiles x few K steps: its 8 workgroups per CU hide the store-heavy epilogues better).
+  const long ktot = (long)p.CK * kh * kw;
+  const bool dma_shape = use_dma == 2 || M <= 8192 || (M <= 32768 && ktot >= 1024);
+  if (use_dma && dma_shape && force_cfg < 0 && vec && p.CN > 32 && (!kscale || p.CK <= 1024)) {
+    const int MT = (int)vr_cdiv(M, 64), NT = (int)vr_cdiv(p.CN, 64);
+    dim3 grid((unsigned)(8 * vr_cdiv(MT, 8) * NT));
+    if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3>), grid, block, 0, st, p, MT, NT);
+    else hipLaunchKernelGGL((igemm_dma_kernel<1, 3>), grid, block, 0, st, p, MT, NT);
+    VR_LAUNCH_CHECK("conv2d");
+    return VR_OK;
+  }
   int cfg = p.CN > 32 ? 2 : 3;
   if (force_cfg >= 0 && p.CN > 32) cfg = (force_cfg == 0 && p.CN <= 64) ? 1 : force_cfg;
   if (cfg == 2) {
@@ -710,7 +1065,7 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
     *cfg = 1; *bn = 64;
     *n_tiles = (int)vr_cdiv(Cout, 64); *c_tiles = (int)vr_cdiv(Cin, 64);
     const long s = splits(tiles64);
-    const long r = vr_cdiv(vr_cdiv(M, s), BK) * BK;
+    const long r = vr_cdiv(vr_cdiv(M, s), 32) * 32;     // 32: contraction rows per stage of the DMA kernel
     *rows = (int)r; *S = (int)vr_cdiv(M, r);
   } else {
     *cfg = 0; *bn = bn128;
@@ -767,7 +1122,13 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
     else if (vec) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, TM_, TN_, WM_, WN_, false, true>), grid, block, 0, st, p);     \
     else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, TM_, TN_, WM_, WN_, false, false>), grid, block, 0, st, p);             \
   } while (0)
-  if (cfg == 1) VR_WGRAD(64, 64, 1, 1, 2, 2);
+  static const int use_dma = getenv("VRNET_WGRAD_DMA") ? atoi(getenv("VRNET_WGRAD_DMA")) : 1;   // tuning aid
+  // measured (bench.py --detail): the ring wins only for the smallest weight matrices (<= 4 tiles: +5..19 %); with
+  // more tiles the row-split grid already fills the chip and the 8-workgroups-per-CU kernel is 5-15 % faster
+  if (cfg == 1 && vec && (use_dma == 2 || (use_dma && nt * ct * T <= 4))) {
+    if (ident) hipLaunchKernelGGL((wgrad_dma_kernel<true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((wgrad_dma_kernel<false>), grid, block, 0, st, p);
+  } else if (cfg == 1) VR_WGRAD(64, 64, 1, 1, 2, 2);
   else if (bn == 128) VR_WGRAD(128, 128, 2, 2, 2, 2);
   else if (bn == 64) VR_WGRAD(128, 64, 2, 1, 2, 2);
   else VR_WGRAD(128, 32, 1, 1, 4, 1);
@@ -775,12 +1136,17 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   VR_LAUNCH_CHECK("conv2d_wgrad");
   const bool rvec = (Cin % 4 == 0);                 // slabs are 16-byte aligned (workspace arena), rows of Cin floats
   const long total = (long)T * Cout * Cin / (rvec ? 4 : 1) + (dbias ? Cout : 0);
-  if (rvec)
-    hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3(vr_cdiv(total, 256)), dim3(256), 0, st, p.slab, p.bslab, row_scale,
-                       dw, dbias, S, T, Cout, Cin, accumulate);
-  else
-    hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(vr_cdiv(total, 256)), dim3(256), 0, st, p.slab, p.bslab, row_scale,
-                       dw, dbias, S, T, Cout, Cin, accumulate);
+#define VR_WREDUCE(VEC_, SL_)                                                                                        \
+  hipLaunchKernelGGL((wgrad_reduce_kernel<VEC_, SL_>), dim3(vr_cdiv(total, 256 / SL_)), dim3(256), 0, st, p.slab, p.bslab, \
+                     row_scale, dw, dbias, S, T, Cout, Cin, accumulate)
+  if (rvec) {
+    if (S > 8) VR_WREDUCE(4, 16);
+    else VR_WREDUCE(4, 4);
+  } else {
+    if (S > 8) VR_WREDUCE(1, 16);
+    else VR_WREDUCE(1, 4);
+  }
+#undef VR_WREDUCE
   VR_LAUNCH_CHECK("conv2d_wgrad_reduce");
   return VR_OK;
 }
