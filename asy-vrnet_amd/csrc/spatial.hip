@@ -82,12 +82,77 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* x, lo
     for (int t = 0; t < 9; ++t) partial[((long)blockIdx.x * C + c) * 9 + t] = acc[t];
   }
 }
-__global__ void dwconv3x3_wgrad_reduce_kernel(const float* partial, int nchunks, int C, float* dw, int accumulate) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= C * 9) return;
+// 16 lanes per output, chunks strided over the lanes, partials added in lane order through LDS (deterministic)
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_reduce_kernel(const float* partial, int nchunks, int C, float* dw,
+                                                                     int accumulate) {
+  __shared__ double red[16][16];
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + o;
+  const bool live = e < C * 9;
   double s = 0;
-  for (int k = 0; k < nchunks; ++k) s += partial[(long)k * C * 9 + e];
-  dw[e] = (accumulate ? dw[e] : 0.f) + (float)s;
+  if (live)
+    for (int k = sl; k < nchunks; k += 16) s += partial[(long)k * C * 9 + e];
+  red[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && live) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][o];
+    dw[e] = (accumulate ? dw[e] : 0.f) + (float)s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ patch embedding
+// Non-overlapping k x k / stride-k patch embedding (PointRecuder k4 s4, vr_coc.py:83-102, fed by
+// cat([x, fea_pos]) :583-586) as gather + plain GEMM: P[b, oy, ox, (ky*k + kx)*CT + c] = cat(x, pos)[b, oy*k+ky,
+// ox*k+kx, c], CT = C + CP.  The concat never materialises; the 1x1 conv over P (weights in OHWI order) then runs
+// on the vector path of the implicit GEMM with K = k*k*CT, instead of gathering 5- / 6-channel rows per tap.
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* x, long ldx, const float* pos, float* out, int B,
+                                                           int H, int W, int C, int CP, int k) {
+  const int CT = C + CP, KT = k * k * CT, OH = H / k, OW = W / k;
+  const long total = (long)B * OH * OW * KT;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int ch = e % KT;
+    const long op = e / KT;
+    const int t = ch / CT, c = ch - t * CT;
+    const int ky = t / k, kx = t - ky * k;
+    const int ox = op % OW;
+    const long q = op / OW;
+    const int oy = q % OH;
+    const long b = q / OH;
+    const int yy = oy * k + ky, xx = ox * k + kx;
+    out[e] = c < C ? x[((b * H + yy) * W + xx) * ldx + c] : pos[((long)yy * W + xx) * CP + (c - C)];
+  }
+}
+// adjoint w.r.t. x: dx[b, y, x, c] (+)= dP[b, y/k, x/k, ((y%k)*k + x%k)*CT + c], c < C
+__global__ __launch_bounds__(256) void patch_scatter_kernel(const float* dp, float* dx, long lddx, int B, int H, int W, int C,
+                                                            int CP, int k, int accumulate) {
+  const int CT = C + CP, KT = k * k * CT, OH = H / k, OW = W / k;
+  const long total = (long)B * H * W * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = e % C;
+    const long pix = e / C;
+    const int xx = pix % W;
+    const long q = pix / W;
+    const int yy = q % H;
+    const long b = q / H;
+    const int t = (yy % k) * k + (xx % k);
+    const float v = dp[((b * OH + yy / k) * OW + xx / k) * KT + t * CT + c];
+    float* d = dx + pix * lddx + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+// weights OIHW [n][c][t] -> OHWI [n][t][c] (dir 0), and the gradient back, OHWI -> OIHW (+)= (dir 1)
+__global__ void ohwi_kernel(const float* src, float* dst, int Cout, int Cin, int T, int dir, int accumulate) {
+  const long total = (long)Cout * Cin * T;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int t = e % T;
+  const long q = e / T;
+  const int c = q % Cin;
+  const long n = q / Cin;
+  const long oihw = e, ohwi = (n * T + t) * Cin + c;
+  if (dir == 0) dst[ohwi] = src[oihw];
+  else dst[oihw] = (accumulate ? dst[oihw] : 0.f) + src[ohwi];
 }
 
 // ------------------------------------------------------------------------------------------ bilinear upsample
@@ -356,13 +421,23 @@ __global__ __launch_bounds__(256) void sa_bwd_reduce_kernel(const float* dy, lon
     partial[((b * nchunks + chunk) * C + q) * 2 + 1] = t2;
   }
 }
-__global__ void sa_reduce_chunks_kernel(const double* partial, double* out, int B, int nchunks, int C) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (long)B * C * 2) return;
-  const long b = e / (2L * C), rem = e - b * 2L * C;
+__global__ __launch_bounds__(256) void sa_reduce_chunks_kernel(const double* partial, double* out, int B, int nchunks, int C) {
+  __shared__ double red[16][16];
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long e = (long)blockIdx.x * 16 + o;
+  const bool live = e < (long)B * C * 2;
   double s = 0.0;
-  for (int k = 0; k < nchunks; ++k) s += partial[((long)b * nchunks + k) * C * 2 + rem];
-  out[e] = s;
+  if (live) {
+    const long b = e / (2L * C), rem = e - b * 2L * C;
+    for (int k = sl; k < nchunks; k += 16) s += partial[((long)b * nchunks + k) * C * 2 + rem];
+  }
+  red[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && live) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][o];
+    out[e] = s;
+  }
 }
 
 // blocks [0, nb1): E,F per (b,q);  block nb1: parameter gradients (one thread per (half, i))
@@ -505,7 +580,7 @@ extern "C" int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* 
   hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(nchunks, vr_cdiv(C, TPR)), dim3(256), 0, st, x, ldx, dy, lddy, B, H, W,
                      C, ppc, partial);
   VR_LAUNCH_CHECK("dwconv3x3_wgrad");
-  hipLaunchKernelGGL(dwconv3x3_wgrad_reduce_kernel, dim3(vr_cdiv(C * 9, 256)), dim3(256), 0, st, partial, nchunks, C, dw,
+  hipLaunchKernelGGL(dwconv3x3_wgrad_reduce_kernel, dim3(vr_cdiv(C * 9, 16)), dim3(256), 0, st, partial, nchunks, C, dw,
                      accumulate);
   VR_LAUNCH_CHECK("dwconv3x3_wgrad_reduce");
   return VR_OK;
@@ -614,7 +689,7 @@ extern "C" int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long
   hipLaunchKernelGGL(sa_bwd_reduce_kernel, dim3(nchunks, B, ncb), dim3(256), 256 * 2 * sizeof(double), st, dy, lddy, x,
                      ldx, P, Q, Mn, HW, C, TPR, rows, nchunks, partial);
   VR_LAUNCH_CHECK("sa_bwd_reduce");
-  hipLaunchKernelGGL(sa_reduce_chunks_kernel, dim3(vr_cdiv((long)B * C * 2, 256)), dim3(256), 0, st, partial, T, B,
+  hipLaunchKernelGGL(sa_reduce_chunks_kernel, dim3(vr_cdiv((long)B * C * 2, 16)), dim3(256), 0, st, partial, T, B,
                      nchunks, C);
   VR_LAUNCH_CHECK("sa_reduce_chunks");
   SaParams sp{cw, cb, sw, sb, gnw, gnb};
@@ -627,5 +702,35 @@ extern "C" int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long
   hipLaunchKernelGGL(sa_bwd_apply_kernel, dim3(grid_for(HW * C), B), dim3(256), 0, st, dy, lddy, x, ldx, P, Q, Mn, E, F, dx,
                      lddx, HW, C, accumulate_dx);
   VR_LAUNCH_CHECK("sa_bwd_apply");
+  return VR_OK;
+}
+
+extern "C" int vrnet_patch_gather_f32(const float* x, long ldx, const float* pos, float* out, int B, int H, int W, int C,
+                                      int CP, int k, void* stream) {
+  VR_CHECK_ARG(x && out && (CP == 0 || pos) && B > 0 && C > 0 && CP >= 0 && k > 0 && H % k == 0 && W % k == 0 && ldx >= C,
+               "patch_gather: bad arguments");
+  hipLaunchKernelGGL(patch_gather_kernel, dim3(grid_for((long)B * H * W * (C + CP))), dim3(256), 0, vr_stream(stream), x,
+                     ldx, pos, out, B, H, W, C, CP, k);
+  VR_LAUNCH_CHECK("patch_gather");
+  return VR_OK;
+}
+
+extern "C" int vrnet_patch_scatter_f32(const float* dp, float* dx, long lddx, int B, int H, int W, int C, int CP, int k,
+                                       int accumulate, void* stream) {
+  VR_CHECK_ARG(dp && dx && B > 0 && C > 0 && CP >= 0 && k > 0 && H % k == 0 && W % k == 0 && lddx >= C,
+               "patch_scatter: bad arguments");
+  hipLaunchKernelGGL(patch_scatter_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, vr_stream(stream), dp, dx,
+                     lddx, B, H, W, C, CP, k, accumulate);
+  VR_LAUNCH_CHECK("patch_scatter");
+  return VR_OK;
+}
+
+extern "C" int vrnet_weight_ohwi_f32(const float* src, float* dst, int Cout, int Cin, int kh, int kw, int dir,
+                                     int accumulate, void* stream) {
+  VR_CHECK_ARG(src && dst && Cout > 0 && Cin > 0 && kh > 0 && kw > 0 && (dir == 0 || dir == 1), "weight_ohwi: bad arguments");
+  const long total = (long)Cout * Cin * kh * kw;
+  hipLaunchKernelGGL(ohwi_kernel, dim3(vr_cdiv(total, 256)), dim3(256), 0, vr_stream(stream), src, dst, Cout, Cin, kh * kw,
+                     dir, accumulate);
+  VR_LAUNCH_CHECK("weight_ohwi");
   return VR_OK;
 }

@@ -83,13 +83,26 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, 
   }
 }
 
-__global__ void moments_reduce_kernel(const double* partial, double* out, int B, int nchunks, int C) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*C*2
-  if (e >= (long)B * C * 2) return;
-  const long b = e / (2L * C), rem = e - b * 2L * C;
+// out[b][c][w] = sum_k partial[b][k][c][w].  16 lanes share one output (lane l adds chunks l, l + 16, ...; the 16
+// partial sums are then added in lane order through LDS: fixed order, deterministic) -- a one-thread-per-output
+// loop over up to 512 chunks is a serial chain of dependent-latency loads on the critical path of every norm.
+__global__ __launch_bounds__(256) void moments_reduce_kernel(const double* partial, double* out, int B, int nchunks, int C) {
+  __shared__ double red[16][16];
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long e = (long)blockIdx.x * 16 + o;   // over B*C*2
+  const bool live = e < (long)B * C * 2;
   double s = 0.0;
-  for (int k = 0; k < nchunks; ++k) s += partial[((long)b * nchunks + k) * C * 2 + rem];
-  out[e] = s;
+  if (live) {
+    const long b = e / (2L * C), rem = e - b * 2L * C;
+    for (int k = sl; k < nchunks; k += 16) s += partial[((long)b * nchunks + k) * C * 2 + rem];
+  }
+  red[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && live) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][o];
+    out[e] = s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ affine
@@ -476,7 +489,7 @@ extern "C" int vrnet_moments_f32(const float* x, long ldx, const float* x2, long
                        TPR, rows, nchunks, partial);
   VR_LAUNCH_CHECK("moments");
   const long n = (long)B * C * 2;
-  hipLaunchKernelGGL(moments_reduce_kernel, dim3(vr_cdiv(n, 256)), dim3(256), 0, st, partial, out, B, nchunks, C);
+  hipLaunchKernelGGL(moments_reduce_kernel, dim3(vr_cdiv(n, 16)), dim3(256), 0, st, partial, out, B, nchunks, C);
   VR_LAUNCH_CHECK("moments_reduce");
   return VR_OK;
 }

@@ -63,19 +63,24 @@ __global__ __launch_bounds__(256) void conv_kernel(const Args p) {
   }
 }
 
-// partial[blk][n][Cin*T + 1]: sum over this block's pixels of dy[pix][n] * x[pix + off_t][c], last = sum dy (bias)
+// partial[blk][n][Cin*T + 1]: sum over this block's pixels of dy[pix][n] * x[pix + off_t][c], last = sum dy (bias).
+// CP = channel count padded to 4 / 8, KS = 1 / 3 (compile-time: the accumulators stay in registers and the tap
+// loops unroll); VEC4: Cin == 4 on 16-byte rows -> one float4 load per tap.  Block totals: DPP row sums (4 VALU
+// ops per accumulator) + one LDS hop, instead of a 6-step ds_bpermute butterfly per accumulator.
+template <int CP, int KS>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* x, long ldx, const float* dy, long lddy, int B, int H,
-                                                    int W, int Cin, int Cout, int k, int pad, int dil,
+                                                    int W, int Cin, int Cout, int pad, int dil, int vec4,
                                                     long pix_per_block, float* partial) {
-  __shared__ float red[4][CMAX * 9 + 1];
-  const int n = blockIdx.y, T = k * k;
+  constexpr int T = KS * KS, NA = CP * T + 1;
+  __shared__ float red[16][NA];
+  const int n = blockIdx.y;
   const long total = (long)B * H * W;
   const long p0 = blockIdx.x * pix_per_block, p1 = min(total, p0 + pix_per_block);
-  float acc[CMAX][9], bs = 0.f;
+  float acc[CP][T], bs = 0.f;
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c)
+  for (int c = 0; c < CP; ++c)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    for (int t = 0; t < T; ++t) acc[c][t] = 0.f;
   for (long pix = p0 + threadIdx.x; pix < p1; pix += 256) {
     const int xx = pix % W;
     const long q = pix / W;
@@ -84,54 +89,72 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* x, long ldx, co
     const float g = dy[pix * lddy + n];
     bs += g;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      if (ky >= k) break;
+    for (int ky = 0; ky < KS; ++ky) {
       const int sy = yy + ky * dil - pad;
       if (sy < 0 || sy >= H) continue;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        if (kx >= k) break;
+      for (int kx = 0; kx < KS; ++kx) {
         const int sx = xx + kx * dil - pad;
         if (sx < 0 || sx >= W) continue;
         const float* src = x + ((b * H + sy) * W + sx) * ldx;
+        if (CP == 4 && vec4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c)
-          if (c < Cin) acc[c][ky * 3 + kx] += g * src[c];
+          for (int c = 0; c < 4; ++c) acc[c][ky * KS + kx] += g * v[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < CP; ++c)
+            if (c < Cin) acc[c][ky * KS + kx] += g * src[c];
+        }
       }
     }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto row16 = [](float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+  };
+  const int rowid = threadIdx.x >> 4;
+  const bool lead = (threadIdx.x & 15) == 0;
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c)
+  for (int c = 0; c < CP; ++c)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float s = wave_sum(acc[c][t]);
-      if (lane == 0) red[wave][c * 9 + t] = s;
+    for (int t = 0; t < T; ++t) {
+      const float sum = row16(acc[c][t]);
+      if (lead) red[rowid][c * T + t] = sum;
     }
-  bs = wave_sum(bs);
-  if (lane == 0) red[wave][CMAX * 9] = bs;
+  bs = row16(bs);
+  if (lead) red[rowid][CP * T] = bs;
   __syncthreads();
   float* out = partial + ((long)blockIdx.x * Cout + n) * (Cin * T + 1);
   for (int i = threadIdx.x; i < Cin * T + 1; i += 256) {
-    int src;
-    if (i == Cin * T) src = CMAX * 9;
-    else {
-      const int c = i / T, t = i - c * T;
-      src = c * 9 + (t / k) * 3 + (t % k);
-    }
-    out[i] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
+    const int src = i == Cin * T ? CP * T : i;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += red[r][src];
+    out[i] = sum;
   }
 }
 
-// dw (OIHW) [n][c][t] and db[n]
-__global__ void wgrad_reduce_kernel(const float* partial, int nblk, int Cin, int Cout, int T, const float* row_scale,
-                                    float* dw, float* db, int accumulate) {
+// dw (OIHW) [n][c][t] and db[n]; 16 lanes per output, blocks strided over the lanes, added in lane order via LDS
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int nblk, int Cin, int Cout, int T,
+                                                           const float* row_scale, float* dw, float* db, int accumulate) {
+  __shared__ double red[16][16];
   const int per = Cin * T + 1;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= Cout * per) return;
-  const int n = e / per, i = e - n * per;
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + o;
+  const bool live = e < Cout * per;
+  const int n = live ? e / per : 0, i = e - n * per;
   double s = 0;
-  for (int b = 0; b < nblk; ++b) s += partial[((long)b * Cout + n) * per + i];
+  if (live)
+    for (int b = sl; b < nblk; b += 16) s += partial[((long)b * Cout + n) * per + i];
+  red[sl][o] = s;
+  __syncthreads();
+  if (sl != 0 || !live) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) s += red[k][o];
   float v = (float)s;
   if (row_scale) v *= row_scale[n];
   if (i == Cin * T) {
@@ -191,7 +214,7 @@ int vr_tiny_conv(int mode, const float* a, long lda, const float* w, const float
 }
 
 static void tiny_wgrad_plan(long npix, int* nblk, long* ppb) {
-  long nb = vr_cdiv(npix, 4096);
+  long nb = vr_cdiv(npix, 8192);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   *ppb = vr_cdiv(npix, nb);
@@ -212,11 +235,22 @@ int vr_tiny_wgrad(const float* x, long ldx, const float* dy, long lddy, float* d
   long ppb;
   tiny_wgrad_plan((long)B * H * W, &nblk, &ppb);
   float* partial = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(tiny::wgrad_kernel, dim3(nblk, Cout), dim3(256), 0, st, x, ldx, dy, lddy, B, H, W, Cin, Cout, k, pad,
-                     dil, ppb, partial);
+  const int vec4 = Cin == 4 && ldx % 4 == 0 && vr_aligned16(x);
+  dim3 grid(nblk, Cout), block(256);
+#define VR_TINY_WGRAD(CP_, KS_)                                                                                          \
+  hipLaunchKernelGGL((tiny::wgrad_kernel<CP_, KS_>), grid, block, 0, st, x, ldx, dy, lddy, B, H, W, Cin, Cout, pad, dil, vec4, \
+                     ppb, partial)
+  if (k == 1) {
+    if (Cin <= 4) VR_TINY_WGRAD(4, 1);
+    else VR_TINY_WGRAD(8, 1);
+  } else {
+    if (Cin <= 4) VR_TINY_WGRAD(4, 3);
+    else VR_TINY_WGRAD(8, 3);
+  }
+#undef VR_TINY_WGRAD
   VR_LAUNCH_CHECK("tiny_wgrad");
   const int per = Cin * k * k + 1;
-  hipLaunchKernelGGL(tiny::wgrad_reduce_kernel, dim3(vr_cdiv(Cout * per, 128)), dim3(128), 0, st, partial, nblk, Cin, Cout,
+  hipLaunchKernelGGL(tiny::wgrad_reduce_kernel, dim3(vr_cdiv(Cout * per, 16)), dim3(256), 0, st, partial, nblk, Cin, Cout,
                      k * k, row_scale, dw, db, accumulate);
   VR_LAUNCH_CHECK("tiny_wgrad_reduce");
   return VR_OK;

@@ -41,6 +41,9 @@ _SIGS = {
     "vrnet_ls_coef_bwd": ([P, P, I, I, P, P, I, P], I),
     "vrnet_moments_to_float": ([P, P, L, D, I, P], I),
     "vrnet_copy_channels_f32": ([P, L, I, P, L, I, L, I, I, P], I),
+    "vrnet_patch_gather_f32": ([P, L, P, P, I, I, I, I, I, I, P], I),
+    "vrnet_patch_scatter_f32": ([P, P, L, I, I, I, I, I, I, I, P], I),
+    "vrnet_weight_ohwi_f32": ([P, P, I, I, I, I, I, I, P], I),
     "vrnet_nchw_to_nhwc_f32": ([P, P, L, I, I, L, P], I),
     "vrnet_nhwc_to_nchw_f32": ([P, L, P, I, I, L, I, P], I),
     "vrnet_add_f32": ([P, P, L, P], I),
@@ -196,6 +199,18 @@ def ls_coef_bwd(mom2, ls, B, C, dls, dbias, accumulate):
 
 def moments_to_float(mom, out, n, scale, which=0):
     _check(_lib.vrnet_moments_to_float(ptr(mom), ptr(out), n, scale, which, stream()), "moments_to_float")
+
+
+def patch_gather(x, ldx, pos, out, B, H, W, C, CP, k):
+    _check(_lib.vrnet_patch_gather_f32(ptr(x), ldx, ptr(pos), ptr(out), B, H, W, C, CP, k, stream()), "patch_gather")
+
+
+def patch_scatter(dp, dx, lddx, B, H, W, C, CP, k, accumulate=0):
+    _check(_lib.vrnet_patch_scatter_f32(ptr(dp), ptr(dx), lddx, B, H, W, C, CP, k, accumulate, stream()), "patch_scatter")
+
+
+def weight_ohwi(src, dst, Cout, Cin, kh, kw, direction, accumulate=0):
+    _check(_lib.vrnet_weight_ohwi_f32(ptr(src), ptr(dst), Cout, Cin, kh, kw, direction, accumulate, stream()), "weight_ohwi")
 
 
 def copy_channels(src, lds, scs, dst, ldd, dcs, rows, C, accumulate=0):

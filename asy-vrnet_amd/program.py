@@ -774,21 +774,45 @@ def backbone_forward(rt, bb, x, r):
         raise RuntimeError(f"input {H}x{W} does not match fea_pos {tuple(bb.fea_pos.shape[:2])}: "
                            "construct EfficientVRNet(..., img_size=(H, W))")
     def embed(act, pe):
-        C = act.C
-        cat = rt.new(B, H, W, C + 2)
-        hip.copy_channels(act.t, act.ld, 1, cat.t, C + 2, 1, act.rows, C)
-        for b in range(B):                                         # fea_pos (H,W,2) is already NHWC; :585 uses fea_pos twice
-            hip.copy_channels(bb.fea_pos, 2, 1, cat.t[b, :, :, C:], C + 2, 1, H * W, 2)
+        """cat([x, fea_pos]) -> 4x4/s4 PointRecuder (vr_coc.py:583-586, 99-102) as patch gather + one plain GEMM:
+        the concat is never materialised and the projection runs on the vector path with K = 16*(C+2)."""
+        conv = pe.proj
+        co, ci, kh, kw = conv.weight.shape
+        C, CP, k = act.C, ci - act.C, kh
+        assert kh == kw == conv.stride[0] and conv.padding[0] == 0 and CP == 2 and H % k == 0 and W % k == 0
+        OH, OW, KT = H // k, W // k, k * k * ci
+        patches = rt.new(B, OH, OW, KT)
+        hip.patch_gather(act.t, act.ld, bb.fea_pos, patches.t, B, H, W, C, CP, k)   # :585 uses fea_pos for both streams
+        w2 = rt.buf(co, KT)                                       # OHWI: [n][(ky,kx)][c]
+        hip.weight_ohwi(conv.weight, w2, co, ci, kh, kw, 0)
+        y = rt.new(B, OH, OW, co)
+        hip.conv2d(patches.t, KT, w2, conv.bias, y.t, y.ld, B, OH, OW, KT, OH, OW, co, 1, 1, 1, 0, 1, mode=0)
 
-        def bwd(cat=cat, act=act, C=C):
-            g = take_grad(cat)
+        def bwd(act=act, patches=patches, w2=w2, y=y):
+            g = take_grad(y)
             if g is None:
                 return
+            gw, accw = rt.pgrad(conv.weight)
+            gb, accb = rt.pgrad(conv.bias)
+            if gw is not None:
+                assert gb is None or accb == accw
+                gw2 = rt.buf(co, KT)
+                if gb is not None and accb:       # one accumulate flag covers dw and dbias: start the scratch dw at 0
+                    hip.fill_(gw2, 0.0)
+                hip.conv2d_wgrad(patches.t, KT, g, co, gw2, gb, None, B, OH, OW, KT, OH, OW, co, 1, 1, 1, 0, 1,
+                                 accumulate=0 if gb is None else accb)
+                hip.weight_ohwi(gw2, gw, co, ci, kh, kw, 1, accumulate=accw)
+                if rt.on_param_grad:
+                    rt.on_param_grad(conv.weight)
+                    if gb is not None:
+                        rt.on_param_grad(conv.bias)
             if act.need_grad:
+                dp = rt.buf(B, OH, OW, KT)
+                hip.conv2d(g, co, w2, None, dp, KT, B, OH, OW, KT, OH, OW, co, 1, 1, 1, 0, 1, mode=1)
                 buf, acc = rt.grad_target(act)
-                hip.copy_channels(g, C + 2, 1, buf, C, 1, act.rows, C, accumulate=acc)
+                hip.patch_scatter(dp, buf, act.C, B, H, W, C, CP, k, accumulate=acc)
         rt.push(bwd)
-        return simple_conv(rt, cat, pe.proj)
+        return y
     xe, re_ = x, r
     x, r = rt.parallel([lambda: embed(xe, bb.patch_embed), lambda: embed(re_, bb.patch_embed_radar)])
     outs, outs_r = [], []

@@ -102,6 +102,19 @@ int vrnet_ls_coef_bwd(const double* mom2, const float* ls, int B, int C, float* 
                       void* stream);
 int vrnet_moments_to_float(const double* mom, float* out, long n, double scale, int which, void* stream);
 
+/* ---- non-overlapping patch embedding as gather + GEMM ---------------------------------------------------
+ * PointRecuder(patch_size=4, stride=4) over cat([x, fea_pos]) (backbone/fusion/vr_coc.py:83-102, 424-430, 583-586):
+ * P[b,oy,ox,(ky*k+kx)*(C+CP)+c] = cat(x, pos)[b, oy*k+ky, ox*k+kx, c]  (pos: (H,W,CP) buffer shared by the batch,
+ * NULL when CP == 0); the projection is then vrnet_conv2d_f32 with a 1x1 kernel over k*k*(C+CP) channels and the
+ * weight in OHWI order (vrnet_weight_ohwi_f32 dir 0).  patch_scatter is the adjoint w.r.t. x;
+ * vrnet_weight_ohwi_f32 dir 1 maps the OHWI weight gradient back to the parameter's OIHW layout. */
+int vrnet_patch_gather_f32(const float* x, long ldx, const float* pos, float* out, int B, int H, int W, int C, int CP,
+                           int k, void* stream);
+int vrnet_patch_scatter_f32(const float* dp, float* dx, long lddx, int B, int H, int W, int C, int CP, int k,
+                            int accumulate, void* stream);
+int vrnet_weight_ohwi_f32(const float* src, float* dst, int Cout, int Cin, int kh, int kw, int dir, int accumulate,
+                          void* stream);
+
 /* ---- layout ---------------------------------------------------------------------------------------- */
 /* dst[r*ldd + c*dcs] (+)= src[r*lds + c*scs]: torch.cat + shuffle_channels(groups=2) (vr_coc.py:70-80,
  * coc_fpn_dual.py:120-130) written straight into the consumer's buffer, and their adjoints. */

@@ -442,3 +442,39 @@ def test_layer_scale_coef_and_layout(hip):
     mf = torch.empty(B, C, device="cuda")
     hip.moments_to_float(hip.moments(nhwc(t), C, B, H * W, C), mf, B * C, 1.0 / (H * W))
     close(mf, t.mean(dim=(2, 3)), what="gap")
+
+
+@pytest.mark.parametrize("C,k", [(3, 4), (4, 4), (5, 2)])
+def test_patch_embed_as_gather_gemm(hip, C, k):
+    """cat([x, fea_pos]) -> conv k x k / stride k (vr_coc.py:583-586, 99-102) through patch_gather + 1x1 GEMM with
+    OHWI weights, and its three gradients, against torch's conv2d on the materialised concat."""
+    B, H, W, CP, Co = 2, 8 * k, 6 * k, 2, 24
+    x = rnd(B, C, H, W, seed=1).requires_grad_(True)
+    pos = rnd(H, W, CP, seed=2)
+    w = (rnd(Co, C + CP, k, k, seed=3) * 0.2).requires_grad_(True)
+    bias = rnd(Co, seed=4).requires_grad_(True)
+    cat = torch.cat([x, pos.permute(2, 0, 1).unsqueeze(0).expand(B, -1, -1, -1)], dim=1)
+    y = F.conv2d(cat, w, bias, stride=k)
+    g = rnd(*y.shape, seed=5)
+    y.backward(g)
+    OH, OW, KT = H // k, W // k, k * k * (C + CP)
+    xg, posg, wg = nhwc(x), pos.cuda(), w.detach().cuda()
+    patches = torch.empty(B, OH, OW, KT, device="cuda")
+    hip.patch_gather(xg, C, posg, patches, B, H, W, C, CP, k)
+    w2 = torch.empty(Co, KT, device="cuda")
+    hip.weight_ohwi(wg, w2, Co, C + CP, k, k, 0)
+    out = torch.empty(B, OH, OW, Co, device="cuda")
+    hip.conv2d(patches, KT, w2, bias.detach().cuda(), out, Co, B, OH, OW, KT, OH, OW, Co, 1, 1, 1, 0, 1, mode=0)
+    close(nchw(out), y, what="patch embed fwd")
+    gg = nhwc(g)
+    gw2, gb = torch.empty(Co, KT, device="cuda"), torch.empty(Co, device="cuda")
+    hip.conv2d_wgrad(patches, KT, gg, Co, gw2, gb, None, B, OH, OW, KT, OH, OW, Co, 1, 1, 1, 0, 1)
+    gw = torch.full((Co, C + CP, k, k), 0.5, device="cuda")
+    hip.weight_ohwi(gw2, gw, Co, C + CP, k, k, 1, accumulate=1)
+    close(gw.cpu() - 0.5, w.grad, what="patch embed dw")
+    close(gb, bias.grad, what="patch embed db")
+    dp = torch.empty(B, OH, OW, KT, device="cuda")
+    hip.conv2d(gg, Co, w2, None, dp, KT, B, OH, OW, KT, OH, OW, Co, 1, 1, 1, 0, 1, mode=1)
+    dx = torch.full((B, H, W, C), 0.25, device="cuda")
+    hip.patch_scatter(dp, dx, C, B, H, W, C, CP, k, accumulate=1)
+    close(nchw(dx) - 0.25, x.grad, what="patch embed dx")
