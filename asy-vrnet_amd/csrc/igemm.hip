@@ -31,7 +31,35 @@ struct IgemmArgs {
   int out_nchw, out_ctot, out_coff, accumulate;
   long wtap;   // Cout*Cin
   int Cin;
+  int perm2;   // data gradient of a stride-2 conv: GEMM rows enumerate the 4 pixel parity classes one after another
 };
+
+// GEMM row -> (sample, y, x) of the M-side pixel grid.  With perm2 the rows are parity-major: class (y&1, x&1)
+// occupies a contiguous quarter of the rows, so every 64-row tile has ONE parity and the live-tap list drops
+// the 5-8 of 9 taps that a stride-2 data gradient never touches for that class (instead of multiplying zeros).
+__device__ __forceinline__ void igemm_row_to_pixel(const IgemmArgs& p, int m, int& b, int& y, int& x) {
+  if (p.perm2) {
+    const int Hh = p.MH >> 1, Wh = p.MW >> 1;
+    const int per = (p.M >> 2);
+    const int ph = m / per, r = m - ph * per;
+    const int xh = r % Wh, q = r / Wh;
+    const int yh = q % Hh;
+    b = q / Hh;
+    y = 2 * yh + (ph >> 1);
+    x = 2 * xh + (ph & 1);
+  } else {
+    x = m % p.MW;
+    const int q = m / p.MW;
+    y = q % p.MH;
+    b = q / p.MH;
+  }
+}
+__device__ __forceinline__ long igemm_row_index(const IgemmArgs& p, int m) {
+  if (!p.perm2) return m;
+  int b, y, x;
+  igemm_row_to_pixel(p, m, b, y, x);
+  return ((long)b * p.MH + y) * p.MW + x;
+}
 
 constexpr int STAGE_LD = 36;                       // epilogue staging tile: 32 rows x 36 floats per wave
 
@@ -64,14 +92,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
           const int m = m0 + wm * TM * 32 + i * 32 + row;
           const int n = n0 + wn * TN * 32 + j * 32 + c4;
           if (m < p.M && n < p.CN) {
+            const long mo = igemm_row_index(p, m);
             f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * STAGE_LD + c4]);
             if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
             if (p.aux) {
-              const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + (long)m * p.ldaux + n);
+              const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + mo * p.ldaux + n);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] *= vr_gelu_grad(a[e]);
             }
-            if (p.ypre) *reinterpret_cast<f32x4*>(p.ypre + (long)m * p.ldypre + n) = v;
+            if (p.ypre) *reinterpret_cast<f32x4*>(p.ypre + mo * p.ldypre + n) = v;
             if (p.act == 1) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -80,11 +109,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
               for (int e = 0; e < 4; ++e) v[e] = vr_gelu(v[e]);
             }
             if (p.res) {
-              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (long)m * p.ldres + n);
+              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + mo * p.ldres + n);
               if (p.res_scale) v = rv + *reinterpret_cast<const f32x4*>(p.res_scale + n) * v;
               else v = rv + v;
             }
-            f32x4* dst = reinterpret_cast<f32x4*>(p.y + (long)m * p.ldy + n);
+            f32x4* dst = reinterpret_cast<f32x4*>(p.y + mo * p.ldy + n);
             if (p.accumulate) v += *dst;
             *dst = v;
           }
@@ -106,18 +135,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         if (m >= p.M) continue;
+        const long mo = igemm_row_index(p, m);
         float v = acc[i][j][r] + bias;
-        if (p.aux) v *= vr_gelu_grad(p.aux[(long)m * p.ldaux + n]);
-        if (p.ypre) p.ypre[(long)m * p.ldypre + n] = v;
+        if (p.aux) v *= vr_gelu_grad(p.aux[mo * p.ldaux + n]);
+        if (p.ypre) p.ypre[mo * p.ldypre + n] = v;
         if (p.act == 1) v = fmaxf(v, 0.f);
         else if (p.act == 2) v = vr_gelu(v);
-        if (p.res) v = p.res[(long)m * p.ldres + n] + rsc * v;
+        if (p.res) v = p.res[mo * p.ldres + n] + rsc * v;
         float* dst;
         if (p.out_nchw) {
-          const long b = m / hw, pix = m - b * hw;
+          const long b = mo / hw, pix = mo - b * hw;
           dst = p.y + ((b * p.out_ctot + p.out_coff + n) * hw + pix);
         } else {
-          dst = p.y + (long)m * p.ldy + n;
+          dst = p.y + mo * p.ldy + n;
         }
         if (p.accumulate) v += *dst;
         *dst = v;
@@ -157,10 +187,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && BK == 16) ? 8 : 1) vo
     const int m = m0 + rbase + RPP * i;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
-    a_x[i] = mm % p.MW;
-    const int q = mm / p.MW;
-    a_y[i] = q % p.MH;
-    a_b[i] = q / p.MH;
+    igemm_row_to_pixel(p, mm, a_b[i], a_y[i], a_x[i]);
   }
   auto src_of = [&](int i, int ky, int kx, int& sy, int& sx) -> bool {
     bool ok = a_ok[i];
@@ -413,10 +440,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p, int M
     const int m = m0 + r;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
-    a_x[i] = mm % p.MW;
-    const int q = mm / p.MW;
-    a_y[i] = q % p.MH;
-    a_b[i] = q / p.MH;
+    igemm_row_to_pixel(p, mm, a_b[i], a_y[i], a_x[i]);
   }
   auto src_of = [&](int i, int ky, int kx, int& sy, int& sx) -> bool {
     bool ok = a_ok[i];
@@ -960,6 +984,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   const long M = (long)B * p.MH * p.MW;
   VR_CHECK_ARG(M < (1L << 31) && (long)B * p.SH * p.SW < (1L << 31), "conv2d: too many pixels");
   p.M = (int)M;
+  p.perm2 = (mode == 1 && stride == 2 && p.MH % 2 == 0 && p.MW % 2 == 0 && (M / 4) % 128 == 0) ? 1 : 0;
   VR_CHECK_ARG(lda >= p.CK && (out_nchw || ldy >= p.CN), "conv2d: row stride smaller than channel count");
   p.a_vec = (p.CK % 4 == 0) && (lda % 4 == 0) && vr_aligned16(a);
   p.b_vec = (Cin % 4 == 0) && vr_aligned16(w);

@@ -56,6 +56,8 @@ CONV_CASES = [
     (1, 16, 16, 24, 40, 3, 1, 18, 18),
     (2, 9, 9, 7, 4, 1, 1, 0, 1),
     (3, 1, 1, 32, 32, 1, 1, 0, 1),
+    (2, 32, 32, 64, 96, 3, 2, 1, 1),     # stride-2 data gradient: parity-major rows on the LDS-DMA kernel
+    (1, 32, 64, 128, 64, 3, 2, 1, 1),
 ]
 
 
