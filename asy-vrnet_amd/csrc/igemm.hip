@@ -1164,12 +1164,17 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
 #define VR_WREDUCE(VEC_, SL_)                                                                                        \
   hipLaunchKernelGGL((wgrad_reduce_kernel<VEC_, SL_>), dim3(vr_cdiv(total, 256 / SL_)), dim3(256), 0, st, p.slab, p.bslab, \
                      row_scale, dw, dbias, S, T, Cout, Cin, accumulate)
+  // lanes per output: enough of them to cover the serial slab loop of the small matrices, one thread per output
+  // once the matrix alone yields >= 64K threads (a 16-lane block there is 6 K workgroups of 256 B of output each)
+  const int sl = (total >= 65536 || S <= 2) ? 1 : ((total >= 16384 || S <= 8) ? 4 : 16);
   if (rvec) {
-    if (S > 8) VR_WREDUCE(4, 16);
-    else VR_WREDUCE(4, 4);
+    if (sl == 16) VR_WREDUCE(4, 16);
+    else if (sl == 4) VR_WREDUCE(4, 4);
+    else VR_WREDUCE(4, 1);
   } else {
-    if (S > 8) VR_WREDUCE(1, 16);
-    else VR_WREDUCE(1, 4);
+    if (sl == 16) VR_WREDUCE(1, 16);
+    else if (sl == 4) VR_WREDUCE(1, 4);
+    else VR_WREDUCE(1, 1);
   }
 #undef VR_WREDUCE
   VR_LAUNCH_CHECK("conv2d_wgrad_reduce");

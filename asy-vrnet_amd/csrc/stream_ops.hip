@@ -445,9 +445,9 @@ static int moments_plan(long HW, int C, int vec, int* TPR, int* ncb, int* nchunk
   while (t < CV && t < 256) t <<= 1;
   *TPR = t;
   *ncb = (int)vr_cdiv(CV, t);
-  long nc = vr_cdiv(HW * C, 16384);   // >= 64 elements per thread; the cross-chunk reduce is serial per output
-  if (nc < 1) nc = 1;
-  if (nc > 96) nc = 96;
+  long nc = vr_cdiv(HW * C, 4096);    // >= 16 elements per thread: B x nc x ncb workgroups must cover 256 CUs several
+  if (nc < 1) nc = 1;                  // times over even for one 16x16 map; the chunk reduce is lane-parallel
+  if (nc > 512) nc = 512;
   if (nc > HW) nc = HW;
   *rows = vr_cdiv(HW, nc);
   *nchunks = (int)vr_cdiv(HW, *rows);

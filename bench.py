@@ -44,7 +44,7 @@ def pmc_traffic_bytes(phi):
         return None
     n, tot = 0, 0.0
     for row in csv.DictReader(open(files[-1])):
-        if row["kernel"].startswith("igemm_kernel"):
+        if row["kernel"].startswith(("igemm_kernel", "igemm_dma_kernel")):
             k = int(row["launches"])
             n += k
             tot += k * float(row["avg_HBM_MB"]) * 1024 * 1024
@@ -252,7 +252,7 @@ def main():
                 ct.detail("cluster_bwd", 1e9, "GB/s")
         model.concurrent = True
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32)",
+        roof = {"bound": "mfma", "kernel": "igemm_dma_kernel + igemm_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32; LDS-DMA ring / register-staged variants)",
                 "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": pmc_traffic_bytes(args.phi) if (args.batch == 8 and args.size == 512) else None,
