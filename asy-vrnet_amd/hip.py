@@ -64,6 +64,10 @@ _SIGS = {
     "vrnet_sa_coef_fwd": ([P] * 7 + [I, L, I, I, P, P, P, P], I),
     "vrnet_sa_apply_f32": ([P, L, P, P, P, P, L, I, L, I, P], I),
     "vrnet_sa_bwd_workspace": ([I, L, I], L),
+    "vrnet_decode_outputs_f32": ([P, P, P, I, I, I, F, F, P, P], I),
+    "vrnet_mt_sgd_f32": ([P, P, P, P, P, I, I, I, F, F, I, I, P], I),
+    "vrnet_mt_adam_f32": ([P, P, P, P, P, I, I, I, F, F, F, F, I, P], I),
+    "vrnet_mt_ema_f32": ([P, P, P, P, I, I, I, F, P], I),
     "vrnet_sa_bwd_f32": ([P, L, P, L, P, P, P, P] + [P] * 6 + [P, L] + [P] * 6 + [P, I, L, I, I, I, I, P, L, P], I),
 }
 for _name, (_args, _res) in _SIGS.items():
@@ -299,3 +303,31 @@ def sa_bwd(dy, lddy, x, ldx, Pq, Qq, Mn, mom, params, dx, lddx, grads, EF, B, HW
                                  *[ptr(t) for t in params],
                                  ptr(dx), lddx, *[ptr(t) for t in grads], ptr(EF), B, HW, C, G, accumulate_dx,
                                  accumulate_params, ptr(ws), ws.numel(), stream()), "sa_bwd")
+
+
+# ---- multi-tensor updates (optimizer step, EMA): tables are int64/int32/float32 device tensors built by optim.py
+def mt_sgd(addrs, sizes, chunk_tensor, chunk_index, weight_decay, n_tensors, n_chunks, chunk_elems, lr, momentum, nesterov,
+           first_step):
+    _check(_lib.vrnet_mt_sgd_f32(ptr(addrs), ptr(sizes), ptr(chunk_tensor), ptr(chunk_index), ptr(weight_decay), n_tensors,
+                                 n_chunks, chunk_elems, lr, momentum, int(nesterov), int(first_step), stream()), "mt_sgd")
+
+
+def mt_adam(addrs, sizes, chunk_tensor, chunk_index, weight_decay, n_tensors, n_chunks, chunk_elems, lr, beta1, beta2, eps,
+            step):
+    _check(_lib.vrnet_mt_adam_f32(ptr(addrs), ptr(sizes), ptr(chunk_tensor), ptr(chunk_index), ptr(weight_decay), n_tensors,
+                                  n_chunks, chunk_elems, lr, beta1, beta2, eps, step, stream()), "mt_adam")
+
+
+def mt_ema(addrs, sizes, chunk_tensor, chunk_index, n_tensors, n_chunks, chunk_elems, decay):
+    _check(_lib.vrnet_mt_ema_f32(ptr(addrs), ptr(sizes), ptr(chunk_tensor), ptr(chunk_index), n_tensors, n_chunks,
+                                 chunk_elems, decay, stream()), "mt_ema")
+
+
+def decode_outputs(levels, input_h, input_w, out):
+    """levels: list of contiguous (B, C, h, w) fp32 GPU tensors; out: (B, sum h*w, C)."""
+    n = len(levels)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in levels])
+    hs = (ctypes.c_int * n)(*[t.shape[2] for t in levels])
+    ws = (ctypes.c_int * n)(*[t.shape[3] for t in levels])
+    _check(_lib.vrnet_decode_outputs_f32(ptrs, hs, ws, n, levels[0].shape[0], levels[0].shape[1], float(input_h),
+                                         float(input_w), ptr(out), stream()), "decode_outputs")

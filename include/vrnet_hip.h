@@ -184,6 +184,29 @@ int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long ldx, const
                      int G, int accumulate_dx, int accumulate_params, void* workspace, long workspace_bytes,
                      void* stream);
 
+/* ---- training-step updates over ALL parameters in one launch ----------------------------------
+ * Tensor table (device memory): addrs[k*n + t] = address of role k of tensor t, sizes[t] = element count; the work
+ * list (chunk_tensor[c], chunk_index[c]) cuts every tensor into chunks of chunk_elems (multiple of 256) elements.
+ * vrnet_mt_sgd_f32   roles {param, grad, momentum_buffer}: torch.optim.SGD(momentum, nesterov) as train.py:468-473
+ *                    builds it; weight_decay[t] per tensor (group pg1 only, train.py:472); first_step = buffers unset.
+ * vrnet_mt_adam_f32  roles {param, grad, exp_avg, exp_avg_sq}: torch.optim.Adam(betas=(momentum, 0.999)), step from 1.
+ * vrnet_mt_ema_f32   roles {ema, model}: ModelEMA.update, nets/yolo_training.py:465-475 (v *= d; v += (1-d)*model). */
+int vrnet_mt_sgd_f32(const long long* addrs, const long* sizes, const int* chunk_tensor, const int* chunk_index,
+                     const float* weight_decay, int n_tensors, int n_chunks, int chunk_elems, float lr, float momentum,
+                     int nesterov, int first_step, void* stream);
+int vrnet_mt_adam_f32(const long long* addrs, const long* sizes, const int* chunk_tensor, const int* chunk_index,
+                      const float* weight_decay, int n_tensors, int n_chunks, int chunk_elems, float lr, float beta1,
+                      float beta2, float eps, int step, void* stream);
+int vrnet_mt_ema_f32(const long long* addrs, const long* sizes, const int* chunk_tensor, const int* chunk_index,
+                     int n_tensors, int n_chunks, int chunk_elems, float decay, void* stream);
+
+/* ---- box decode ----------------------------------------------------------------------------
+ * decode_outputs, utils/utils_bbox.py:32-84: levels[l] = raw head map (B, C = 5+num_classes, hs[l], ws[l]) NCHW (the
+ * hot path's det outputs); out (B, sum_l hs*ws, C): [cx/in_w, cy/in_h, w/in_w, h/in_h, sigmoid(obj), sigmoid(cls)...],
+ * anchors level-major then row-major, stride_l = input_h / hs[l].  `levels`, `hs`, `ws` are HOST arrays. */
+int vrnet_decode_outputs_f32(const float* const* levels, const int* hs, const int* ws, int n_levels, int B, int C,
+                             float input_h, float input_w, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
