@@ -65,6 +65,10 @@ _SIGS = {
     "vrnet_sa_apply_f32": ([P, L, P, P, P, P, L, I, L, I, P], I),
     "vrnet_sa_bwd_workspace": ([I, L, I], L),
     "vrnet_decode_outputs_f32": ([P, P, P, I, I, I, F, F, P, P], I),
+    "vrnet_yolo_loss_workspace": ([I, L, I, I], L),
+    "vrnet_yolo_loss_f32": ([P, P, P, P, P, I, I, I, P, P, I, F, P, P, P, P, P, L, P], I),
+    "vrnet_seg_loss_workspace": ([I, I, L], L),
+    "vrnet_seg_loss_f32": ([P, P, P, P, I, I, L, I, I, F, F, F, F, F, P, P, P, L, P], I),
     "vrnet_mt_sgd_f32": ([P, P, P, P, P, I, I, I, F, F, I, I, P], I),
     "vrnet_mt_adam_f32": ([P, P, P, P, P, I, I, I, F, F, F, F, I, P], I),
     "vrnet_mt_ema_f32": ([P, P, P, P, I, I, I, F, P], I),
@@ -331,3 +335,26 @@ def decode_outputs(levels, input_h, input_w, out):
     ws = (ctypes.c_int * n)(*[t.shape[3] for t in levels])
     _check(_lib.vrnet_decode_outputs_f32(ptrs, hs, ws, n, levels[0].shape[0], levels[0].shape[1], float(input_h),
                                          float(input_w), ptr(out), stream()), "decode_outputs")
+
+
+def yolo_loss(levels, grads, strides, labels, counts, max_gt, grad_scale, out, fg=None, matched=None, piou=None):
+    """levels / grads: lists of contiguous (B, C, h, w) fp32 GPU tensors (grads None = value only)."""
+    n = len(levels)
+    B, C = levels[0].shape[:2]
+    A = sum(t.shape[2] * t.shape[3] for t in levels)
+    lv = (ctypes.c_void_p * n)(*[t.data_ptr() for t in levels])
+    gr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads]) if grads is not None else None
+    hs = (ctypes.c_int * n)(*[t.shape[2] for t in levels])
+    ws_ = (ctypes.c_int * n)(*[t.shape[3] for t in levels])
+    st = (ctypes.c_float * n)(*[float(s) for s in strides])
+    ws = _ws.get(_lib.vrnet_yolo_loss_workspace(B, A, max_gt, C - 5), levels[0].device)
+    _check(_lib.vrnet_yolo_loss_f32(lv, gr, hs, ws_, st, n, B, C, ptr(labels), ptr(counts), max_gt, float(grad_scale),
+                                    ptr(out), ptr(fg), ptr(matched), ptr(piou), ptr(ws), ws.numel(), stream()), "yolo_loss")
+
+
+def seg_loss(x, png, onehot, weights, focal, dice, alpha, gamma, beta, smooth, grad_scale, out, dx):
+    B, C, H, W = x.shape
+    ws = _ws.get(_lib.vrnet_seg_loss_workspace(B, C, H * W), x.device)
+    _check(_lib.vrnet_seg_loss_f32(ptr(x), ptr(png), ptr(onehot), ptr(weights), B, C, H * W, int(focal), int(bool(dice)),
+                                   float(alpha), float(gamma), float(beta), float(smooth), float(grad_scale), ptr(out),
+                                   ptr(dx), ptr(ws), ws.numel(), stream()), "seg_loss")

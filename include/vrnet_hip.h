@@ -207,6 +207,28 @@ int vrnet_mt_ema_f32(const long long* addrs, const long* sizes, const int* chunk
 int vrnet_decode_outputs_f32(const float* const* levels, const int* hs, const int* ws, int n_levels, int B, int C,
                              float input_h, float input_w, float* out, void* stream);
 
+/* ---- training losses on the path's outputs: value + gradient w.r.t. the head outputs ------------
+ * vrnet_yolo_loss_f32: YOLOLoss (nets/yolo_training.py:60-427): decode (:99-111), SimOTA assignment per image
+ *   (get_assignments :200-264, get_in_boxes_info :291-368, dynamic_k_matching :370-427), IoU / objectness / class
+ *   losses (:113-198, IOUloss :13-57).  levels[l]: raw (B, C = 5+nc, hs[l], ws[l]) NCHW maps; grads[l]: same shapes,
+ *   receives grad_scale * d loss / d levels[l] (grads or grads[l] NULL = value only); labels (B, max_gt, 5) =
+ *   [cx, cy, w, h, class] in input pixels, counts[b] boxes valid in image b (0 allowed, :145-149).
+ *   out[5] = {loss, num_fg, sum iou loss, sum obj loss, sum cls loss}; optional per-anchor assignment outputs
+ *   fg_out (B,A) u8, matched_out (B,A) int (-1 = background), piou_out (B,A).  levels/grads/hs/ws/strides: HOST arrays.
+ * vrnet_seg_loss_f32: CE_Loss (focal = 0), Focal_Loss (focal = 1) or no main term (focal = -1) (+ Dice_loss when dice = 1)
+ *   (nets/deeplabv3_training.py:9-59; combination utils/utils_fit.py:96-103) on logits x (B, C, H, W) NCHW already at
+ *   label size, png (B, H, W) int64 with ignore index C, onehot (B, H, W, C+1) float, weights[C] or NULL.
+ *   out[3] = {main, dice, main + dice}; dx (NULL = value only) = grad_scale * d(main + dice)/dx. */
+long vrnet_yolo_loss_workspace(int B, long n_anchors, int max_gt, int num_classes);
+int vrnet_yolo_loss_f32(const float* const* levels, float* const* grads, const int* hs, const int* ws, const float* strides,
+                        int n_levels, int B, int C, const float* labels, const int* counts, int max_gt, float grad_scale,
+                        float* out, unsigned char* fg_out, int* matched_out, float* piou_out, void* workspace,
+                        long workspace_bytes, void* stream);
+long vrnet_seg_loss_workspace(int B, int C, long HW);
+int vrnet_seg_loss_f32(const float* x, const long long* png, const float* onehot, const float* weights, int B, int C,
+                       long HW, int focal, int dice, float alpha, float gamma, float beta, float smooth, float grad_scale,
+                       float* out, float* dx, void* workspace, long workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
