@@ -1,0 +1,89 @@
+"""Input formats: every function against hand-worked values (the reference has no fixtures for this
+row and its dataloader cannot be imported; parity unpinned)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from asy_vrnet_amd import data
+
+LINE = "/data/VOC2007/JPEGImages/1664091257.87023.jpg 10,20,110,220,3 0,0,5,5,1"
+
+
+def test_annotation_line_and_frame_id():
+    path, boxes = data.parse_annotation_line(LINE)
+    assert path.endswith("1664091257.87023.jpg") and boxes.tolist() == [[10, 20, 110, 220, 3], [0, 0, 5, 5, 1]]
+    assert data.frame_id(LINE) == "1664091257.87023"
+    p, b = data.parse_annotation_line("/x/1664091257.87023.jpg")
+    assert b.shape == (0, 5)
+    with pytest.raises(ValueError):
+        data.parse_annotation_line("/x/a.jpg 1,2,3,4")
+    with pytest.raises(ValueError):
+        data.frame_id("/x/a.jpg")
+
+
+def test_radar_npz_roundtrip(tmp_path):
+    arr = np.arange(4 * 6 * 8, dtype=np.float32).reshape(4, 6, 8)
+    np.savez(os.path.join(tmp_path, "1664091257.87023.npz"), arr)
+    got = data.load_radar(str(tmp_path), data.frame_id(LINE))
+    assert got.shape == (4, 6, 8) and np.array_equal(got, arr)
+    r = data.preprocess_input_radar(arr)
+    assert abs(r.min() - 1e-13) < 1e-15 and abs(r.max() - 1.0) < 1e-9
+
+
+def test_image_normalisation():
+    img = np.zeros((2, 2, 3))
+    img[0, 0] = [255, 255, 255]
+    out = data.preprocess_input(img)
+    assert np.allclose(out[0, 0], (1 - data.MEAN) / data.STD) and np.allclose(out[1, 1], -data.MEAN / data.STD)
+    assert img[0, 0, 0] == 255                                    # the input is not modified
+
+
+def test_letterbox_boxes_and_cxcywh():
+    # 640x360 image into 512x512: scale .8 -> 512x288, dy = 112
+    assert data.letterbox_geometry(640, 360, 512, 512) == (512, 288, 0, 112)
+    box = np.array([[100, 50, 300, 250, 2], [630, 350, 640, 360, 1], [0, 0, 1, 1, 0]])
+    out = data.adjust_boxes(box, 640, 360, 512, 512)
+    assert np.allclose(out, [[80, 152, 240, 312, 2], [504, 392, 512, 400, 1]])     # 0.8 px wide box dropped
+    cx = data.boxes_xyxy_to_cxcywh(out)
+    assert np.allclose(cx, [[160, 232, 160, 160, 2], [508, 396, 8, 8, 1]])
+    assert data.boxes_xyxy_to_cxcywh(np.zeros((0, 5))).shape == (0, 5)
+
+
+def test_seg_targets_and_collate():
+    png = np.array([[0, 3], [9, 255]])
+    p, oh = data.seg_targets(png, 9)
+    assert p.tolist() == [[0, 3], [9, 9]] and oh.shape == (2, 2, 10)
+    assert oh[1, 1].tolist() == [0] * 9 + [1] and oh[0, 1, 3] == 1
+    s1 = data.make_sample(np.full((2, 2, 3), 255.0), np.array([[0, 0, 2, 2, 1]]), np.ones((4, 2, 2)), png, 9)
+    s2 = data.make_sample(np.zeros((2, 2, 3)), np.zeros((0, 5)), np.zeros((4, 2, 2)), png, 9)
+    images, boxes, radars, pngs, seg = data.yolo_dataset_collate([s1, s2])
+    assert images.shape == (2, 3, 2, 2) and images.dtype == torch.float32
+    assert boxes[0].tolist() == [[1, 1, 2, 2, 1]] and boxes[1].shape == (0, 5)
+    assert radars.shape == (2, 4, 2, 2) and pngs.dtype == torch.int64 and seg.shape == (2, 2, 2, 10)
+
+
+def test_letterbox_sample_with_pil():
+    Image = pytest.importorskip("PIL.Image")
+    img = Image.fromarray(np.full((36, 64, 3), 200, dtype=np.uint8))
+    lab = Image.fromarray(np.full((36, 64), 5, dtype=np.uint8))
+    new_image, box, new_label = data.letterbox_sample(img, lab, np.array([[10, 5, 30, 25, 2]]), (64, 64))
+    a, l = np.array(new_image), np.array(new_label)
+    assert a.shape == (64, 64, 3) and (a[0, 0] == 128).all() and (a[32, 32] == 200).all()      # grey bars, image centre
+    assert l[0, 0] == 0 and l[32, 32] == 5 and np.allclose(box, [[10, 19, 30, 39, 2]])
+
+
+def test_reference_annotation_file_sample():
+    """First lines of the reference's own 2007_val.txt (a data file it ships), copied verbatim as a fixture."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    lines = open(os.path.join(here, "golden", "annotation_lines_sample.txt")).read().splitlines()
+    assert len(lines) == 5
+    path, boxes = data.parse_annotation_line(lines[0])
+    assert path.endswith("1664091274.85923.jpg") and data.frame_id(lines[0]) == "1664091274.85923"
+    assert boxes.tolist() == [[889, 405, 903, 450, 0], [1001, 404, 1015, 458, 0], [1, 396, 23, 438, 0]]
+    for ln in lines:
+        p, b = data.parse_annotation_line(ln)
+        assert b.shape[1] == 5 and (b[:, 2] > b[:, 0]).all() and (b[:, 3] > b[:, 1]).all() and data.frame_id(ln) in p
+        cx = data.boxes_xyxy_to_cxcywh(data.adjust_boxes(b, 1920, 1080, 512, 512))
+        assert (cx[:, 2:4] > 1).all() and (cx[:, :2] >= 0).all() and (cx[:, :2] <= 512).all()
