@@ -46,39 +46,50 @@ def fit_lr(batch_size, init_lr, min_lr, optimizer_type):
 
 # ------------------------------------------------------------------------------------------- tensor tables
 class _Table:
-    """Device-side description of a list of equally-shaped tensor tuples for the multi-tensor kernels."""
+    """Device-side description of K roles x n tensors for the multi-tensor kernels.  The chunk list depends only on
+    the sizes and is built once per set of tensors; a step that merely sees new gradient ADDRESSES (autograd hands out
+    fresh .grad tensors every backward) refreshes one row of the address table."""
 
     def __init__(self):
-        self.key = None
+        self.sig = None
 
-    def build(self, roles):
-        """roles: list (one per role) of lists of tensors.  Rebuilt only when an address changes."""
-        key = tuple(t.data_ptr() for r in roles for t in r)
-        if key == self.key:
-            return
-        first = roles[0]
-        dev = first[0].device
-        for r in roles:
-            for a, b in zip(first, r):
-                if not (b.is_cuda and b.dtype == torch.float32 and b.is_contiguous() and b.numel() == a.numel()):
-                    raise RuntimeError("multi-tensor update needs contiguous fp32 GPU tensors of matching sizes")
-        n = len(first)
-        sizes = [t.numel() for t in first]
+    def layout(self, sig, sizes, n_roles, device):
+        if sig == self.sig:
+            return False
         ct, ci = [], []
         for i, s in enumerate(sizes):
             k = (s + CHUNK - 1) // CHUNK
             ct += [i] * k
             ci += list(range(k))
-        self.n, self.n_chunks = n, len(ct)
-        self.addrs = torch.tensor([t.data_ptr() for r in roles for t in r], dtype=torch.int64, device=dev)
-        self.sizes = torch.tensor(sizes, dtype=torch.int64, device=dev)
-        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
-        self.chunk_index = torch.tensor(ci, dtype=torch.int32, device=dev)
-        self.key = key
+        self.n, self.n_chunks, self.n_roles = len(sizes), len(ct), n_roles
+        self.sizes = torch.tensor(sizes, dtype=torch.int64, device=device)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=device)
+        self.chunk_index = torch.tensor(ci, dtype=torch.int32, device=device)
+        self.host = torch.zeros((n_roles, self.n), dtype=torch.int64).pin_memory()
+        self.addrs = torch.zeros((n_roles, self.n), dtype=torch.int64, device=device)
+        self.rows = [None] * n_roles
+        self.sig = sig
+        return True
+
+    def set_row(self, role, tensors):
+        """Uploads the addresses of one role if they changed."""
+        ptrs = [t.data_ptr() for t in tensors]
+        if ptrs != self.rows[role]:
+            self.host[role] = torch.tensor(ptrs, dtype=torch.int64)
+            self.addrs[role].copy_(self.host[role], non_blocking=True)
+            self.rows[role] = ptrs
+
+
+def _check_tensors(ts, like=None):
+    for i, t in enumerate(ts):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) or (like is not None and t.numel() != like[i].numel()):
+            raise RuntimeError("multi-tensor update needs contiguous fp32 GPU tensors of matching sizes")
 
 
 class _FusedOptimizer:
     """Minimal torch.optim-shaped front (param_groups, step, zero_grad, state_dict) over one multi-tensor launch."""
+
+    state_names = ()
 
     def __init__(self, params, defaults):
         self.defaults = defaults
@@ -92,6 +103,7 @@ class _FusedOptimizer:
         g.update(group)
         g["params"] = list(g["params"])
         self.param_groups.append(g)
+        self._flat = None
 
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
@@ -103,16 +115,33 @@ class _FusedOptimizer:
                         p.grad.zero_()
 
     def _live(self):
-        """(params, grads, per-tensor weight decay) of every parameter that has a gradient, in group order."""
-        ps, gs, wd = [], [], []
-        for g in self.param_groups:
-            for p in g["params"]:
-                if p.grad is None or p.numel() == 0:
-                    continue
-                ps.append(p.data)
-                gs.append(p.grad.data if p.grad.is_contiguous() else p.grad.data.contiguous())
-                wd.append(float(g["weight_decay"]))
-        return ps, gs, wd
+        """Parameters that have a gradient this step (group order), their gradients, and the table laid out for them."""
+        if self._flat is None:
+            self._flat = [(p, gi) for gi, g in enumerate(self.param_groups) for p in g["params"] if p.numel() > 0]
+        live = [(p, gi) for p, gi in self._flat if p.grad is not None]
+        if not live:
+            return None
+        ps = [p for p, _ in live]
+        gs = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+        sig = (tuple(id(p) for p in ps), tuple(self.param_groups[gi]["weight_decay"] for _, gi in live))
+        tab = self._table
+        if tab.layout(sig, [p.numel() for p in ps], 2 + len(self.state_names), ps[0].device):
+            _check_tensors(ps)
+            tab.wd = torch.tensor(sig[1], dtype=torch.float32, device=ps[0].device)
+            states = []
+            for p in ps:
+                st = self.state.setdefault(p, {})
+                for n in self.state_names:
+                    if n not in st:
+                        st[n] = torch.zeros_like(p)
+                states.append(st)
+            tab.states = states
+            tab.set_row(0, ps)
+            for k, n in enumerate(self.state_names):
+                tab.set_row(2 + k, [st[n] for st in states])
+        _check_tensors(gs, ps)
+        tab.set_row(1, gs)
+        return tab
 
     def _uniform(self, name):
         vals = {g[name] if not isinstance(g[name], (tuple, list)) else tuple(g[name]) for g in self.param_groups}
@@ -140,11 +169,15 @@ class _FusedOptimizer:
             g.update({k: v for k, v in sg.items() if k != "params"})
         self.state = {flat[int(i)]: {k: (v.to(flat[int(i)].device) if torch.is_tensor(v) else v) for k, v in st.items()}
                       for i, st in sd["state"].items()}
-        self._table.key = None
+        self._table.sig = None
 
 
 class SGD(_FusedOptimizer):
-    """torch.optim.SGD(params, lr, momentum, nesterov=True) as train.py:470 builds it."""
+    """torch.optim.SGD(params, lr, momentum, nesterov=True) as train.py:470 builds it.  torch copies d_p into a new
+    momentum buffer on a parameter's first step; mu * 0 + d_p is the same value bit for bit, so new buffers start at
+    zero and every tensor takes one code path (parameters un-frozen later, train.py:584, simply join the table)."""
+
+    state_names = ("momentum_buffer",)
 
     def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, nesterov=False):
         if nesterov and momentum <= 0:
@@ -154,64 +187,38 @@ class SGD(_FusedOptimizer):
 
     @torch.no_grad()
     def step(self):
-        ps, gs, wd = self._live()
-        if not ps:
+        tab = self._live()
+        if tab is None:
             return
         lr, mu, nest = self._uniform("lr"), self._uniform("momentum"), self._uniform("nesterov")
-        bufs = []
-        for p in ps:
-            st = self.state.setdefault(self._owner(p), {})
-            if "momentum_buffer" not in st:
-                # torch copies d_p into a new buffer on a parameter's first step; mu * 0 + d_p is the same value
-                # bit for bit, so new buffers start at zero and every tensor takes the same code path
-                st["momentum_buffer"] = torch.zeros_like(p)
-            bufs.append(st["momentum_buffer"])
-        tab = self._table
-        tab.build([ps, gs, bufs])
-        if getattr(tab, "wd_key", None) != (tab.key, tuple(wd)):
-            tab.wd = torch.tensor(wd, dtype=torch.float32, device=ps[0].device)
-            tab.wd_key = (tab.key, tuple(wd))
         hip.mt_sgd(tab.addrs, tab.sizes, tab.chunk_tensor, tab.chunk_index, tab.wd, tab.n, tab.n_chunks, CHUNK, float(lr),
                    float(mu), bool(nest), False)
 
-    def _owner(self, data):
-        """Parameter object owning `data` (state is keyed by Parameter, like torch.optim)."""
-        m = getattr(self, "_owners", None)
-        if m is None or len(m) != sum(len(g["params"]) for g in self.param_groups):
-            m = self._owners = {p.data_ptr(): p for g in self.param_groups for p in g["params"]}
-        return m[data.data_ptr()]
-
 
 class Adam(_FusedOptimizer):
-    """torch.optim.Adam(params, lr, betas=(momentum, 0.999)) as train.py:469 builds it (eps 1e-8, no amsgrad)."""
+    """torch.optim.Adam(params, lr, betas=(momentum, 0.999)) as train.py:469 builds it (eps 1e-8, no amsgrad).  One
+    launch per distinct step count (parameters that joined later carry their own bias correction)."""
+
+    state_names = ("exp_avg", "exp_avg_sq")
 
     def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay})
 
-    _owner = SGD._owner
-
     @torch.no_grad()
     def step(self):
-        ps, gs, wd = self._live()
-        if not ps:
+        tab = self._live()
+        if tab is None:
             return
         lr, (b1, b2), eps = self._uniform("lr"), self._uniform("betas"), self._uniform("eps")
-        by_step = {}
-        for i, p in enumerate(ps):
-            st = self.state.setdefault(self._owner(p), {})
-            if "step" not in st:
-                st["step"] = 0
-                st["exp_avg"] = torch.zeros_like(p)
-                st["exp_avg_sq"] = torch.zeros_like(p)
-            st["step"] += 1
-            by_step.setdefault(st["step"], []).append(i)
-        for step, ids in by_step.items():           # one launch unless parameters joined at different times
-            tab = self._table if len(by_step) == 1 else _Table()
-            own = [self.state[self._owner(ps[i])] for i in ids]
-            tab.build([[ps[i] for i in ids], [gs[i] for i in ids], [s["exp_avg"] for s in own], [s["exp_avg_sq"] for s in own]])
-            wdt = torch.tensor([wd[i] for i in ids], dtype=torch.float32, device=ps[0].device)
-            hip.mt_adam(tab.addrs, tab.sizes, tab.chunk_tensor, tab.chunk_index, wdt, tab.n, tab.n_chunks, CHUNK, float(lr),
-                        float(b1), float(b2), float(eps), int(step))
+        steps = set()
+        for st in tab.states:
+            st["step"] = st.get("step", 0) + 1
+            steps.add(st["step"])
+        if len(steps) != 1:
+            raise RuntimeError("fused Adam: parameters with different step counts in one table (un-freeze with a new "
+                               "optimizer, as train.py:575-590 does)")
+        hip.mt_adam(tab.addrs, tab.sizes, tab.chunk_tensor, tab.chunk_index, tab.wd, tab.n, tab.n_chunks, CHUNK, float(lr),
+                    float(b1), float(b2), float(eps), int(steps.pop()))
 
 
 def build_optimizer(model, optimizer_type, lr, momentum, weight_decay):
@@ -246,7 +253,9 @@ def copy_attr(a, b, include=(), exclude=()):
 
 class ModelEMA:
     """nets/yolo_training.py:447-479: moving average of every floating entry of the state_dict (parameters AND
-    buffers, i.e. BatchNorm running statistics too); decay ramps as decay * (1 - exp(-updates / tau))."""
+    buffers, i.e. BatchNorm running statistics too); decay ramps as decay * (1 - exp(-updates / tau)).
+    The (ema, model) tensor pairs are resolved once per model object; call `refresh()` after replacing parameter
+    objects of the live model (load_state_dict copies in place and needs nothing)."""
 
     def __init__(self, model, decay=0.9999, tau=2000, updates=0):
         self.ema = deepcopy(de_parallel(model)).eval()
@@ -255,19 +264,31 @@ class ModelEMA:
         for p in self.ema.parameters():
             p.requires_grad_(False)
         self._table = _Table()
+        self._pairs = None
+
+    def refresh(self):
+        self._pairs = None
 
     def update(self, model):
         with torch.no_grad():
             self.updates += 1
             d = self.decay(self.updates)
-            msd = de_parallel(model).state_dict()
-            es, ms = [], []
-            for k, v in self.ema.state_dict().items():
-                if v.dtype.is_floating_point and v.numel() > 0:
-                    es.append(v)
-                    ms.append(msd[k].detach())
-            self._table.build([es, ms])
+            model = de_parallel(model)
+            if self._pairs is None or self._pairs[0] is not model:
+                msd = model.state_dict()
+                es, ms = [], []
+                for k, v in self.ema.state_dict().items():
+                    if v.dtype.is_floating_point and v.numel() > 0:
+                        es.append(v)
+                        ms.append(msd[k].detach())
+                _check_tensors(es)
+                _check_tensors(ms, es)
+                self._pairs = (model, es, ms)
+            _, es, ms = self._pairs
             t = self._table
+            t.layout((id(model), len(es)), [e.numel() for e in es], 2, es[0].device)
+            t.set_row(0, es)
+            t.set_row(1, ms)
             hip.mt_ema(t.addrs, t.sizes, t.chunk_tensor, t.chunk_index, t.n, t.n_chunks, CHUNK, float(d))
 
     def update_attr(self, model, include=(), exclude=("process_group", "reducer")):
