@@ -37,6 +37,55 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* x, long ldx
   }
 }
 
+// Vector variant (C % 4 == 0, C <= 1024, 16-byte rows): a thread owns 4 consecutive channels -- its 36 weights sit in
+// registers for the whole kernel -- and walks pixels; every tap is one 16-byte load, a wave covers whole rows of
+// channels.  The scalar kernel above issues 18 dword loads (9 of them 36-byte-strided weight reads) per output.
+__global__ __launch_bounds__(256) void dwconv3x3_vec_kernel(const float* x, long ldx, const float* w, float* y, long ldy,
+                                                            int B, int H, int W, int C, int flip, int accumulate,
+                                                            int pix_per_block) {
+  const int CQ = C >> 2, PP = 256 / CQ;          // channel quads, pixels in flight per pass (CQ divides 256 or PP = 1...)
+  const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
+  if (pr >= PP) return;
+  f32x4 wt[9];
+  {
+    float raw[36];
+    const float* ws = w + (long)cq * 36;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(ws + 4 * i);
+      raw[4 * i] = t[0]; raw[4 * i + 1] = t[1]; raw[4 * i + 2] = t[2]; raw[4 * i + 3] = t[3];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ts = flip ? 8 - t : t;
+      wt[t] = f32x4{raw[ts], raw[9 + ts], raw[18 + ts], raw[27 + ts]};
+    }
+  }
+  const int total = B * H * W;
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(total, p0 + pix_per_block);
+  for (int pix = p0 + pr; pix < p1; pix += PP) {
+    const int xx = pix % W;
+    const int q = pix / W;
+    const int yy = q % H;
+    const int b = q / H;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int sy = yy + ky - 1;
+      if (sy < 0 || sy >= H) continue;
+      const float* row = x + ((long)(b * H + sy) * W) * ldx + 4 * cq;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int sx = xx + kx - 1;
+        if (sx < 0 || sx >= W) continue;
+        s += *reinterpret_cast<const f32x4*>(row + (long)sx * ldx) * wt[ky * 3 + kx];
+      }
+    }
+    f32x4* d = reinterpret_cast<f32x4*>(y + (long)pix * ldy + 4 * cq);
+    *d = accumulate ? *d + s : s;
+  }
+}
+
 // partial[chunk][c][9]: dw[c][t] = sum_pix dy[pix, c] * x[pix + tap t, c].  A chunk is a run of image rows
 // (b, y); all index math is 32-bit and row-uniform.
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* x, long ldx, const float* dy, long lddy,
@@ -543,8 +592,19 @@ extern "C" int vrnet_dwconv3x3_f32(const float* x, long ldx, const float* w, flo
                                    int C, int flip, int accumulate, void* stream) {
   VR_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && C > 0, "dwconv3x3: bad arguments");
   VR_CHECK_ARG((long)B * H * W * C < (1L << 31), "dwconv3x3: tensor too large");
-  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, vr_stream(stream), x, ldx, w, y,
-                     ldy, B, H, W, C, flip, accumulate);
+  const bool vec = C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && ldx % 4 == 0 && ldy % 4 == 0 && vr_aligned16(x) &&
+                   vr_aligned16(y) && vr_aligned16(w);
+  if (vec) {
+    const long npix = (long)B * H * W;
+    const int pp = 256 / (C / 4);
+    long ppb = pp * 8L;                              // >= 8 pixels per thread, at least ~2048 workgroups when possible
+    while (vr_cdiv(npix, ppb) > 4096) ppb *= 2;
+    hipLaunchKernelGGL(dwconv3x3_vec_kernel, dim3(vr_cdiv(npix, ppb)), dim3(256), 0, vr_stream(stream), x, ldx, w, y, ldy, B,
+                       H, W, C, flip, accumulate, (int)ppb);
+  } else {
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, vr_stream(stream), x, ldx, w, y,
+                       ldy, B, H, W, C, flip, accumulate);
+  }
   VR_LAUNCH_CHECK("dwconv3x3");
   return VR_OK;
 }

@@ -114,59 +114,65 @@ struct AffineArgs {
   long HW; int C; long bstride; int pre; int accumulate;
 };
 
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// One element (VEC consecutive channels of one pixel).  Every operand -- coefficients too -- moves as one 16-byte
+// access on the vector path (C % 4 == 0 keeps cb + c a multiple of 4).
+template <int VEC>
+__device__ __forceinline__ void affine_one(const AffineArgs& p, long row, long cb, int c) {
+  if (VEC == 4) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+    f32x4 v = p.D1 ? ld4(p.D1 + cb + c) : zero;
+    // issue the streaming loads first: they are independent and the longest-latency operands
+    f32x4 a = zero, x2 = zero, mk = zero, acc = zero;
+    if (p.x1) a = ld4(p.x1 + row * p.ld1 + c);
+    if (p.x2) x2 = ld4(p.x2 + row * p.ld2 + c);
+    if (p.pre == 2) mk = ld4(p.masky + row * p.ldm + c);
+    float* o = p.out + row * p.ldo + c;
+    if (p.accumulate) acc = ld4(o);
+    if (p.x1) v += (p.A ? ld4(p.A + cb + c) : one) * (a - (p.S1 ? ld4(p.S1 + cb + c) : zero));
+    if (p.pre == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    } else if (p.pre == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!(mk[j] > 0.f)) v[j] = 0.f;
+    }
+    if (p.x2) v += (p.E ? ld4(p.E + cb + c) : one) * (x2 - (p.S2 ? ld4(p.S2 + cb + c) : zero));
+    if (p.D2) v += ld4(p.D2 + cb + c);
+    if (p.accumulate) v += acc;
+    *reinterpret_cast<f32x4*>(o) = v;
+  } else {
+    float v = p.D1 ? p.D1[cb + c] : 0.f;
+    if (p.x1) v += (p.A ? p.A[cb + c] : 1.f) * (p.x1[row * p.ld1 + c] - (p.S1 ? p.S1[cb + c] : 0.f));
+    if (p.pre == 1) v = fmaxf(v, 0.f);
+    else if (p.pre == 2 && !(p.masky[row * p.ldm + c] > 0.f)) v = 0.f;
+    if (p.x2) v += (p.E ? p.E[cb + c] : 1.f) * (p.x2[row * p.ld2 + c] - (p.S2 ? p.S2[cb + c] : 0.f));
+    if (p.D2) v += p.D2[cb + c];
+    float* o = p.out + row * p.ldo + c;
+    if (p.accumulate) v += o[0];
+    o[0] = v;
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void affine_kernel(const AffineArgs p) {
   const int CV = p.C / VEC;
   const long total = p.HW * CV;
   const long b = blockIdx.y;
   const long cb = b * p.bstride;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long r = e / CV;
-    const int c = (int)(e - r * CV) * VEC;
-    const long row = b * p.HW + r;
-    float v[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) v[j] = p.D1 ? p.D1[cb + c + j] : 0.f;
-    if (p.x1) {
-      float a[VEC];
-      if (VEC == 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p.x1 + row * p.ld1 + c);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) a[j] = t[j];
-      } else {
-        a[0] = p.x1[row * p.ld1 + c];
-      }
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] += (p.A ? p.A[cb + c + j] : 1.f) * (a[j] - (p.S1 ? p.S1[cb + c + j] : 0.f));
-    }
-    if (p.pre == 1) {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] = fmaxf(v[j], 0.f);
-    } else if (p.pre == 2) {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j)
-        if (!(p.masky[row * p.ldm + c + j] > 0.f)) v[j] = 0.f;
-    }
-    if (p.x2) {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j)
-        v[j] += (p.E ? p.E[cb + c + j] : 1.f) * (p.x2[row * p.ld2 + c + j] - (p.S2 ? p.S2[cb + c + j] : 0.f));
-    }
-    if (p.D2) {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] += p.D2[cb + c + j];
-    }
-    float* o = p.out + row * p.ldo + c;
-    if (p.accumulate) {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] += o[j];
-    }
-    if (VEC == 4) {
-      f32x4 t = {v[0], v[VEC > 1 ? 1 : 0], v[VEC > 2 ? 2 : 0], v[VEC > 3 ? 3 : 0]};
-      *reinterpret_cast<f32x4*>(o) = t;
-    } else {
-      o[0] = v[0];
-    }
+  const long stride = (long)gridDim.x * 256;
+  long e = (long)blockIdx.x * 256 + threadIdx.x;
+  // two elements per trip: both sets of loads are in flight before the first store
+  for (; e + stride < total; e += 2 * stride) {
+    const long r0 = e / CV, r1 = (e + stride) / CV;
+    affine_one<VEC>(p, b * p.HW + r0, cb, (int)(e - r0 * CV) * VEC);
+    affine_one<VEC>(p, b * p.HW + r1, cb, (int)(e + stride - r1 * CV) * VEC);
+  }
+  if (e < total) {
+    const long r0 = e / CV;
+    affine_one<VEC>(p, b * p.HW + r0, cb, (int)(e - r0 * CV) * VEC);
   }
 }
 
@@ -503,6 +509,9 @@ extern "C" int vrnet_affine_f32(const float* x1, long ld1, const float* A, const
   AffineArgs p{x1, ld1, A, D1, S1, masky, ldm, x2, ld2, E, D2, S2, out, ldo, HW, C, coef_bstride, pre, accumulate};
   bool vec = (C % 4 == 0) && (ldo % 4 == 0) && vr_aligned16(out) && (coef_bstride % 4 == 0);
   if (x1) vec = vec && (ld1 % 4 == 0) && vr_aligned16(x1);
+  if (x2) vec = vec && (ld2 % 4 == 0) && vr_aligned16(x2);
+  if (pre == 2) vec = vec && (ldm % 4 == 0) && vr_aligned16(masky);
+  for (const float* c : {A, D1, S1, E, D2, S2}) vec = vec && (!c || vr_aligned16(c));
   long blocks = vr_cdiv(HW * (C / (vec ? 4 : 1)), 256 * 4);
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;

@@ -37,6 +37,9 @@ class Act:
         return self.B * self.H * self.W
 
 
+WGRAD_STREAMS = int(os.environ.get("VRNET_WGRAD_STREAMS", "4"))   # side streams for deferred weight gradients
+
+
 class RT:
     """Per-call runtime: mode, tape, parameter-gradient table, packed-weight cache."""
 
@@ -113,7 +116,7 @@ class RT:
         if not self._deferred_wgrads:
             return
         cur = torch.cuda.current_stream(self.device)
-        streams = self._streams(8)[4:8]
+        streams = self._streams(8)[4:4 + WGRAD_STREAMS]
         for st in streams:
             st.wait_stream(cur)
         work = self._launch_deferred_wgrads(cur, streams)
@@ -153,7 +156,7 @@ class RT:
                 if hook is not None:           # a bucket's all-reduce must not start before BOTH chains have joined
                     self.on_param_grad = deferred.append
                 # weight gradients deferred by the PREVIOUS section run beside this section's data-gradient chains
-                wstreams = self._streams(8)[4:8] if self._deferred_wgrads else []
+                wstreams = self._streams(8)[4:4 + WGRAD_STREAMS] if self._deferred_wgrads else []
                 for st in wstreams:
                     st.wait_stream(cur_b)
                 held = self._launch_deferred_wgrads(cur_b, wstreams) if wstreams else []

@@ -291,8 +291,9 @@ def test_cluster_rejects_bad_shapes(hip):
         hip.cluster_fwd(f, f, 32, ab, ab, o, 32, idx, None, 1, 6, 6, 1, 32, 4)
 
 
-def test_depthwise(hip):
-    B, H, W, C = 2, 9, 8, 64
+@pytest.mark.parametrize("C", [64, 256, 6, 40])      # vector kernel (64, 256), scalar kernel (6; 40: 256 % 10 != 0)
+def test_depthwise(hip, C):
+    B, H, W = 2, 9, 8
     x = rnd(B, C, H, W, seed=1).requires_grad_(True)
     w = rnd(C, 1, 3, 3, seed=2).requires_grad_(True)
     y = F.conv2d(x, w, None, 1, 1, 1, C)
