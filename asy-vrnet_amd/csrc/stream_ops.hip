@@ -30,8 +30,16 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, 
   for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0;
   if (cv < CV) {
     const long base = (long)b * HW;
-    for (long r = r0 + ty; r < r1; r += RP) {
-      float a[VEC], c2[VEC], mk[VEC];
+    auto accum = [&](const float (&a)[VEC], const float (&c2)[VEC], const float (&mk)[VEC]) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float v = a[j];
+        if (mask && !(mk[j] > 0.f)) v = 0.f;
+        s1[j] += (double)v;
+        s2[j] += (double)v * (double)(x2 ? c2[j] : v);
+      }
+    };
+    auto load = [&](long r, float (&a)[VEC], float (&c2)[VEC], float (&mk)[VEC]) {
       if (VEC == 4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + (base + r) * ldx + cv * 4);
 #pragma unroll
@@ -51,13 +59,20 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, 
         if (x2) c2[0] = x2[(base + r) * ldx2 + cv];
         if (mask) mk[0] = mask[(base + r) * ldm + cv];
       }
+    };
+    long r = r0 + ty;
+    // four rows per trip: all their loads are issued before the first fp64 accumulate
+    for (; r + 3L * RP < r1; r += 4L * RP) {
+      float a[4][VEC], c2[4][VEC], mk[4][VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        float v = a[j];
-        if (mask && !(mk[j] > 0.f)) v = 0.f;
-        s1[j] += (double)v;
-        s2[j] += (double)v * (double)(x2 ? c2[j] : v);
-      }
+      for (int u = 0; u < 4; ++u) load(r + (long)u * RP, a[u], c2[u], mk[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accum(a[u], c2[u], mk[u]);
+    }
+    for (; r < r1; r += RP) {
+      float a[VEC], c2[VEC], mk[VEC];
+      load(r, a, c2, mk);
+      accum(a, c2, mk);
     }
   }
 #pragma unroll
@@ -208,6 +223,40 @@ __global__ __launch_bounds__(256) void gn_coef_fwd_kernel(const double* mom, con
   for (int c = threadIdx.x; c < C; c += 256) {
     A[(long)b * C + c] = (float)(rstd * gamma[c]);      // y = A * (x - S) + D: the subtraction comes first, as in
     D[(long)b * C + c] = beta[c];                         // torch (A*x + (beta - mean*A) cancels when |mean| >> std)
+    S[(long)b * C + c] = (float)mean;
+  }
+  if (threadIdx.x == 0) {
+    mean_rstd[2 * b] = (float)mean;
+    mean_rstd[2 * b + 1] = (float)rstd;
+  }
+}
+
+// GroupNorm(1, C) forward statistics straight from the moments kernel's per-chunk partials: the per-sample totals
+// are flat sums over (chunk, channel), so the cross-chunk reduce kernel and the per-channel table are skipped (one
+// launch instead of two on the critical path of every block).
+__global__ __launch_bounds__(256) void gn_coef_fwd_partial_kernel(const double* partial, long pairs, const float* gamma,
+                                                                  const float* beta, float eps, long HW, int C, float* A,
+                                                                  float* D, float* S, float* mean_rstd) {
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  const double* src = partial + (long)b * pairs * 2;
+  double s1 = 0, s2 = 0, t1 = 0, t2 = 0;
+  long i = threadIdx.x;
+  for (; i + 256 < pairs; i += 512) {          // two independent pairs per trip
+    s1 += src[2 * i]; s2 += src[2 * i + 1];
+    t1 += src[2 * (i + 256)]; t2 += src[2 * (i + 256) + 1];
+  }
+  if (i < pairs) { s1 += src[2 * i]; s2 += src[2 * i + 1]; }
+  s1 = block_sum(s1 + t1, red);
+  s2 = block_sum(s2 + t2, red);
+  const double n = (double)HW * C;
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0) var = 0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    A[(long)b * C + c] = (float)(rstd * gamma[c]);
+    D[(long)b * C + c] = beta[c];
     S[(long)b * C + c] = (float)mean;
   }
   if (threadIdx.x == 0) {
@@ -469,10 +518,9 @@ extern "C" long vrnet_moments_workspace(int B, long HW, int C) {
   return (long)B * nchunks * C * 2 * 8 + 256;
 }
 
-extern "C" int vrnet_moments_f32(const float* x, long ldx, const float* x2, long ldx2, const float* mask, long ldm,
-                                 int B, long HW, int C, double* out, void* workspace, long workspace_bytes,
-                                 void* stream) {
-  VR_CHECK_ARG(x && out && workspace, "moments: null tensor");
+static int moments_launch(const float* x, long ldx, const float* x2, long ldx2, const float* mask, long ldm, int B,
+                          long HW, int C, void* workspace, long workspace_bytes, hipStream_t st, int* nchunks_out) {
+  VR_CHECK_ARG(x && workspace, "moments: null tensor");
   VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && ldx >= C, "moments: bad shape");
   bool vec = (C % 4 == 0) && (ldx % 4 == 0) && vr_aligned16(x);
   if (x2) vec = vec && (ldx2 % 4 == 0) && vr_aligned16(x2);
@@ -485,7 +533,6 @@ extern "C" int vrnet_moments_f32(const float* x, long ldx, const float* x2, long
     return VR_ERR_WORKSPACE;
   }
   double* partial = reinterpret_cast<double*>(workspace);
-  hipStream_t st = vr_stream(stream);
   dim3 grid(nchunks, B, ncb), block(256);
   if (vec)
     hipLaunchKernelGGL((moments_kernel<4>), grid, block, 256 * 8 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
@@ -494,9 +541,36 @@ extern "C" int vrnet_moments_f32(const float* x, long ldx, const float* x2, long
     hipLaunchKernelGGL((moments_kernel<1>), grid, block, 256 * 2 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
                        TPR, rows, nchunks, partial);
   VR_LAUNCH_CHECK("moments");
+  *nchunks_out = nchunks;
+  return VR_OK;
+}
+
+extern "C" int vrnet_moments_f32(const float* x, long ldx, const float* x2, long ldx2, const float* mask, long ldm,
+                                 int B, long HW, int C, double* out, void* workspace, long workspace_bytes,
+                                 void* stream) {
+  VR_CHECK_ARG(out, "moments: null tensor");
+  hipStream_t st = vr_stream(stream);
+  int nchunks;
+  int rc = moments_launch(x, ldx, x2, ldx2, mask, ldm, B, HW, C, workspace, workspace_bytes, st, &nchunks);
+  if (rc) return rc;
   const long n = (long)B * C * 2;
-  hipLaunchKernelGGL(moments_reduce_kernel, dim3(vr_cdiv(n, 16)), dim3(256), 0, st, partial, out, B, nchunks, C);
+  hipLaunchKernelGGL(moments_reduce_kernel, dim3(vr_cdiv(n, 16)), dim3(256), 0, st, reinterpret_cast<double*>(workspace), out,
+                     B, nchunks, C);
   VR_LAUNCH_CHECK("moments_reduce");
+  return VR_OK;
+}
+
+extern "C" int vrnet_gn_stats_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, int B,
+                                  long HW, int C, float* A, float* D, float* S, float* mean_rstd, void* workspace,
+                                  long workspace_bytes, void* stream) {
+  VR_CHECK_ARG(gamma && beta && A && D && S && mean_rstd, "gn_stats_fwd: null tensor");
+  hipStream_t st = vr_stream(stream);
+  int nchunks;
+  int rc = moments_launch(x, ldx, nullptr, 0, nullptr, 0, B, HW, C, workspace, workspace_bytes, st, &nchunks);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_coef_fwd_partial_kernel, dim3(B), dim3(256), 0, st, reinterpret_cast<double*>(workspace),
+                     (long)nchunks * C, gamma, beta, eps, HW, C, A, D, S, mean_rstd);
+  VR_LAUNCH_CHECK("gn_stats_fwd");
   return VR_OK;
 }
 

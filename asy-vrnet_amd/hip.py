@@ -33,6 +33,7 @@ _SIGS = {
     "vrnet_moments_f32": ([P, L, P, L, P, L, I, L, I, P, P, L, P], I),
     "vrnet_affine_f32": ([P, L, P, P, P, I, P, L, P, L, P, P, P, L, P, L, I, L, I, I, P], I),
     "vrnet_gn_coef_fwd": ([P, P, P, F, I, L, I, P, P, P, P, P], I),
+    "vrnet_gn_stats_fwd": ([P, L, P, P, F, I, L, I, P, P, P, P, P, L, P], I),
     "vrnet_gn_coef_bwd": ([P, P, P, I, L, I, P, P, P, P, P, P, I, P], I),
     "vrnet_bn_coef_fwd": ([P, P, P, F, F, P, P, P, I, I, L, I, P, P, P, P, P], I),
     "vrnet_bn_coef_bwd": ([P, P, P, I, I, L, I, P, P, P, P, P, P, I, P], I),
@@ -174,6 +175,12 @@ def affine(out, ldo, B, HW, C, x1=None, ld1=0, A=None, D1=None, pre=0, masky=Non
 def gn_coef_fwd(mom, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd):
     _check(_lib.vrnet_gn_coef_fwd(ptr(mom), ptr(gamma), ptr(beta), eps, B, HW, C, ptr(A), ptr(Dc), ptr(S),
                                   ptr(mean_rstd), stream()), "gn_coef_fwd")
+
+
+def gn_stats_fwd(x, ldx, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd):
+    ws = _ws.get(_lib.vrnet_moments_workspace(B, HW, C), x.device)
+    _check(_lib.vrnet_gn_stats_fwd(ptr(x), ldx, ptr(gamma), ptr(beta), eps, B, HW, C, ptr(A), ptr(Dc), ptr(S),
+                                   ptr(mean_rstd), ptr(ws), ws.numel(), stream()), "gn_stats_fwd")
 
 
 def gn_coef_bwd(mom2, mean_rstd, gamma, B, HW, C, A, E, Dc, S, dgamma, dbeta, accumulate):

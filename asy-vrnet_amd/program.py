@@ -364,7 +364,7 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
 def gn_forward(rt, x, gn):
     B, HW, C = x.B, x.HW, x.C
     A, D, S, ms = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C), rt.buf(B, 2)
-    hip.gn_coef_fwd(hip.moments(x.t, x.ld, B, HW, C), gn.weight, gn.bias, gn.eps, B, HW, C, A, D, S, ms)
+    hip.gn_stats_fwd(x.t, x.ld, gn.weight, gn.bias, gn.eps, B, HW, C, A, D, S, ms)
     y = rt.new(x.B, x.H, x.W, C)
     hip.affine(y.t, C, B, HW, C, x1=x.t, ld1=x.ld, A=A, D1=D, S1=S, bstride=C)
     return y, ms

@@ -79,6 +79,11 @@ int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1,
 /* GroupNorm(1,C), eps 1e-5 (vr_coc.py:105-111): y = A*(x - S) + D with A,D,S [B][C]; mean_rstd [B][2]. */
 int vrnet_gn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, int B, long HW, int C,
                       float* A, float* D, float* S, float* mean_rstd, void* stream);
+/* vrnet_moments_f32 + vrnet_gn_coef_fwd in two launches (the per-sample totals come straight from the chunk partials);
+ * workspace as vrnet_moments_workspace. */
+int vrnet_gn_stats_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, int B, long HW, int C,
+                       float* A, float* D, float* S, float* mean_rstd, void* workspace, long workspace_bytes,
+                       void* stream);
 /* mom2 = moments(dy, x2 = x): dx = A*dy + E*(x - S) + D with A,E,D,S [B][C]; dgamma, dbeta [C]. */
 int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int B, long HW, int C,
                       float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,

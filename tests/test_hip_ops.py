@@ -184,6 +184,11 @@ def test_group_norm_chain(hip):
     out = torch.empty(B, H, W, C, device="cuda")
     hip.affine(out, C, B, H * W, C, x1=xg, ld1=C, A=A, D1=D, S1=S, bstride=C)
     close(nchw(out), y, what="gn fwd")
+    A1, D1, S1 = (torch.empty(B, C, device="cuda") for _ in range(3))          # statistics + coefficients in two launches
+    ms1 = torch.empty(B, 2, device="cuda")
+    hip.gn_stats_fwd(xg, C, gam.detach().cuda(), bet.detach().cuda(), 1e-5, B, H * W, C, A1, D1, S1, ms1)
+    for got, want, what in ((A1, A, "A"), (D1, D, "D"), (S1, S, "S"), (ms1, ms, "mean/rstd")):
+        close(got, want, tol=1e-6, what="gn_stats_fwd " + what)
     mom2 = hip.moments(gg, C, B, H * W, C, x2=xg, ldx2=C)
     A2, E2, D2, S2 = (torch.empty(B, C, device="cuda") for _ in range(4))
     dgam, dbet = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
