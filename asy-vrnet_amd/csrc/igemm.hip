@@ -63,96 +63,111 @@ __device__ __forceinline__ long igemm_row_index(const IgemmArgs& p, int m) {
 
 constexpr int STAGE_LD = 36;                       // epilogue staging tile: 32 rows x 36 floats per wave
 
+// One 32x32 accumulator tile (tile row `ti`, tile column `tj` of the wave's TM x TN grid).  A function of ONE
+// accumulator taken by value: looping `acc[i][j]` over runtime-looking indices (the compiler refuses to unroll a
+// loop that contains barriers) makes the whole accumulator array runtime-indexed, i.e. moves it to scratch.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32x16 acc, float* smem, int m0, int n0, int ti,
+                                                   int tj) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int khalf = lane >> 5;
+  // Row-contiguous float4 epilogue: each wave transposes one 32x32 accumulator tile through its private
+  // LDS staging tile, then 8 lanes cover one 128-byte output row segment (aux / residual loads and all
+  // stores are whole lines).  The main loop ended with a barrier, so the operand images can be reused.
+  float* stage = smem + wave * (32 * STAGE_LD);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * STAGE_LD + (lane & 31)] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int q = lane + 64 * t;
+    const int row = q >> 3, c4 = (q & 7) * 4;
+    const int m = m0 + wm * TM * 32 + ti * 32 + row;
+    const int n = n0 + wn * TN * 32 + tj * 32 + c4;
+    if (m < p.M && n < p.CN) {
+      const long mo = igemm_row_index(p, m);
+      f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * STAGE_LD + c4]);
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.aux) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + mo * p.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= vr_gelu_grad(a[e]);
+      }
+      if (p.ypre) *reinterpret_cast<f32x4*>(p.ypre + mo * p.ldypre + n) = v;
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = vr_gelu(v[e]);
+      }
+      if (p.res) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + mo * p.ldres + n);
+        if (p.res_scale) v = rv + *reinterpret_cast<const f32x4*>(p.res_scale + n) * v;
+        else v = rv + v;
+      }
+      f32x4* dst = reinterpret_cast<f32x4*>(p.y + mo * p.ldy + n);
+      if (p.accumulate) v += *dst;
+      *dst = v;
+    }
+  }
+  __syncthreads();
+}
+
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue_scalar(const IgemmArgs& p, const f32x16 acc, int m0, int n0, int ti, int tj) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int khalf = lane >> 5;
+  const long hw = (long)p.MH * p.MW;
+  const int n = n0 + wn * TN * 32 + tj * 32 + (lane & 31);
+  if (n >= p.CN) return;
+  const float bias = p.bias ? p.bias[n] : 0.f;
+  const float rsc = (p.res && p.res_scale) ? p.res_scale[n] : 1.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * TM * 32 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    if (m >= p.M) continue;
+    const long mo = igemm_row_index(p, m);
+    float v = acc[r] + bias;
+    if (p.aux) v *= vr_gelu_grad(p.aux[mo * p.ldaux + n]);
+    if (p.ypre) p.ypre[mo * p.ldypre + n] = v;
+    if (p.act == 1) v = fmaxf(v, 0.f);
+    else if (p.act == 2) v = vr_gelu(v);
+    if (p.res) v = p.res[mo * p.ldres + n] + rsc * v;
+    float* dst;
+    if (p.out_nchw) {
+      const long b = mo / hw, pix = mo - b * hw;
+      dst = p.y + ((b * p.out_ctot + p.out_coff + n) * hw + pix);
+    } else {
+      dst = p.y + mo * p.ldy + n;
+    }
+    if (p.accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
 // Epilogue shared by the igemm kernels.  C/D map of the 32x32 MFMA: col = lane & 31,
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  `smem` must hold 4 * 32 * STAGE_LD floats and no wave may
 // still be reading operand images from it (callers end their main loop with a barrier).
 template <int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int khalf = lane >> 5;
-  const long hw = (long)p.MH * p.MW;
+  static_assert(TM <= 2 && TN <= 2, "accumulator tiles are named explicitly");
   if (p.e_vec) {
-    // Row-contiguous float4 epilogue: each wave transposes one 32x32 accumulator tile through its private
-    // LDS staging tile, then 8 lanes cover one 128-byte output row segment (aux / residual loads and all
-    // stores are whole lines).  The main loop ended with a barrier, so the operand images can be reused.
-    float* stage = smem + wave * (32 * STAGE_LD);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * STAGE_LD + (lane & 31)] = acc[i][j][r];
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int q = lane + 64 * t;
-          const int row = q >> 3, c4 = (q & 7) * 4;
-          const int m = m0 + wm * TM * 32 + i * 32 + row;
-          const int n = n0 + wn * TN * 32 + j * 32 + c4;
-          if (m < p.M && n < p.CN) {
-            const long mo = igemm_row_index(p, m);
-            f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * STAGE_LD + c4]);
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.aux) {
-              const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + mo * p.ldaux + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] *= vr_gelu_grad(a[e]);
-            }
-            if (p.ypre) *reinterpret_cast<f32x4*>(p.ypre + mo * p.ldypre + n) = v;
-            if (p.act == 1) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (p.act == 2) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = vr_gelu(v[e]);
-            }
-            if (p.res) {
-              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + mo * p.ldres + n);
-              if (p.res_scale) v = rv + *reinterpret_cast<const f32x4*>(p.res_scale + n) * v;
-              else v = rv + v;
-            }
-            f32x4* dst = reinterpret_cast<f32x4*>(p.y + mo * p.ldy + n);
-            if (p.accumulate) v += *dst;
-            *dst = v;
-          }
-        }
-        __syncthreads();
-      }
+    igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[0][0], smem, m0, n0, 0, 0);
+    if constexpr (TN > 1) igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[0][1], smem, m0, n0, 0, 1);
+    if constexpr (TM > 1) {
+      igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[1][0], smem, m0, n0, 1, 0);
+      if constexpr (TN > 1) igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[1][1], smem, m0, n0, 1, 1);
     }
     return;
   }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-    if (n >= p.CN) continue;
-    const float bias = p.bias ? p.bias[n] : 0.f;
-    const float rsc = (p.res && p.res_scale) ? p.res_scale[n] : 1.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (m >= p.M) continue;
-        const long mo = igemm_row_index(p, m);
-        float v = acc[i][j][r] + bias;
-        if (p.aux) v *= vr_gelu_grad(p.aux[mo * p.ldaux + n]);
-        if (p.ypre) p.ypre[mo * p.ldypre + n] = v;
-        if (p.act == 1) v = fmaxf(v, 0.f);
-        else if (p.act == 2) v = vr_gelu(v);
-        if (p.res) v = p.res[mo * p.ldres + n] + rsc * v;
-        float* dst;
-        if (p.out_nchw) {
-          const long b = mo / hw, pix = mo - b * hw;
-          dst = p.y + ((b * p.out_ctot + p.out_coff + n) * hw + pix);
-        } else {
-          dst = p.y + mo * p.ldy + n;
-        }
-        if (p.accumulate) v += *dst;
-        *dst = v;
-      }
-    }
+  igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[0][0], m0, n0, 0, 0);
+  if constexpr (TN > 1) igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[0][1], m0, n0, 0, 1);
+  if constexpr (TM > 1) {
+    igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[1][0], m0, n0, 1, 0);
+    if constexpr (TN > 1) igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[1][1], m0, n0, 1, 1);
   }
 }
 
@@ -409,13 +424,20 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && BK == 16) ? 8 : 1) vo
 //     share an XCD), so the A rows are fetched into a single L2 once.
 __device__ __attribute__((aligned(128))) float vr_zero_page[64];
 
-template <int MODE, int NST>
-__global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p, int MT, int NT) {
-  constexpr int BM = 64, BN = 64, BK = 32;
+// T = 1: 64 x 64 x 32 tile, one 32x32 accumulator per wave (16 MFMAs per stage); T = 2: 128 x 128 x 16 tile, 2 x 2
+// accumulators per wave (32 MFMAs per stage, half the LDS-fill bytes and fragment reads per MFMA) for the layers
+// whose grid still fills the chip with 128-row tiles.  Both stage 16 KB per K step.
+template <int MODE, int NST, int T>
+__global__ __launch_bounds__(256, 3) void igemm_dma_kernel(const IgemmArgs p, int MT, int NT) {
+  constexpr int BM = 64 * T, BN = 64 * T, BK = 32 / T;
+  constexpr int QPR = BK / 4;                       // 16-byte quads per K-contiguous row of a stage
+  constexpr int KQ = QPR / 2;                       // quads each lane owns per stage (k = h*BK/2 .. +BK/2)
+  constexpr int RSH = QPR == 8 ? 1 : 2;             // swizzle: quad' = quad ^ ((row >> RSH) & (QPR - 1))
   constexpr int A_FLOATS = BM * BK, ST_FLOATS = A_FLOATS + BN * BK;
   constexpr int RING = NST * ST_FLOATS;
   constexpr int KS_MAX = 1024;                      // kscale copy (mode 1)
   static_assert(RING >= 4 * 32 * STAGE_LD, "epilogue staging must fit the ring");
+  static_assert(ST_FLOATS == 4096, "two 1 KB DMA pieces per wave and operand");
   // one LDS object only: a second __shared__ beside a DMA staging array makes hipcc drain vmcnt before ds_reads
   __shared__ __attribute__((aligned(16))) float smem[RING + 16 + (MODE == 1 ? KS_MAX : 0)];
   unsigned* tapmask_s = reinterpret_cast<unsigned*>(smem + RING);
@@ -428,15 +450,15 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p, int M
   if (mt >= MT) return;
   const int m0 = mt * BM, n0 = nt * BN;
   const int nkb = (p.CK + BK - 1) / BK;
-  const int T = p.kh * p.kw;
+  const int TAPS = p.kh * p.kw;
 
   // ---- loader roles: two 16-B slots of the A image and two of the B image per thread and stage
   int a_q[2], a_b[2], a_y[2], a_x[2];
   bool a_ok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int sl = (wave * 2 + i) * 64 + lane, r = sl >> 3;
-    a_q[i] = (sl & 7) ^ ((r >> 1) & 7);
+    const int sl = (wave * 2 + i) * 64 + lane, r = sl / QPR;
+    a_q[i] = (sl % QPR) ^ ((r >> RSH) & (QPR - 1));
     const int m = m0 + r;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
@@ -455,13 +477,13 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p, int M
     }
     return ok && sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;
   };
-  int ntaps = T;
-  const bool use_list = T > 1 && T <= 32;
+  int ntaps = TAPS;
+  const bool use_list = TAPS > 1 && TAPS <= 32;
   if (use_list) {      // block-uniform list of the taps that are live for at least one row of this tile
     if (tid == 0) *tapmask_s = 0u;
     __syncthreads();
     unsigned mine = 0u;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < TAPS; ++t) {
       const int ky = t / p.kw, kx = t - ky * p.kw;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p, int M
     if (tid == 0) {
       const unsigned mk = *tapmask_s;
       int c = 0;
-      for (int t = 0; t < T; ++t)
+      for (int t = 0; t < TAPS; ++t)
         if (mk & (1u << t)) taps_s[c++] = (unsigned char)t;
     }
     __syncthreads();
@@ -504,11 +526,11 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p, int M
     for (int i = 0; i < 2; ++i) {
       const int sl = (wave * 2 + i) * 64 + lane;
       if (MODE == 0) {           // rows n, contiguous contraction: same image as A
-        const int r = sl >> 3, q = (sl & 7) ^ ((r >> 1) & 7);
+        const int r = sl / QPR, q = (sl % QPR) ^ ((r >> RSH) & (QPR - 1));
         b_ptr[i] = (n0 + r < p.CN) ? wt + (long)(n0 + r) * p.Cin + 4 * q : nullptr;
         b_k[i] = 4 * q;
-      } else {                   // rows = contraction index, contiguous output channels: linear [32][64]
-        const int kr = sl >> 4, col = n0 + 4 * (sl & 15);
+      } else {                   // rows = contraction index, contiguous output channels: linear [BK][BN]
+        const int kr = sl / (BN / 4), col = n0 + 4 * (sl % (BN / 4));
         b_ptr[i] = (col < p.CN) ? wt + (long)kr * p.Cin + col : nullptr;
         b_k[i] = kr;
       }
@@ -542,13 +564,21 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p, int M
     if (++ld_buf == NST) ld_buf = 0;
   };
 
-  f32x16 acc[1][1];
+  f32x16 acc[T][T];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int h = lane >> 5;
-  const int ra = wm * 32 + (lane & 31), rb = wn * 32 + (lane & 31);
-  const int a_off = ra * 32, a_swz = (ra >> 1) & 7;
-  const int b_off = MODE == 0 ? rb * 32 : rb, b_swz = (rb >> 1) & 7;
+  int a_off[T], a_swz[T], b_off[T], b_swz[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const int ra = wm * 32 * T + 32 * i + (lane & 31), rb = wn * 32 * T + 32 * i + (lane & 31);
+    a_off[i] = ra * BK; a_swz[i] = (ra >> RSH) & (QPR - 1);
+    b_off[i] = MODE == 0 ? rb * BK : rb; b_swz[i] = (rb >> RSH) & (QPR - 1);
+  }
 
 #pragma unroll
   for (int st = 0; st < NST - 1; ++st)
@@ -567,35 +597,49 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs p, int M
     if (s + NST - 1 < nsteps) issue();      // into the slot every wave finished reading before this barrier
     const float* As = smem + cur * ST_FLOATS;
     const float* Bs = As + A_FLOATS;
-    f32x4 af[4], bq[4];
+    f32x4 af[T][KQ], bq[T][KQ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(As + a_off + 4 * ((4 * h + j) ^ a_swz));
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) af[i][j] = *reinterpret_cast<const f32x4*>(As + a_off[i] + 4 * ((KQ * h + j) ^ a_swz[i]));
     if (MODE == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const f32x4*>(Bs + b_off + 4 * ((4 * h + j) ^ b_swz));
+      for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) bq[i][j] = *reinterpret_cast<const f32x4*>(Bs + b_off[i] + 4 * ((KQ * h + j) ^ b_swz[i]));
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < T; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bq[j][e] = Bs[(16 * h + 4 * j + e) * 64 + b_off];
+        for (int j = 0; j < KQ; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bq[i][j][e] = Bs[(4 * KQ * h + 4 * j + e) * BN + b_off[i]];
       if (p.kscale) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = kb * BK + 16 * h + 4 * j;     // CK % 4 == 0: a quad is inside the stash or all-zero data
-          if (k < p.CK) bq[j] *= *reinterpret_cast<const f32x4*>(ks_s + k);
+        for (int j = 0; j < KQ; ++j) {
+          const int k = kb * BK + 4 * KQ * h + 4 * j;     // CK % 4 == 0: a quad is inside the stash or all-zero data
+          if (k < p.CK) {
+            const f32x4 ks = *reinterpret_cast<const f32x4*>(ks_s + k);
+#pragma unroll
+            for (int i = 0; i < T; ++i) bq[i][j] *= ks;
+          }
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < KQ; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], bq[j][e], acc[0][0], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+          for (int jn = 0; jn < T; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j][e], bq[jn][j][e], acc[i][jn], 0, 0, 0);
     if (++cur == NST) cur = 0;
     if (++kb == nkb) kb = 0;
   }
   __syncthreads();
-  igemm_epilogue<1, 1, 2, 2>(p, acc, smem, m0, n0);
+  igemm_epilogue<T, T, 2, 2>(p, acc, smem, m0, n0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1027,12 +1071,18 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   // per CU (M <= 8192 pixels: +5..40 %) and on long contractions; the register-staged kernel keeps the large-M,
   // short-K layers (2048 row tiles x few K steps: its 8 workgroups per CU hide the store-heavy epilogues better).
   const long ktot = (long)p.CK * kh * kw;
+  const bool dma_ok = use_dma && force_cfg < 0 && vec && p.CN > 32 && (!kscale || p.CK <= 1024);
+  // 64 x 64 ring tiles where the grid cannot fill the chip with 8 workgroups per CU (M <= 8192 pixels: +5..40 %) and
+  // on long contractions; the register-staged kernel keeps the large-M, short-K layers (2048 row tiles x few K steps:
+  // its 8 workgroups per CU hide the store-heavy epilogues better).  128 x 128 ring tiles (T = 2) were measured on the
+  // large-M layers with >= 768 such tiles: 4-11 % slower than either (K <= 256 there: prologue / epilogue bound), so
+  // they are not dispatched.  All measured with bench.py --detail.
   const bool dma_shape = use_dma == 2 || M <= 8192 || (M <= 32768 && ktot >= 1024);
-  if (use_dma && dma_shape && force_cfg < 0 && vec && p.CN > 32 && (!kscale || p.CK <= 1024)) {
+  if (dma_ok && dma_shape) {
     const int MT = (int)vr_cdiv(M, 64), NT = (int)vr_cdiv(p.CN, 64);
     dim3 grid((unsigned)(8 * vr_cdiv(MT, 8) * NT));
-    if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3>), grid, block, 0, st, p, MT, NT);
-    else hipLaunchKernelGGL((igemm_dma_kernel<1, 3>), grid, block, 0, st, p, MT, NT);
+    if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 1>), grid, block, 0, st, p, MT, NT);
+    else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 1>), grid, block, 0, st, p, MT, NT);
     VR_LAUNCH_CHECK("conv2d");
     return VR_OK;
   }
