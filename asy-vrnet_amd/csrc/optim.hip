@@ -88,6 +88,16 @@ __global__ __launch_bounds__(256) void mt_ema_kernel(MtArgs a, float d) {
   for (long i = lo + threadIdx.x; i < hi; i += 256) e[i] = e[i] * d + om * m[i];
 }
 
+// dst = src (multi-tensor copy): builds the concatenated fc1|fc_v weights of every Cluster in one launch
+__global__ __launch_bounds__(256) void mt_copy_kernel(MtArgs a) {
+  int t;
+  long lo, hi;
+  if (!mt_range(a, t, lo, hi)) return;
+  float* d = reinterpret_cast<float*>(a.addrs[t]);
+  const float* s = reinterpret_cast<const float*>(a.addrs[a.n + t]);
+  for (long i = lo + threadIdx.x; i < hi; i += 256) d[i] = s[i];
+}
+
 int mt_check(const char* name, const long long* addrs, const long* sizes, const int* ct, const int* ci, int n, int nc,
              int ce) {
   VR_CHECK_ARG(addrs && sizes && ct && ci && n > 0 && nc >= 0 && ce >= 256 && ce % 256 == 0, "%s: bad tensor table", name);
@@ -132,5 +142,16 @@ extern "C" int vrnet_mt_ema_f32(const long long* addrs, const long* sizes, const
   MtArgs a{addrs, sizes, chunk_tensor, chunk_index, nullptr, n_tensors, chunk_elems};
   hipLaunchKernelGGL(mt_ema_kernel, dim3(n_chunks), dim3(256), 0, vr_stream(stream), a, decay);
   VR_LAUNCH_CHECK("mt_ema");
+  return VR_OK;
+}
+
+extern "C" int vrnet_mt_copy_f32(const long long* addrs, const long* sizes, const int* chunk_tensor, const int* chunk_index,
+                                 int n_tensors, int n_chunks, int chunk_elems, void* stream) {
+  int rc = mt_check("mt_copy", addrs, sizes, chunk_tensor, chunk_index, n_tensors, n_chunks, chunk_elems);
+  if (rc) return rc;
+  if (n_chunks == 0) return VR_OK;
+  MtArgs a{addrs, sizes, chunk_tensor, chunk_index, nullptr, n_tensors, chunk_elems};
+  hipLaunchKernelGGL(mt_copy_kernel, dim3(n_chunks), dim3(256), 0, vr_stream(stream), a);
+  VR_LAUNCH_CHECK("mt_copy");
   return VR_OK;
 }

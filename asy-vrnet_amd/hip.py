@@ -73,6 +73,7 @@ _SIGS = {
     "vrnet_mt_sgd_f32": ([P, P, P, P, P, I, I, I, F, F, I, I, P], I),
     "vrnet_mt_adam_f32": ([P, P, P, P, P, I, I, I, F, F, F, F, I, P], I),
     "vrnet_mt_ema_f32": ([P, P, P, P, I, I, I, F, P], I),
+    "vrnet_mt_copy_f32": ([P, P, P, P, I, I, I, P], I),
     "vrnet_sa_bwd_f32": ([P, L, P, L, P, P, P, P] + [P] * 6 + [P, L] + [P] * 6 + [P, I, L, I, I, I, I, P, L, P], I),
 }
 for _name, (_args, _res) in _SIGS.items():
@@ -332,6 +333,11 @@ def mt_adam(addrs, sizes, chunk_tensor, chunk_index, weight_decay, n_tensors, n_
 def mt_ema(addrs, sizes, chunk_tensor, chunk_index, n_tensors, n_chunks, chunk_elems, decay):
     _check(_lib.vrnet_mt_ema_f32(ptr(addrs), ptr(sizes), ptr(chunk_tensor), ptr(chunk_index), n_tensors, n_chunks,
                                  chunk_elems, decay, stream()), "mt_ema")
+
+
+def mt_copy(addrs, sizes, chunk_tensor, chunk_index, n_tensors, n_chunks, chunk_elems):
+    _check(_lib.vrnet_mt_copy_f32(ptr(addrs), ptr(sizes), ptr(chunk_tensor), ptr(chunk_index), n_tensors, n_chunks,
+                                  chunk_elems, stream()), "mt_copy")
 
 
 def decode_outputs(levels, input_h, input_w, out):

@@ -446,13 +446,14 @@ def cluster_block(rt, x, m, name=None):
     E, Dh, fold = tm.heads, tm.head_dim, tm.fold
     ED = E * Dh
     xn, ms1 = gn_forward(rt, x, m.norm1)
-    f, v = rt.new(B, H, W, ED), rt.new(B, H, W, ED)
-    conv_call(rt, xn, tm.fc1, f)
-    conv_call(rt, xn, tm.fc_v, v)
+    wcat, bcat = rt.fused_qkv[tm]                                # [fc1 ; fc_v]: one GEMM, f | v side by side
+    fv = rt.new(B, H, W, 2 * ED)
+    hip.conv2d(xn.t, xn.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0)
+    f_t, v_t = fv.t, fv.t[..., ED:]
     o = rt.new(B, H, W, ED)
     idx = rt.buf(B, H, W, E, dtype=torch.uint8)
     big = (H // max(fold, 1)) * (W // max(fold, 1)) > 256       # streaming kernel keeps the similarity map
-    hip.cluster_fwd(f.t, v.t, ED, tm.sim_alpha, tm.sim_beta, o.t, ED, idx, rt.buf(B, H, W, E) if big else None,
+    hip.cluster_fwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, o.t, ED, idx, rt.buf(B, H, W, E) if big else None,
                     B, H, W, E, Dh, fold)
     if name is not None:
         rt.idx_maps[name] = idx
@@ -487,27 +488,48 @@ def cluster_block(rt, x, m, name=None):
         _ls_grads(rt, mom2, ls1, tm.fc2.bias, B, C)
         do = rt.new(B, H, W, ED)
         conv_backward(rt, o, tm.fc2, dx2, C, kscale=ls1, row_scale=ls1, skip_bias=True, dx_to=do, defer_ok=False)
-        df, dv = rt.new(B, H, W, ED), rt.new(B, H, W, ED)
+        dfv = rt.new(B, H, W, 2 * ED)
         ga, acca = rt.pgrad(tm.sim_alpha)
         gb, _ = rt.pgrad(tm.sim_beta)
         if ga is None:
             ga, acca = rt.buf(1), 0
         if gb is None:
             gb = rt.buf(1)
-        hip.cluster_bwd(f.t, v.t, ED, tm.sim_alpha, tm.sim_beta, idx, do.t, ED, df.t, dv.t, ED, ga, gb, acca, B, H, W, E,
-                        Dh, fold)
+        hip.cluster_bwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, idx, do.t, ED, dfv.t, dfv.t[..., ED:], 2 * ED, ga, gb,
+                        acca, B, H, W, E, Dh, fold)
         if rt.on_param_grad:
             rt.on_param_grad(tm.sim_alpha)
             rt.on_param_grad(tm.sim_beta)
-        dxn = rt.new(B, H, W, C)
-        conv_backward(rt, xn, tm.fc1, df.t, ED, dx_to=dxn)
-        xn.grad = dxn.t                                          # fc_v accumulates onto fc1's dx
-        xn.need_grad = True
-        conv_backward(rt, xn, tm.fc_v, dv.t, ED)
-        gn_backward(rt, m.norm1, x, ms1, take_grad(xn), dx2, accumulate=1)     # dx2 now holds dx
+        _fused_qkv_wgrad(rt, tm, xn, dfv, wcat)
+        dxn = rt.new(B, H, W, C)                                 # d xn = [df | dv] . [fc1 ; fc_v]: one data-gradient GEMM
+        hip.conv2d(dfv.t, 2 * ED, wcat, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1)
+        gn_backward(rt, m.norm1, x, ms1, dxn.t, dx2, accumulate=1)             # dx2 now holds dx
         rt.give_grad(x, dx2)
     rt.push(bwd)
     return x2
+
+
+def _fused_qkv_wgrad(rt, tm, xn, dfv, wcat):
+    """Weight / bias gradients of fc1 and fc_v as one GEMM into a scratch [2ED, C] | [2ED], then copied (or added)
+    into the four parameter gradients; deferred off the critical path like every other weight gradient."""
+    ed, c = tm.fc1.weight.shape[0], tm.fc1.weight.shape[1]
+    targets = [(tm.fc1.weight, 0, c), (tm.fc_v.weight, ed, c), (tm.fc1.bias, 0, 1), (tm.fc_v.bias, ed, 1)]
+    grads = [(prm,) + rt.pgrad(prm) + (row0, width) for prm, row0, width in targets]
+    if all(g is None for _, g, _, _, _ in grads):
+        return
+    B, H, W = xn.B, xn.H, xn.W
+
+    def wgrad():
+        gw, gbias = rt.buf(2 * ed, c), rt.buf(2 * ed)
+        hip.conv2d_wgrad(xn.t, xn.ld, dfv.t, 2 * ed, gw, gbias, None, B, H, W, c, H, W, 2 * ed, 1, 1, 1, 0, 1)
+        for prm, g, acc, row0, width in grads:
+            if g is None:
+                continue
+            src = gw[row0:] if width > 1 else gbias[row0:]
+            hip.copy_channels(src, width, 1, g, width, 1, ed, width, accumulate=acc)
+            if rt.on_param_grad:
+                rt.on_param_grad(prm)
+    rt.aside(wgrad, (xn.t, dfv.t))
 
 
 def _ls_grads(rt, mom2, ls, bias, B, C):
@@ -896,6 +918,46 @@ def head_forward(rt, hd, feats, det_outs):
     rt.parallel([(lambda k=k, x=x: level(k, x)) for k, x in enumerate(feats)])
 
 
+class FusedQKV:
+    """Concatenated [fc1 ; fc_v] weights and biases of every Cluster module (vr_coc.py:145-147): both 1x1 convs read
+    the same normalised input, so each block runs them as ONE GEMM with 2*E*D output channels (twice the tiles of the
+    small-M layers, the input read once) and their data / weight gradients as one GEMM each.  The copies are derived
+    caches (the state_dict keeps fc1 / fc_v): persistent buffers refreshed by one multi-tensor copy per forward."""
+
+    CHUNK = 4096
+
+    def __init__(self, model, device):
+        self.entries, dst, src = {}, [], []
+        for mod in model.modules():
+            tm = getattr(mod, "token_mixer", None)
+            if tm is None or not hasattr(tm, "fc_v"):
+                continue
+            ed, c = tm.fc1.weight.shape[0], tm.fc1.weight.shape[1]
+            w = torch.zeros((2 * ed, c), device=device)
+            b = torch.zeros((2 * ed,), device=device)
+            self.entries[tm] = (w, b)
+            dst += [w[:ed], w[ed:], b[:ed], b[ed:]]
+            src += [tm.fc1.weight, tm.fc_v.weight, tm.fc1.bias, tm.fc_v.bias]
+        self.dst, self.src, self.key = dst, src, None
+
+    def refresh(self):
+        key = tuple(t.data_ptr() for t in self.src)
+        if key != self.key:
+            dev = self.dst[0].device
+            sizes = [t.numel() for t in self.dst]
+            ct, ci = [], []
+            for i, n in enumerate(sizes):
+                k = (n + self.CHUNK - 1) // self.CHUNK
+                ct += [i] * k
+                ci += list(range(k))
+            self.addrs = torch.tensor([t.data_ptr() for t in self.dst] + list(key), dtype=torch.int64, device=dev)
+            self.sizes = torch.tensor(sizes, dtype=torch.int64, device=dev)
+            self.ct = torch.tensor(ct, dtype=torch.int32, device=dev)
+            self.ci = torch.tensor(ci, dtype=torch.int32, device=dev)
+            self.n, self.nc, self.key = len(sizes), len(ct), key
+        hip.mt_copy(self.addrs, self.sizes, self.ct, self.ci, self.n, self.nc, self.CHUNK)
+
+
 class _VRNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, x_radar, *params):
@@ -912,6 +974,11 @@ class _VRNetFunction(torch.autograd.Function):
         rt.bucketer = getattr(model, "_grad_bucketer", None)
         rt.aside_ok = rt.bucketer is None or rt.bucketer.deferred
         rt.on_param_grad = getattr(model, "_on_param_grad", None) if rt.bucketer is not None else None
+        fq = getattr(model, "_fused_qkv", None)
+        if fq is None or fq.dst[0].device != x.device:
+            fq = model._fused_qkv = FusedQKV(model, x.device)
+        fq.refresh()
+        rt.fused_qkv = fq.entries
         xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=ctx.needs_input_grad[1])
         ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=ctx.needs_input_grad[2])
         hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)

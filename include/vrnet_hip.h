@@ -204,6 +204,10 @@ int vrnet_mt_adam_f32(const long long* addrs, const long* sizes, const int* chun
                       float beta2, float eps, int step, void* stream);
 int vrnet_mt_ema_f32(const long long* addrs, const long* sizes, const int* chunk_tensor, const int* chunk_index,
                      int n_tensors, int n_chunks, int chunk_elems, float decay, void* stream);
+/* roles {dst, src}: dst = src for every tensor of the table in one launch (the concatenated fc1 | fc_v weights of all
+ * Cluster modules, vr_coc.py:145-147, so that both 1x1 convs of a block run as one GEMM). */
+int vrnet_mt_copy_f32(const long long* addrs, const long* sizes, const int* chunk_tensor, const int* chunk_index,
+                      int n_tensors, int n_chunks, int chunk_elems, void* stream);
 
 /* ---- box decode ----------------------------------------------------------------------------
  * decode_outputs, utils/utils_bbox.py:32-84: levels[l] = raw head map (B, C = 5+num_classes, hs[l], ws[l]) NCHW (the
