@@ -8,7 +8,7 @@ from oracle import vrnet_oracle as O
 def rnd(*shape, seed=0):
     return torch.from_numpy(np.random.default_rng([seed, len(shape)] + list(shape)).standard_normal(shape).astype(np.float32))
 
-for case in [(2, 4, 32, 4, 4, 1), (2, 4, 32, 8, 8, 2), (2, 4, 24, 4, 4, 2), (2, 4, 32, 32, 32, 2), (2, 8, 32, 16, 16, 1)]:
+for case in [(4, 4, 24, 8, 8, 2), (4, 4, 24, 16, 16, 2), (2, 4, 32, 4, 4, 1), (2, 4, 32, 8, 8, 2), (2, 4, 24, 4, 4, 2), (2, 4, 32, 32, 32, 2), (2, 8, 32, 16, 16, 1)]:
     B, E, D, H, W, fold = case
     f, v, g = rnd(B, E * D, H, W, seed=1), rnd(B, E * D, H, W, seed=2), rnd(B, E * D, H, W, seed=3)
     alpha, beta = torch.tensor([1.3]), torch.tensor([-0.2])
