@@ -510,16 +510,23 @@ __global__ __launch_bounds__(256, 3) void igemm_dma_kernel(const IgemmArgs p, in
   }
   const int nsteps = ntaps * nkb;
 
-  const float* a_ptr[2];
-  const float* b_ptr[2];
-  int b_k[2];
+  // Per tap: a running source pointer and a per-stage advance for each of the thread's four DMA slots.  Slots that
+  // are masked for the whole tap (row outside the tile / image, padded tap, channel quad beyond CK or CN) point at
+  // the zero page and do not advance, so a stage issues with two 64-bit adds per slot and no compares; only the
+  // last K block of a tap whose contraction is not a multiple of BK re-checks the quad against CK.
+  const float* a_run[2];
+  const float* b_run[2];
+  int a_inc[2], b_inc[2], a_k[2], b_k[2];
+  const bool k_tail = (p.CK % BK) != 0;
   auto setup_tap = [&](int t) {
     const int ky = t / p.kw, kx = t - ky * p.kw;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int sy, sx;
-      const bool ok = src_of(i, ky, kx, sy, sx);
-      a_ptr[i] = ok ? p.a + ((long)(a_b[i] * p.SH + sy) * p.SW + sx) * p.lda + 4 * a_q[i] : nullptr;
+      const bool ok = src_of(i, ky, kx, sy, sx) && 4 * a_q[i] < p.CK;
+      a_run[i] = ok ? p.a + ((long)(a_b[i] * p.SH + sy) * p.SW + sx) * p.lda + 4 * a_q[i] : vr_zero_page;
+      a_inc[i] = ok ? BK : 0;
+      a_k[i] = 4 * a_q[i];
     }
     const float* wt = p.w + (long)t * p.wtap;
 #pragma unroll
@@ -527,11 +534,15 @@ __global__ __launch_bounds__(256, 3) void igemm_dma_kernel(const IgemmArgs p, in
       const int sl = (wave * 2 + i) * 64 + lane;
       if (MODE == 0) {           // rows n, contiguous contraction: same image as A
         const int r = sl / QPR, q = (sl % QPR) ^ ((r >> RSH) & (QPR - 1));
-        b_ptr[i] = (n0 + r < p.CN) ? wt + (long)(n0 + r) * p.Cin + 4 * q : nullptr;
+        const bool ok = n0 + r < p.CN && 4 * q < p.CK;
+        b_run[i] = ok ? wt + (long)(n0 + r) * p.Cin + 4 * q : vr_zero_page;
+        b_inc[i] = ok ? BK : 0;
         b_k[i] = 4 * q;
       } else {                   // rows = contraction index, contiguous output channels: linear [BK][BN]
         const int kr = sl / (BN / 4), col = n0 + 4 * (sl % (BN / 4));
-        b_ptr[i] = (col < p.CN) ? wt + (long)kr * p.Cin + col : nullptr;
+        const bool ok = col < p.CN && kr < p.CK;
+        b_run[i] = ok ? wt + (long)kr * p.Cin + col : vr_zero_page;
+        b_inc[i] = ok ? BK * p.Cin : 0;
         b_k[i] = kr;
       }
     }
@@ -540,22 +551,23 @@ __global__ __launch_bounds__(256, 3) void igemm_dma_kernel(const IgemmArgs p, in
   int ld_ti = 0, ld_kb = 0, ld_buf = 0;       // (tap index, k block, ring slot) of the NEXT stage to issue
   auto issue = [&]() {
     if (ld_kb == 0) setup_tap(use_list ? (int)taps_s[ld_ti] : ld_ti);
-    const int c0 = ld_kb * BK;
     float* stage = smem + ld_buf * ST_FLOATS;
+    const bool last = k_tail && ld_kb == nkb - 1;          // block-uniform
+    const int c0 = ld_kb * BK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float* src = (a_ptr[i] != nullptr && c0 + 4 * a_q[i] < p.CK) ? a_ptr[i] + c0 : vr_zero_page;
+      const float* src = (last && c0 + a_k[i] >= p.CK) ? vr_zero_page : a_run[i];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(stage + (wave * 2 + i) * 256), 16, 0, 0);
+      a_run[i] += a_inc[i];
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float* src;
-      if (MODE == 0) src = (b_ptr[i] != nullptr && c0 + b_k[i] < p.CK) ? b_ptr[i] + c0 : vr_zero_page;
-      else src = (b_ptr[i] != nullptr && c0 + b_k[i] < p.CK) ? b_ptr[i] + (long)c0 * p.Cin : vr_zero_page;
+      const float* src = (last && c0 + b_k[i] >= p.CK) ? vr_zero_page : b_run[i];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(stage + A_FLOATS + (wave * 2 + i) * 256),
                                        16, 0, 0);
+      b_run[i] += b_inc[i];
     }
     if (++ld_kb == nkb) {
       ld_kb = 0;
