@@ -16,7 +16,7 @@ namespace {
 template <int VEC>
 __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, const float* x2, long ldx2,
                                                       const float* mask, long ldm, long HW, int C, int TPR,
-                                                      long rows_per_chunk, int nchunks, double* partial) {
+                                                      long rows_per_chunk, int nchunks, double* partial, int total_only) {
   extern __shared__ double sm[];   // [256][2*VEC]
   const int tid = threadIdx.x;
   const int tx = tid % TPR, ty = tid / TPR, RP = 256 / TPR;
@@ -74,6 +74,18 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, 
       load(r, a, c2, mk);
       accum(a, c2, mk);
     }
+  }
+  if (total_only) {       // GroupNorm(1, C) forward: only the per-sample totals are needed -> one pair per workgroup
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { t1 += s1[j]; t2 += s2[j]; }
+    t1 = wave_sum(t1);
+    t2 = wave_sum(t2);
+    if ((tid & 63) == 0) { sm[2 * (tid >> 6)] = t1; sm[2 * (tid >> 6) + 1] = t2; }
+    __syncthreads();
+    if (tid < 2)
+      partial[(((long)b * nchunks + chunk) * gridDim.z + blockIdx.z) * 2 + tid] = sm[tid] + sm[2 + tid] + sm[4 + tid] + sm[6 + tid];
+    return;
   }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
@@ -231,9 +243,9 @@ __global__ __launch_bounds__(256) void gn_coef_fwd_kernel(const double* mom, con
   }
 }
 
-// GroupNorm(1, C) forward statistics straight from the moments kernel's per-chunk partials: the per-sample totals
-// are flat sums over (chunk, channel), so the cross-chunk reduce kernel and the per-channel table are skipped (one
-// launch instead of two on the critical path of every block).
+// GroupNorm(1, C) forward statistics straight from the moments kernel: in `total_only` mode every workgroup of the
+// moments kernel emits one (sum, sum of squares) pair, and this kernel adds the <= 512 pairs of a sample and writes
+// the coefficients -- the cross-chunk reduce launch and the per-channel table are skipped.
 __global__ __launch_bounds__(256) void gn_coef_fwd_partial_kernel(const double* partial, long pairs, const float* gamma,
                                                                   const float* beta, float eps, long HW, int C, float* A,
                                                                   float* D, float* S, float* mean_rstd) {
@@ -519,7 +531,8 @@ extern "C" long vrnet_moments_workspace(int B, long HW, int C) {
 }
 
 static int moments_launch(const float* x, long ldx, const float* x2, long ldx2, const float* mask, long ldm, int B,
-                          long HW, int C, void* workspace, long workspace_bytes, hipStream_t st, int* nchunks_out) {
+                          long HW, int C, void* workspace, long workspace_bytes, hipStream_t st, int* nchunks_out,
+                          int total_only = 0) {
   VR_CHECK_ARG(x && workspace, "moments: null tensor");
   VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && ldx >= C, "moments: bad shape");
   bool vec = (C % 4 == 0) && (ldx % 4 == 0) && vr_aligned16(x);
@@ -536,12 +549,12 @@ static int moments_launch(const float* x, long ldx, const float* x2, long ldx2, 
   dim3 grid(nchunks, B, ncb), block(256);
   if (vec)
     hipLaunchKernelGGL((moments_kernel<4>), grid, block, 256 * 8 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
-                       TPR, rows, nchunks, partial);
+                       TPR, rows, nchunks, partial, total_only);
   else
     hipLaunchKernelGGL((moments_kernel<1>), grid, block, 256 * 2 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
-                       TPR, rows, nchunks, partial);
+                       TPR, rows, nchunks, partial, total_only);
   VR_LAUNCH_CHECK("moments");
-  *nchunks_out = nchunks;
+  *nchunks_out = total_only ? nchunks * ncb : nchunks;
   return VR_OK;
 }
 
@@ -566,10 +579,10 @@ extern "C" int vrnet_gn_stats_fwd(const float* x, long ldx, const float* gamma, 
   VR_CHECK_ARG(gamma && beta && A && D && S && mean_rstd, "gn_stats_fwd: null tensor");
   hipStream_t st = vr_stream(stream);
   int nchunks;
-  int rc = moments_launch(x, ldx, nullptr, 0, nullptr, 0, B, HW, C, workspace, workspace_bytes, st, &nchunks);
+  int rc = moments_launch(x, ldx, nullptr, 0, nullptr, 0, B, HW, C, workspace, workspace_bytes, st, &nchunks, 1);
   if (rc) return rc;
   hipLaunchKernelGGL(gn_coef_fwd_partial_kernel, dim3(B), dim3(256), 0, st, reinterpret_cast<double*>(workspace),
-                     (long)nchunks * C, gamma, beta, eps, HW, C, A, D, S, mean_rstd);
+                     (long)nchunks, gamma, beta, eps, HW, C, A, D, S, mean_rstd);
   VR_LAUNCH_CHECK("gn_stats_fwd");
   return VR_OK;
 }

@@ -514,10 +514,22 @@ def _fused_qkv_wgrad(rt, tm, xn, dfv, wcat):
     into the four parameter gradients; deferred off the critical path like every other weight gradient."""
     ed, c = tm.fc1.weight.shape[0], tm.fc1.weight.shape[1]
     targets = [(tm.fc1.weight, 0, c), (tm.fc_v.weight, ed, c), (tm.fc1.bias, 0, 1), (tm.fc_v.bias, ed, 1)]
+    B, H, W = xn.B, xn.H, xn.W
+    fresh = rt.bucketer is None and all(prm.requires_grad and prm not in rt.pgrads for prm, _, _ in targets)
+    if fresh:
+        # no gradient buffer exists yet for any of the four: hand out views of one [2ED, C] | [2ED] pair, so the GEMM
+        # writes the parameter gradients in place (no scatter copies)
+        gw, gbias = rt.buf(2 * ed, c), rt.buf(2 * ed)
+        rt.pgrads[tm.fc1.weight], rt.pgrads[tm.fc_v.weight] = gw[:ed].view_as(tm.fc1.weight), gw[ed:].view_as(tm.fc_v.weight)
+        rt.pgrads[tm.fc1.bias], rt.pgrads[tm.fc_v.bias] = gbias[:ed], gbias[ed:]
+
+        def wgrad_direct():
+            hip.conv2d_wgrad(xn.t, xn.ld, dfv.t, 2 * ed, gw, gbias, None, B, H, W, c, H, W, 2 * ed, 1, 1, 1, 0, 1)
+        rt.aside(wgrad_direct, (xn.t, dfv.t))
+        return
     grads = [(prm,) + rt.pgrad(prm) + (row0, width) for prm, row0, width in targets]
     if all(g is None for _, g, _, _, _ in grads):
         return
-    B, H, W = xn.B, xn.H, xn.W
 
     def wgrad():
         gw, gbias = rt.buf(2 * ed, c), rt.buf(2 * ed)
