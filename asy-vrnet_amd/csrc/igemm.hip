@@ -32,6 +32,8 @@ struct IgemmArgs {
   long wtap;   // Cout*Cin
   int Cin;
   int perm2;   // data gradient of a stride-2 conv: GEMM rows enumerate the 4 pixel parity classes one after another
+  double* stats;   // [ceil(M/32)][ceil(CN/32)][2]: (sum, sum of squares) of the stored outputs per 32x32 tile, or NULL
+  int stats_nb;    // ceil(CN/32)
 };
 
 // GEMM row -> (sample, y, x) of the M-side pixel grid.  With perm2 the rows are parity-major: class (y&1, x&1)
@@ -79,6 +81,7 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
 #pragma unroll
   for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * STAGE_LD + (lane & 31)] = acc[r];
   __syncthreads();
+  double st1 = 0.0, st2 = 0.0;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int q = lane + 64 * t;
@@ -110,6 +113,23 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
       f32x4* dst = reinterpret_cast<f32x4*>(p.y + mo * p.ldy + n);
       if (p.accumulate) v += *dst;
       *dst = v;
+      if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          st1 += (double)v[e];
+          st2 += (double)v[e] * (double)v[e];
+        }
+      }
+    }
+  }
+  if (p.stats) {      // statistics of exactly what was stored (fp64, as the moments kernel): GroupNorm of the consumer
+    st1 = wave_sum(st1);
+    st2 = wave_sum(st2);
+    const int mb = (m0 + wm * TM * 32 + ti * 32) >> 5, nb = (n0 + wn * TN * 32 + tj * 32) >> 5;
+    if (lane == 0 && mb * 32 < p.M && nb < p.stats_nb) {
+      double* d = p.stats + ((long)mb * p.stats_nb + nb) * 2;
+      d[0] = st1;
+      d[1] = st2;
     }
   }
   __syncthreads();
@@ -1010,7 +1030,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                                 int pad, int dil, int mode, int act, float* ypre, long ldypre, const float* res,
                                 long ldres, const float* res_scale, const float* kscale, const float* aux,
                                 long ldaux, int out_nchw, int out_ctot, int out_coff, int accumulate,
-                                void* stream) {
+                                double* stats, void* stream) {
   VR_CHECK_ARG(a && w && y, "conv2d: null tensor");
   VR_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0, "conv2d: bad shape");
   VR_CHECK_ARG(kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d: bad geometry");
@@ -1018,7 +1038,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                    (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1 == OW,
                "conv2d: output size %dx%d inconsistent with input %dx%d k%d s%d p%d d%d", OH, OW, H, W, kh,
                stride, pad, dil);
-  const bool plain = !ypre && !res && !kscale && !aux && !out_nchw && act == 0;
+  const bool plain = !ypre && !res && !kscale && !aux && !out_nchw && act == 0 && !stats;
   if (plain && tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride))
     return vr_tiny_conv(mode, a, lda, w, mode == 0 ? bias : nullptr, y, ldy, B, H, W, Cin, Cout, kh, pad, dil, accumulate,
                         vr_stream(stream));
@@ -1048,6 +1068,11 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
             (!bias || vr_aligned16(bias)) && (!ypre || ((ldypre % 4 == 0) && vr_aligned16(ypre))) &&
             (!res || ((ldres % 4 == 0) && vr_aligned16(res))) && (!res_scale || vr_aligned16(res_scale)) &&
             (!aux || ((ldaux % 4 == 0) && vr_aligned16(aux)));
+  p.stats = stats;
+  p.stats_nb = (int)vr_cdiv(p.CN, 32);
+  VR_CHECK_ARG(!stats || (p.e_vec && !p.perm2 && mode == 0 && ((long)p.MH * p.MW) % 32 == 0 && p.CN > 32),
+               "conv2d: output statistics need the vector epilogue, a forward conv, > 32 output channels and a map of a "
+               "multiple of 32 pixels");
   dim3 block(256);
   hipStream_t st = vr_stream(stream);
   // Tile choice: 128-row tiles while they fill the chip (256 CUs x >= 2 workgroups); otherwise 64 x 64 tiles,

@@ -573,6 +573,16 @@ extern "C" int vrnet_moments_f32(const float* x, long ldx, const float* x2, long
   return VR_OK;
 }
 
+extern "C" int vrnet_gn_coef_from_pairs(const double* pairs, long pairs_per_sample, const float* gamma, const float* beta,
+                                        float eps, int B, long HW, int C, float* A, float* D, float* S, float* mean_rstd,
+                                        void* stream) {
+  VR_CHECK_ARG(pairs && pairs_per_sample > 0 && gamma && beta && A && D && S && mean_rstd, "gn_coef_from_pairs: bad arguments");
+  hipLaunchKernelGGL(gn_coef_fwd_partial_kernel, dim3(B), dim3(256), 0, vr_stream(stream), pairs, pairs_per_sample, gamma, beta,
+                     eps, HW, C, A, D, S, mean_rstd);
+  VR_LAUNCH_CHECK("gn_coef_from_pairs");
+  return VR_OK;
+}
+
 extern "C" int vrnet_gn_stats_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, int B,
                                   long HW, int C, float* A, float* D, float* S, float* mean_rstd, void* workspace,
                                   long workspace_bytes, void* stream) {

@@ -25,7 +25,7 @@ _SIGS = {
     "vrnet_abi_version": ([], I),
     "vrnet_last_error": ([], ctypes.c_char_p),
     "vrnet_device_arch": ([ctypes.c_char_p, I], I),
-    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P], I),
+    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, P], I),
     "vrnet_conv2d_wgrad_workspace": ([I] * 7, L),
     "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 13 + [P, L, P], I),
     "vrnet_pack_weight_f32": ([P, P, I, I, I, I, P], I),
@@ -33,6 +33,7 @@ _SIGS = {
     "vrnet_moments_f32": ([P, L, P, L, P, L, I, L, I, P, P, L, P], I),
     "vrnet_affine_f32": ([P, L, P, P, P, I, P, L, P, L, P, P, P, L, P, L, I, L, I, I, P], I),
     "vrnet_gn_coef_fwd": ([P, P, P, F, I, L, I, P, P, P, P, P], I),
+    "vrnet_gn_coef_from_pairs": ([P, L, P, P, F, I, L, I, P, P, P, P, P], I),
     "vrnet_gn_stats_fwd": ([P, L, P, P, F, I, L, I, P, P, P, P, P, L, P], I),
     "vrnet_gn_coef_bwd": ([P, P, P, I, L, I, P, P, P, P, P, P, I, P], I),
     "vrnet_bn_coef_fwd": ([P, P, P, F, F, P, P, P, I, I, L, I, P, P, P, P, P], I),
@@ -138,11 +139,19 @@ _ws = Workspace()
 # --------------------------------------------------------------------------------------- wrappers
 def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, mode=0, act=0,
            ypre=None, ldypre=0, res=None, ldres=0, res_scale=None, kscale=None, aux=None, ldaux=0,
-           out_nchw=0, out_ctot=0, out_coff=0, accumulate=0):
+           out_nchw=0, out_ctot=0, out_coff=0, accumulate=0, stats=None):
     _check(_lib.vrnet_conv2d_f32(ptr(a), lda, ptr(w), ptr(bias), ptr(y), ldy, B, H, W, Cin, OH, OW, Cout, kh, kw,
                                  stride, pad, dil, mode, act, ptr(ypre), ldypre, ptr(res), ldres, ptr(res_scale),
-                                 ptr(kscale), ptr(aux), ldaux, out_nchw, out_ctot, out_coff, accumulate, stream()),
-           "conv2d")
+                                 ptr(kscale), ptr(aux), ldaux, out_nchw, out_ctot, out_coff, accumulate, ptr(stats),
+                                 stream()), "conv2d")
+
+
+def conv_stats_buffer(B, HW, Cout, device):
+    """(buffer, pairs per sample) for the `stats` output of conv2d, or (None, 0) when the shape does not qualify."""
+    if HW % 32 or Cout <= 32 or Cout % 4:
+        return None, 0
+    nb = (Cout + 31) // 32
+    return torch.empty((B * HW // 32, nb, 2), dtype=torch.float64, device=device), (HW // 32) * nb
 
 
 def conv2d_wgrad(x, ldx, dy, lddy, dw, dbias, row_scale, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil,
@@ -176,6 +185,11 @@ def affine(out, ldo, B, HW, C, x1=None, ld1=0, A=None, D1=None, pre=0, masky=Non
 def gn_coef_fwd(mom, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd):
     _check(_lib.vrnet_gn_coef_fwd(ptr(mom), ptr(gamma), ptr(beta), eps, B, HW, C, ptr(A), ptr(Dc), ptr(S),
                                   ptr(mean_rstd), stream()), "gn_coef_fwd")
+
+
+def gn_coef_from_pairs(pairs, per_sample, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd):
+    _check(_lib.vrnet_gn_coef_from_pairs(ptr(pairs), per_sample, ptr(gamma), ptr(beta), eps, B, HW, C, ptr(A), ptr(Dc),
+                                         ptr(S), ptr(mean_rstd), stream()), "gn_coef_from_pairs")
 
 
 def gn_stats_fwd(x, ldx, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd):

@@ -19,10 +19,11 @@ from . import modules as M
 
 class Act:
     """NHWC activation: `t` is a (B,H,W,C) tensor or channel-slice view; row stride `ld` floats."""
-    __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad")
+    __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad", "pairs")
 
     def __init__(self, t, need_grad=True):
         self.t = t
+        self.pairs = None       # (fp64 (sum, sumsq) pairs, pairs per sample) emitted by the conv that produced `t`
         self.B, self.H, self.W, self.C = t.shape
         self.ld = t.stride(2)
         self.grad = None
@@ -262,14 +263,18 @@ def conv_geom(x, conv):
     return co, ci, kh, kw, s, p, d, OH, OW
 
 
-def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw=None, bias=True):
+def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw=None, bias=True, stats=False):
     """out: Act (NHWC target) or, with nchw=(tensor, ctot, coff), a channel range of an NCHW tensor."""
     co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, conv)
     b = conv.bias if bias else None
     if nchw is None:
+        pairs, per = hip.conv_stats_buffer(x.B, OH * OW, co, x.t.device) if stats else (None, 0)
         hip.conv2d(x.t, x.ld, rt.weight(conv), b, out.t, out.ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
                    mode=0, act=act, ypre=None if ypre is None else ypre.t, ldypre=0 if ypre is None else ypre.ld,
-                   res=None if res is None else res.t, ldres=0 if res is None else res.ld, res_scale=res_scale)
+                   res=None if res is None else res.t, ldres=0 if res is None else res.ld, res_scale=res_scale,
+                   stats=pairs)
+        if pairs is not None:       # statistics of the stored output: the consumer's GroupNorm skips its moments pass
+            out.pairs = (pairs, per)
     else:
         t, ctot, coff = nchw
         hip.conv2d(x.t, x.ld, rt.weight(conv), b, t, 0, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=0, act=act,
@@ -364,7 +369,10 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
 def gn_forward(rt, x, gn):
     B, HW, C = x.B, x.HW, x.C
     A, D, S, ms = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C), rt.buf(B, 2)
-    hip.gn_stats_fwd(x.t, x.ld, gn.weight, gn.bias, gn.eps, B, HW, C, A, D, S, ms)
+    if x.pairs is not None:
+        hip.gn_coef_from_pairs(x.pairs[0], x.pairs[1], gn.weight, gn.bias, gn.eps, B, HW, C, A, D, S, ms)
+    else:
+        hip.gn_stats_fwd(x.t, x.ld, gn.weight, gn.bias, gn.eps, B, HW, C, A, D, S, ms)
     y = rt.new(x.B, x.H, x.W, C)
     hip.affine(y.t, C, B, HW, C, x1=x.t, ld1=x.ld, A=A, D1=D, S1=S, bstride=C)
     return y, ms
@@ -459,7 +467,7 @@ def cluster_block(rt, x, m, name=None):
         rt.idx_maps[name] = idx
     t1 = rt.new(B, H, W, C) if rt.record else None
     x1 = rt.new(B, H, W, C)
-    conv_call(rt, o, tm.fc2, x1, ypre=t1, res=x, res_scale=m.layer_scale_1)
+    conv_call(rt, o, tm.fc2, x1, ypre=t1, res=x, res_scale=m.layer_scale_1, stats=True)
     xn2, ms2 = gn_forward(rt, x1, m.norm2)
     hid = mlp.fc1.weight.shape[0]
     u = rt.new(B, H, W, hid) if rt.record else None
@@ -467,7 +475,7 @@ def cluster_block(rt, x, m, name=None):
     conv_call(rt, xn2, mlp.fc1, h, act=2, ypre=u)
     t2 = rt.new(B, H, W, C) if rt.record else None
     x2 = rt.new(B, H, W, C)
-    conv_call(rt, h, mlp.fc2, x2, ypre=t2, res=x1, res_scale=m.layer_scale_2)
+    conv_call(rt, h, mlp.fc2, x2, ypre=t2, res=x1, res_scale=m.layer_scale_2, stats=True)
 
     def bwd():
         dx2 = take_grad(x2)                                      # owned; becomes dx1, then dx

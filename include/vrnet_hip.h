@@ -38,12 +38,15 @@ int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sram
  *   v = acc + bias[n];  v *= gelu'(aux[m,n]) (Mlp backward);  ypre[m,n] = v (pre-activation / branch output);
  *   act: 1 ReLU, 2 exact-erf GELU;  v = res[m,n] + res_scale[n] * v (layer-scale residual, vr_coc.py:266-271);
  *   store NHWC y[m*ldy+n] or NCHW y[b][out_coff+n][pix] of a (B,out_ctot,OH,OW) tensor (head cat, decouplehead.py:86).
- * kscale[k]: multiplies the contraction channels of `a` (layer scale folded into the data gradient). */
+ * kscale[k]: multiplies the contraction channels of `a` (layer scale folded into the data gradient).
+ * stats (NULL = none; forward, NHWC, Cout > 32, OH*OW % 32 == 0): [ceil(M/32)][ceil(Cout/32)][2] fp64 (sum, sum of
+ *   squares) of the STORED outputs per 32-row x 32-channel tile -- the GroupNorm statistics of the consumer
+ *   (vrnet_gn_coef_from_pairs: OH*OW/32 * ceil(Cout/32) consecutive pairs per sample) without another pass over y. */
 int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias, float* y, long ldy,
                      int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride, int pad,
                      int dil, int mode, int act, float* ypre, long ldypre, const float* res, long ldres,
                      const float* res_scale, const float* kscale, const float* aux, long ldaux, int out_nchw,
-                     int out_ctot, int out_coff, int accumulate, void* stream);
+                     int out_ctot, int out_coff, int accumulate, double* stats, void* stream);
 
 /* Weight (+ bias) gradient of the same convolutions (autograd of nn.Conv2d): dw in OIHW layout
  * [Cout][Cin][kh][kw], dbias[Cout] (NULL = none), both scaled by row_scale[Cout] when given (layer scale).
@@ -79,6 +82,10 @@ int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1,
 /* GroupNorm(1,C), eps 1e-5 (vr_coc.py:105-111): y = A*(x - S) + D with A,D,S [B][C]; mean_rstd [B][2]. */
 int vrnet_gn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, int B, long HW, int C,
                       float* A, float* D, float* S, float* mean_rstd, void* stream);
+/* The same coefficients from (sum, sum of squares) pairs, pairs_per_sample consecutive pairs per sample (the `stats`
+ * output of vrnet_conv2d_f32). */
+int vrnet_gn_coef_from_pairs(const double* pairs, long pairs_per_sample, const float* gamma, const float* beta, float eps,
+                             int B, long HW, int C, float* A, float* D, float* S, float* mean_rstd, void* stream);
 /* vrnet_moments_f32 + vrnet_gn_coef_fwd in two launches (the per-sample totals come straight from the chunk partials);
  * workspace as vrnet_moments_workspace. */
 int vrnet_gn_stats_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, int B, long HW, int C,

@@ -486,3 +486,32 @@ def test_patch_embed_as_gather_gemm(hip, C, k):
     dx = torch.full((B, H, W, C), 0.25, device="cuda")
     hip.patch_scatter(dp, dx, C, B, H, W, C, CP, k, accumulate=1)
     close(nchw(dx) - 0.25, x.grad, what="patch embed dx")
+
+
+def test_conv_output_statistics(hip):
+    """`stats` output of conv2d: fp64 (sum, sum of squares) of the stored outputs per 32x32 tile, feeding GroupNorm."""
+    B, H, W, Ci, Co = 2, 16, 8, 64, 96
+    x, w, bias = rnd(B, Ci, H, W, seed=1), rnd(Co, Ci, 1, 1, seed=2) * 0.2, rnd(Co, seed=3)
+    res, ls = rnd(B, Co, H, W, seed=4) + 30.0, rnd(Co, seed=5) * 0.3 + 1            # |mean| >> std
+    y = res + ls.view(1, -1, 1, 1) * F.conv2d(x, w, bias)
+    pairs, per = hip.conv_stats_buffer(B, H * W, Co, "cuda")
+    assert per == (H * W // 32) * 3
+    out = torch.empty(B, H, W, Co, device="cuda")
+    hip.conv2d(nhwc(x), Ci, w.cuda(), bias.cuda(), out, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=0, res=nhwc(res), ldres=Co,
+               res_scale=ls.cuda(), stats=pairs)
+    close(nchw(out), y, what="conv + residual")
+    got = pairs.view(B, -1, 2).sum(1).cpu()
+    yd = y.double().reshape(B, -1)
+    want = torch.stack([yd.sum(1), (yd * yd).sum(1)], 1)
+    assert torch.allclose(got, want, rtol=1e-6), (got, want)
+    gam, bet = rnd(Co, seed=6) * 0.3 + 1, rnd(Co, seed=7)
+    A, D, S = (torch.empty(B, Co, device="cuda") for _ in range(3))
+    ms = torch.empty(B, 2, device="cuda")
+    hip.gn_coef_from_pairs(pairs, per, gam.cuda(), bet.cuda(), 1e-5, B, H * W, Co, A, D, S, ms)
+    o2 = torch.empty(B, H, W, Co, device="cuda")
+    hip.affine(o2, Co, B, H * W, Co, x1=out, ld1=Co, A=A, D1=D, S1=S, bstride=Co)
+    close(nchw(o2), F.group_norm(y, 1, gam, bet, 1e-5), what="GroupNorm from conv statistics")
+    assert hip.conv_stats_buffer(B, 40, Co, "cuda") == (None, 0)
+    with pytest.raises(RuntimeError, match="statistics"):
+        hip.conv2d(out, Co, w.cuda(), None, torch.empty(B, H, W, Ci, device="cuda"), Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1,
+                   mode=1, stats=pairs)                               # data gradients have no GroupNorm consumer
