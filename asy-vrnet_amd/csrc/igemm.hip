@@ -80,8 +80,13 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
   float* stage = smem + wave * (32 * STAGE_LD);
 #pragma unroll
   for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * STAGE_LD + (lane & 31)] = acc[r];
-  __syncthreads();
-  double st1 = 0.0, st2 = 0.0;
+  // the staging tile is private to this wave and a wave's LDS operations complete in program order: no workgroup
+  // barrier, only a fence against compiler reordering
+  __builtin_amdgcn_wave_barrier();
+  // statistics of the stored values: per thread in fp32 around its first value (deviations from a nearby value stay
+  // small when |mean| >> std), un-shifted and combined across the wave in fp64
+  float sh = 0.f, d1 = 0.f, d2 = 0.f;
+  int cnt = 0;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int q = lane + 64 * t;
@@ -114,15 +119,21 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
       if (p.accumulate) v += *dst;
       *dst = v;
       if (p.stats) {
+        if (cnt == 0) sh = v[0];
+        cnt += 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          st1 += (double)v[e];
-          st2 += (double)v[e] * (double)v[e];
+          const float d = v[e] - sh;
+          d1 += d;
+          d2 += d * d;
         }
       }
     }
   }
   if (p.stats) {      // statistics of exactly what was stored (fp64, as the moments kernel): GroupNorm of the consumer
+    const double x0 = (double)sh, n = (double)cnt;
+    double st1 = (double)d1 + n * x0;
+    double st2 = (double)d2 + 2.0 * x0 * (double)d1 + n * x0 * x0;
     st1 = wave_sum(st1);
     st2 = wave_sum(st2);
     const int mb = (m0 + wm * TM * 32 + ti * 32) >> 5, nb = (n0 + wn * TN * 32 + tj * 32) >> 5;
@@ -132,7 +143,7 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
       d[1] = st2;
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
 }
 
 template <int TM, int TN, int WM, int WN>
