@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void cluster_ab_reduce_kernel(const float* par
   }
 }
 
-int cluster_plan(int N, int* T, int* npt) {
+int cluster_plan(int N, long blocks, int* T, int* npt) {
   if (N > 256) {      // streaming kernel (points re-read in chunks): any region size
     *T = 0;
     *npt = 0;
@@ -697,6 +697,9 @@ int cluster_plan(int N, int* T, int* npt) {
   }
   int t = ((N + 63) / 64) * 64;
   if (t < 64) t = 64;
+  // few region-heads (stages 2-3: B*E*fold^2 = 256 / 64 workgroups): spread each region over 4x the threads
+  // (2 points per thread instead of 8) so that the chip holds 4x the waves and loads in flight
+  if (blocks <= 256 && N > 4 * (t / 8)) t *= 4;     // measured: 512 workgroups of 256 threads already do better as they are
   if (t > 1024) t = 1024;
   const int pp = t / 8;
   const int np = (N + pp - 1) / pp;
@@ -721,7 +724,12 @@ int cluster_launch(const ClusterArgs& p, int T, int npt, long blocks, hipStream_
       default: hipLaunchKernelGGL((cluster_kernel<8, BWD, 256>), grid, block, 0, st, p); break;
     }
   } else {
-    hipLaunchKernelGGL((cluster_kernel<8, BWD, 1024>), grid, block, 0, st, p);
+    switch (npt) {
+      case 1: hipLaunchKernelGGL((cluster_kernel<1, BWD, 1024>), grid, block, 0, st, p); break;
+      case 2: hipLaunchKernelGGL((cluster_kernel<2, BWD, 1024>), grid, block, 0, st, p); break;
+      case 4: hipLaunchKernelGGL((cluster_kernel<4, BWD, 1024>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((cluster_kernel<8, BWD, 1024>), grid, block, 0, st, p); break;
+    }
   }
   return 0;
 }
@@ -735,7 +743,7 @@ int cluster_check(const char* name, const void* f, const void* v, long ld, int B
                "Ensure the feature map size (%d*%d) can be divided by fold %d*%d", H, W, fold, fold);
   VR_CHECK_ARG(ld % 4 == 0 && vr_aligned16(f) && vr_aligned16(v), "%s: rows must be 16-byte aligned", name);
   const int N = (H / fold) * (W / fold);
-  VR_CHECK_ARG(cluster_plan(N, T, npt) == 0, "%s: unsupported region of %d points", name, N);
+  VR_CHECK_ARG(cluster_plan(N, (long)B * E * fold * fold, T, npt) == 0, "%s: unsupported region of %d points", name, N);
   return VR_OK;
 }
 
