@@ -454,7 +454,7 @@ def cluster_block(rt, x, m, name=None):
     E, Dh, fold = tm.heads, tm.head_dim, tm.fold
     ED = E * Dh
     xn, ms1 = gn_forward(rt, x, m.norm1)
-    wcat, bcat = rt.fused_qkv[tm]                                # [fc1 ; fc_v]: one GEMM, f | v side by side
+    wcat, bcat = tm._fused_qkv                                   # [fc1 ; fc_v]: one GEMM, f | v side by side
     fv = rt.new(B, H, W, 2 * ED)
     hip.conv2d(xn.t, xn.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0)
     f_t, v_t = fv.t, fv.t[..., ED:]
@@ -947,7 +947,10 @@ class FusedQKV:
     CHUNK = 4096
 
     def __init__(self, model, device):
-        self.entries, dst, src = {}, [], []
+        # bound to THIS module tree: copy.deepcopy (ModelEMA) and nn.DataParallel replicas carry a stale copy of the
+        # object along (views lose their aliasing under deepcopy), so the owner id is checked on every forward
+        self.owner = id(model)
+        dst, src = [], []
         for mod in model.modules():
             tm = getattr(mod, "token_mixer", None)
             if tm is None or not hasattr(tm, "fc_v"):
@@ -955,7 +958,7 @@ class FusedQKV:
             ed, c = tm.fc1.weight.shape[0], tm.fc1.weight.shape[1]
             w = torch.zeros((2 * ed, c), device=device)
             b = torch.zeros((2 * ed,), device=device)
-            self.entries[tm] = (w, b)
+            tm._fused_qkv = (w, b)
             dst += [w[:ed], w[ed:], b[:ed], b[ed:]]
             src += [tm.fc1.weight, tm.fc_v.weight, tm.fc1.bias, tm.fc_v.bias]
         self.dst, self.src, self.key = dst, src, None
@@ -995,10 +998,9 @@ class _VRNetFunction(torch.autograd.Function):
         rt.aside_ok = rt.bucketer is None or rt.bucketer.deferred
         rt.on_param_grad = getattr(model, "_on_param_grad", None) if rt.bucketer is not None else None
         fq = getattr(model, "_fused_qkv", None)
-        if fq is None or fq.dst[0].device != x.device:
+        if fq is None or fq.owner != id(model) or fq.dst[0].device != x.device:
             fq = model._fused_qkv = FusedQKV(model, x.device)
         fq.refresh()
-        rt.fused_qkv = fq.entries
         xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=ctx.needs_input_grad[1])
         ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=ctx.needs_input_grad[2])
         hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)

@@ -142,3 +142,30 @@ def test_data_parallel_wrapper_single_rank(A):
     for (k, p), (_, q) in zip(m2.named_parameters(), ref.named_parameters()):
         if p.numel():
             assert torch.equal(p.grad, q.grad), k
+
+
+@pytest.mark.gpu
+def test_deepcopy_and_updated_weights_use_fresh_fused_weights(A):
+    """The concatenated fc1|fc_v weights are derived caches: a deep copy (ModelEMA, yolo_training.py:457) and an
+    in-place parameter update (optimizer step) must both be reflected by the next forward."""
+    import copy
+    model = A.EfficientVRNet(4, 9, "nano", img_size=(64, 64)).cuda().eval()
+    A.randomize_state_dict(model.state_dict(), seed=3)
+    x, r = A.synthetic_inputs(2, 64, 7, "cuda")
+    with torch.no_grad():
+        det0, seg0 = model(x, r)
+        clone = copy.deepcopy(model)
+        det1, seg1 = clone(x, r)
+        assert torch.equal(seg0, seg1) and all(torch.equal(a, b) for a, b in zip(det0, det1))
+        # change a fused weight of the copy only: the copy's output moves, the original's does not
+        w = clone.backbone.backbone.network[0][0].token_mixer.fc_v.weight
+        w.mul_(1.5)
+        det2, seg2 = clone(x, r)
+        assert not torch.equal(seg2, seg1)
+        det3, seg3 = model(x, r)
+        assert torch.equal(seg3, seg0)
+        w.div_(1.5)
+        w2 = model.backbone.backbone.network[0][0].token_mixer.fc1.weight
+        w2.add_(0.01)
+        det4, seg4 = model(x, r)
+        assert not torch.equal(seg4, seg0)
