@@ -459,7 +459,7 @@ __device__ __attribute__((aligned(128))) float vr_zero_page[64];
 // accumulators per wave (32 MFMAs per stage, half the LDS-fill bytes and fragment reads per MFMA) for the layers
 // whose grid still fills the chip with 128-row tiles.  Both stage 16 KB per K step.
 template <int MODE, int NST, int T>
-__global__ __launch_bounds__(256, 3) void igemm_dma_kernel(const IgemmArgs p, int MT, int NT) {
+__global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_dma_kernel(const IgemmArgs p, int MT, int NT) {
   constexpr int BM = 64 * T, BN = 64 * T, BK = 32 / T;
   constexpr int QPR = BK / 4;                       // 16-byte quads per K-contiguous row of a stage
   constexpr int KQ = QPR / 2;                       // quads each lane owns per stage (k = h*BK/2 .. +BK/2)
@@ -468,13 +468,17 @@ __global__ __launch_bounds__(256, 3) void igemm_dma_kernel(const IgemmArgs p, in
   constexpr int RING = NST * ST_FLOATS;
   constexpr int KS_MAX = 1024;                      // kscale copy (mode 1)
   static_assert(RING >= 4 * 32 * STAGE_LD, "epilogue staging must fit the ring");
+  static_assert(NST >= 3 && NST <= 6, "counted waits cover up to 4 younger stages");
   static_assert(ST_FLOATS == 4096, "two 1 KB DMA pieces per wave and operand");
   // one LDS object only: a second __shared__ beside a DMA staging array makes hipcc drain vmcnt before ds_reads
   __shared__ __attribute__((aligned(16))) float smem[RING + 16 + (MODE == 1 ? KS_MAX : 0)];
   unsigned* tapmask_s = reinterpret_cast<unsigned*>(smem + RING);
   unsigned char* taps_s = reinterpret_cast<unsigned char*>(smem + RING + 4);     // 32 bytes
   float* ks_s = smem + RING + 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave id as a scalar: the LDS destinations of the DMAs (M0) then come from SALU arithmetic, not from a
+  // v_readfirstlane per piece
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int L = blockIdx.x, jj = L >> 3;
   const int nt = jj % NT, mt = (jj / NT) * 8 + (L & 7);
@@ -580,33 +584,47 @@ __global__ __launch_bounds__(256, 3) void igemm_dma_kernel(const IgemmArgs p, in
   };
 
   int ld_ti = 0, ld_kb = 0, ld_buf = 0;       // (tap index, k block, ring slot) of the NEXT stage to issue
-  auto issue = [&]() {
+  // The four DMA instructions of a stage are issued one by one (piece 0, 1 = A, 2, 3 = B): in the main loop each one
+  // goes behind a group of MFMAs, whose 64-cycle execution hides the DMA's issue cost (60-185 cycles per piece when
+  // issued back to back in front of the fragment reads).
+  auto issue_begin = [&]() {
     if (ld_kb == 0) setup_tap(use_list ? (int)taps_s[ld_ti] : ld_ti);
+  };
+  auto issue_piece = [&](int i) {
     float* stage = smem + ld_buf * ST_FLOATS;
     const bool last = k_tail && ld_kb == nkb - 1;          // block-uniform
     const int c0 = ld_kb * BK;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    if (i < 2) {
       const float* src = (last && c0 + a_k[i] >= p.CK) ? vr_zero_page : a_run[i];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(stage + (wave * 2 + i) * 256), 16, 0, 0);
       a_run[i] += a_inc[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float* src = (last && c0 + b_k[i] >= p.CK) ? vr_zero_page : b_run[i];
+    } else {
+      const int j = i - 2;
+      const float* src = (last && c0 + b_k[j] >= p.CK) ? vr_zero_page : b_run[j];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(stage + A_FLOATS + (wave * 2 + i) * 256),
+                                       (__attribute__((address_space(3))) void*)(stage + A_FLOATS + (wave * 2 + j) * 256),
                                        16, 0, 0);
-      b_run[i] += b_inc[i];
+      b_run[j] += b_inc[j];
     }
+  };
+  auto issue_end = [&]() {
     if (++ld_kb == nkb) {
       ld_kb = 0;
       ++ld_ti;
     }
     if (++ld_buf == NST) ld_buf = 0;
   };
+  auto issue = [&]() {
+    issue_begin();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_piece(i);
+    issue_end();
+  };
 
+  // (one accumulator chain per tile: a second, independent set was measured with in-kernel stamps and changes
+  // nothing -- with one wave per SIMD the 16 MFMAs of a stage take 1540 cycles because the wave's four DMA issues
+  // cost ~130 cycles each in its own instruction stream, not because of the accumulator dependency)
   f32x16 acc[T][T];
 #pragma unroll
   for (int i = 0; i < T; ++i)
@@ -627,17 +645,29 @@ __global__ __launch_bounds__(256, 3) void igemm_dma_kernel(const IgemmArgs p, in
   for (int st = 0; st < NST - 1; ++st)
     if (st < nsteps) issue();
   int cur = 0, kb = 0;
+#ifdef VR_IGEMM_STAMP
+  unsigned long long* stamp = reinterpret_cast<unsigned long long*>(p.stats);     // diagnostic build: 64 x 4 stamps
+#endif
   for (int s = 0; s < nsteps; ++s) {
-    // stage s has landed once at most the (NST - 2) younger stages (4 DMAs each) are still outstanding
-    if (NST == 3) {
-      if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#ifdef VR_IGEMM_STAMP
+    if (blockIdx.x == 8 && tid == 0 && s < 64) stamp[4 * s + 3] = __builtin_amdgcn_s_memtime();
+#endif
+    // stage s has landed once at most the min(NST - 2, stages left) younger stages (4 DMAs each) are still outstanding
+    {
+      const int younger = nsteps - 1 - s < NST - 2 ? nsteps - 1 - s : NST - 2;      // block-uniform
+      if (younger >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (younger == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (s + NST - 1 < nsteps) issue();      // into the slot every wave finished reading before this barrier
+#ifdef VR_IGEMM_STAMP
+    if (blockIdx.x == 8 && tid == 0 && s < 64) stamp[4 * s + 0] = __builtin_amdgcn_s_memtime();
+#endif
+    const bool more = s + NST - 1 < nsteps;   // next stage goes into the slot every wave finished reading before this barrier
+    if (more) issue_begin();
     const float* As = smem + cur * ST_FLOATS;
     const float* Bs = As + A_FLOATS;
     f32x4 af[T][KQ], bq[T][KQ];
@@ -669,8 +699,12 @@ __global__ __launch_bounds__(256, 3) void igemm_dma_kernel(const IgemmArgs p, in
         }
       }
     }
+#ifdef VR_IGEMM_STAMP
+    if (blockIdx.x == 8 && tid == 0 && s < 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp[4 * s + 1] = __builtin_amdgcn_s_memtime(); }
+#endif
+    constexpr int GROUPS = KQ >= 4 ? 4 : KQ;          // MFMA groups that each carry DMA pieces behind them
 #pragma unroll
-    for (int j = 0; j < KQ; ++j)
+    for (int j = 0; j < KQ; ++j) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -678,11 +712,28 @@ __global__ __launch_bounds__(256, 3) void igemm_dma_kernel(const IgemmArgs p, in
 #pragma unroll
           for (int jn = 0; jn < T; ++jn)
             acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j][e], bq[jn][j][e], acc[i][jn], 0, 0, 0);
+      if (more && j < GROUPS) {
+        __builtin_amdgcn_sched_barrier(0);          // keep the DMA behind this MFMA group, not hoisted to the top
+#pragma unroll
+        for (int q = j * (4 / GROUPS); q < (j + 1) * (4 / GROUPS); ++q) issue_piece(q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (more) issue_end();
+#ifdef VR_IGEMM_STAMP
+    if (blockIdx.x == 8 && tid == 0 && s < 64) stamp[4 * s + 2] = __builtin_amdgcn_s_memtime();
+#endif
     if (++cur == NST) cur = 0;
     if (++kb == nkb) kb = 0;
   }
   __syncthreads();
+#ifdef VR_IGEMM_STAMP
+  IgemmArgs q = p;            // the stats pointer carries the stamps in this build
+  q.stats = nullptr;
+  igemm_epilogue<T, T, 2, 2>(q, acc, smem, m0, n0);
+#else
   igemm_epilogue<T, T, 2, 2>(p, acc, smem, m0, n0);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1129,6 +1180,8 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   if (dma_ok && dma_shape) {
     const int MT = (int)vr_cdiv(M, 64), NT = (int)vr_cdiv(p.CN, 64);
     dim3 grid((unsigned)(8 * vr_cdiv(MT, 8) * NT));
+    // (rings of 4 / 6 stages for launches with <= 2 / 1 workgroups per CU were measured: 3-10 % slower -- the stage
+    // time there is not DMA latency but per-stage issue overhead, see the interleaved issue in the kernel)
     if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 1>), grid, block, 0, st, p, MT, NT);
     else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 1>), grid, block, 0, st, p, MT, NT);
     VR_LAUNCH_CHECK("conv2d");

@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape kernel breakdown on stderr (tuning aid)")
+    ap.add_argument("--serial", action="store_true", help="one stream: no concurrent chains (diagnostic)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     args = ap.parse_args()
 
@@ -188,6 +189,8 @@ def main():
     from asy_vrnet_amd.parallel import DataParallelVRNet
     model = A.EfficientVRNet(4, 9, args.phi, img_size=args.size).to(dev).train()
     A.randomize_state_dict(model.state_dict(), seed=0)
+    if args.serial:
+        model.concurrent = False
     net = DataParallelVRNet(model) if world > 1 else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 
