@@ -1,0 +1,194 @@
+// Shared by the implicit-GEMM kernels (igemm.hip: fp32 MFMA; igemm_bf16.hip: bf16 MFMA): argument block, GEMM-row ->
+// pixel maps and the fused epilogue.
+#pragma once
+#include "common.h"
+
+namespace {
+
+struct IgemmArgs {
+  const float* a; long lda;
+  const float* w;
+  const float* bias;
+  float* y; long ldy;
+  float* ypre; long ldypre;
+  const float* res; long ldres; const float* res_scale;
+  const float* kscale;
+  const float* aux; long ldaux;
+  int M, MH, MW, SH, SW, CK, CN;
+  int kh, kw, stride, pad, dil;
+  int mode, act, a_vec, b_vec, e_vec;
+  int out_nchw, out_ctot, out_coff, accumulate;
+  long wtap;   // Cout*Cin
+  int Cin;
+  int perm2;   // data gradient of a stride-2 conv: GEMM rows enumerate the 4 pixel parity classes one after another
+  double* stats;   // [ceil(M/32)][ceil(CN/32)][2]: (sum, sum of squares) of the stored outputs per 32x32 tile, or NULL
+  int stats_nb;    // ceil(CN/32)
+};
+
+// GEMM row -> (sample, y, x) of the M-side pixel grid.  With perm2 the rows are parity-major: class (y&1, x&1)
+// occupies a contiguous quarter of the rows, so every 64-row tile has ONE parity and the live-tap list drops
+// the 5-8 of 9 taps that a stride-2 data gradient never touches for that class (instead of multiplying zeros).
+__device__ __forceinline__ void igemm_row_to_pixel(const IgemmArgs& p, int m, int& b, int& y, int& x) {
+  if (p.perm2) {
+    const int Hh = p.MH >> 1, Wh = p.MW >> 1;
+    const int per = (p.M >> 2);
+    const int ph = m / per, r = m - ph * per;
+    const int xh = r % Wh, q = r / Wh;
+    const int yh = q % Hh;
+    b = q / Hh;
+    y = 2 * yh + (ph >> 1);
+    x = 2 * xh + (ph & 1);
+  } else {
+    x = m % p.MW;
+    const int q = m / p.MW;
+    y = q % p.MH;
+    b = q / p.MH;
+  }
+}
+__device__ __forceinline__ long igemm_row_index(const IgemmArgs& p, int m) {
+  if (!p.perm2) return m;
+  int b, y, x;
+  igemm_row_to_pixel(p, m, b, y, x);
+  return ((long)b * p.MH + y) * p.MW + x;
+}
+
+constexpr int STAGE_LD = 36;                       // epilogue staging tile: 32 rows x 36 floats per wave
+
+// One 32x32 accumulator tile (tile row `ti`, tile column `tj` of the wave's TM x TN grid).  A function of ONE
+// accumulator taken by value: looping `acc[i][j]` over runtime-looking indices (the compiler refuses to unroll a
+// loop that contains barriers) makes the whole accumulator array runtime-indexed, i.e. moves it to scratch.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32x16 acc, float* smem, int m0, int n0, int ti,
+                                                   int tj) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int khalf = lane >> 5;
+  // Row-contiguous float4 epilogue: each wave transposes one 32x32 accumulator tile through its private
+  // LDS staging tile, then 8 lanes cover one 128-byte output row segment (aux / residual loads and all
+  // stores are whole lines).  The main loop ended with a barrier, so the operand images can be reused.
+  float* stage = smem + wave * (32 * STAGE_LD);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * STAGE_LD + (lane & 31)] = acc[r];
+  // the staging tile is private to this wave and a wave's LDS operations complete in program order: no workgroup
+  // barrier, only a fence against compiler reordering
+  __builtin_amdgcn_wave_barrier();
+  // statistics of the stored values: per thread in fp32 around its first value (deviations from a nearby value stay
+  // small when |mean| >> std), un-shifted and combined across the wave in fp64
+  float sh = 0.f, d1 = 0.f, d2 = 0.f;
+  int cnt = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int q = lane + 64 * t;
+    const int row = q >> 3, c4 = (q & 7) * 4;
+    const int m = m0 + wm * TM * 32 + ti * 32 + row;
+    const int n = n0 + wn * TN * 32 + tj * 32 + c4;
+    if (m < p.M && n < p.CN) {
+      const long mo = igemm_row_index(p, m);
+      f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * STAGE_LD + c4]);
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.aux) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + mo * p.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= vr_gelu_grad(a[e]);
+      }
+      if (p.ypre) *reinterpret_cast<f32x4*>(p.ypre + mo * p.ldypre + n) = v;
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = vr_gelu(v[e]);
+      }
+      if (p.res) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + mo * p.ldres + n);
+        if (p.res_scale) v = rv + *reinterpret_cast<const f32x4*>(p.res_scale + n) * v;
+        else v = rv + v;
+      }
+      f32x4* dst = reinterpret_cast<f32x4*>(p.y + mo * p.ldy + n);
+      if (p.accumulate) v += *dst;
+      *dst = v;
+      if (p.stats) {
+        if (cnt == 0) sh = v[0];
+        cnt += 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[e] - sh;
+          d1 += d;
+          d2 += d * d;
+        }
+      }
+    }
+  }
+  if (p.stats) {      // statistics of exactly what was stored (fp64, as the moments kernel): GroupNorm of the consumer
+    const double x0 = (double)sh, n = (double)cnt;
+    double st1 = (double)d1 + n * x0;
+    double st2 = (double)d2 + 2.0 * x0 * (double)d1 + n * x0 * x0;
+    st1 = wave_sum(st1);
+    st2 = wave_sum(st2);
+    const int mb = (m0 + wm * TM * 32 + ti * 32) >> 5, nb = (n0 + wn * TN * 32 + tj * 32) >> 5;
+    if (lane == 0 && mb * 32 < p.M && nb < p.stats_nb) {
+      double* d = p.stats + ((long)mb * p.stats_nb + nb) * 2;
+      d[0] = st1;
+      d[1] = st2;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue_scalar(const IgemmArgs& p, const f32x16 acc, int m0, int n0, int ti, int tj) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int khalf = lane >> 5;
+  const long hw = (long)p.MH * p.MW;
+  const int n = n0 + wn * TN * 32 + tj * 32 + (lane & 31);
+  if (n >= p.CN) return;
+  const float bias = p.bias ? p.bias[n] : 0.f;
+  const float rsc = (p.res && p.res_scale) ? p.res_scale[n] : 1.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * TM * 32 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    if (m >= p.M) continue;
+    const long mo = igemm_row_index(p, m);
+    float v = acc[r] + bias;
+    if (p.aux) v *= vr_gelu_grad(p.aux[mo * p.ldaux + n]);
+    if (p.ypre) p.ypre[mo * p.ldypre + n] = v;
+    if (p.act == 1) v = fmaxf(v, 0.f);
+    else if (p.act == 2) v = vr_gelu(v);
+    if (p.res) v = p.res[mo * p.ldres + n] + rsc * v;
+    float* dst;
+    if (p.out_nchw) {
+      const long b = mo / hw, pix = mo - b * hw;
+      dst = p.y + ((b * p.out_ctot + p.out_coff + n) * hw + pix);
+    } else {
+      dst = p.y + mo * p.ldy + n;
+    }
+    if (p.accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
+// Epilogue shared by the igemm kernels.  C/D map of the 32x32 MFMA: col = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  `smem` must hold 4 * 32 * STAGE_LD floats and no wave may
+// still be reading operand images from it (callers end their main loop with a barrier).
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0) {
+  static_assert(TM <= 2 && TN <= 2, "accumulator tiles are named explicitly");
+  if (p.e_vec) {
+    igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[0][0], smem, m0, n0, 0, 0);
+    if constexpr (TN > 1) igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[0][1], smem, m0, n0, 0, 1);
+    if constexpr (TM > 1) {
+      igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[1][0], smem, m0, n0, 1, 0);
+      if constexpr (TN > 1) igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[1][1], smem, m0, n0, 1, 1);
+    }
+    return;
+  }
+  igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[0][0], m0, n0, 0, 0);
+  if constexpr (TN > 1) igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[0][1], m0, n0, 0, 1);
+  if constexpr (TM > 1) {
+    igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[1][0], m0, n0, 1, 0);
+    if constexpr (TN > 1) igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[1][1], m0, n0, 1, 1);
+  }
+}
+
+}  // namespace

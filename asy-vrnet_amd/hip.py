@@ -25,7 +25,8 @@ _SIGS = {
     "vrnet_abi_version": ([], I),
     "vrnet_last_error": ([], ctypes.c_char_p),
     "vrnet_device_arch": ([ctypes.c_char_p, I], I),
-    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, P], I),
+    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, P], I),
+    "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
     "vrnet_conv2d_wgrad_workspace": ([I] * 7, L),
     "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 13 + [P, L, P], I),
     "vrnet_pack_weight_f32": ([P, P, I, I, I, I, P], I),
@@ -139,11 +140,21 @@ _ws = Workspace()
 # --------------------------------------------------------------------------------------- wrappers
 def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, mode=0, act=0,
            ypre=None, ldypre=0, res=None, ldres=0, res_scale=None, kscale=None, aux=None, ldaux=0,
-           out_nchw=0, out_ctot=0, out_coff=0, accumulate=0, stats=None):
+           out_nchw=0, out_ctot=0, out_coff=0, accumulate=0, stats=None, precision=0):
     _check(_lib.vrnet_conv2d_f32(ptr(a), lda, ptr(w), ptr(bias), ptr(y), ldy, B, H, W, Cin, OH, OW, Cout, kh, kw,
                                  stride, pad, dil, mode, act, ptr(ypre), ldypre, ptr(res), ldres, ptr(res_scale),
                                  ptr(kscale), ptr(aux), ldaux, out_nchw, out_ctot, out_coff, accumulate, ptr(stats),
-                                 stream()), "conv2d")
+                                 precision, stream()), "conv2d")
+
+
+def bf16_conv_ok(lda, Cin, Cout, mode):
+    """Shapes the bf16-operand path of conv2d accepts (mirrors the check in vrnet_conv2d_f32)."""
+    ck, cn = (Cin, Cout) if mode == 0 else (Cout, Cin)
+    return ck % 4 == 0 and lda % 4 == 0 and cn > 32 and cn % 4 == 0
+
+
+def pack_weight_t(w_oihw, kscale, out, Cout, Cin, kh, kw):
+    _check(_lib.vrnet_pack_weight_t_f32(ptr(w_oihw), ptr(kscale), ptr(out), Cout, Cin, kh, kw, stream()), "pack_weight_t")
 
 
 def conv_stats_buffer(B, HW, Cout, device):

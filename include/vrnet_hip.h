@@ -39,6 +39,10 @@ int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sram
  *   act: 1 ReLU, 2 exact-erf GELU;  v = res[m,n] + res_scale[n] * v (layer-scale residual, vr_coc.py:266-271);
  *   store NHWC y[m*ldy+n] or NCHW y[b][out_coff+n][pix] of a (B,out_ctot,OH,OW) tensor (head cat, decouplehead.py:86).
  * kscale[k]: multiplies the contraction channels of `a` (layer scale folded into the data gradient).
+ * precision: 0 = fp32 operands on v_mfma_f32_32x32x2_f32 (the parity path); 1 = operands rounded to bf16 while staged,
+ *   v_mfma_f32_32x32x16_bf16, fp32 accumulate and epilogue (BASELINE configs "bf16 with MFMA conv path"): needs
+ *   16-byte rows, Cin % 4 == 0 (mode 0) / Cout % 4 == 0 (mode 1), > 32 GEMM columns, and in mode 1 `w` =
+ *   vrnet_pack_weight_t_f32's [kh*kw][Cin][Cout] pack with kscale folded in (kscale itself must then be NULL).
  * stats (NULL = none; forward, NHWC, Cout > 32, OH*OW % 32 == 0): [ceil(M/32)][ceil(Cout/32)][2] fp64 (sum, sum of
  *   squares) of the STORED outputs per 32-row x 32-channel tile -- the GroupNorm statistics of the consumer
  *   (vrnet_gn_coef_from_pairs: OH*OW/32 * ceil(Cout/32) consecutive pairs per sample) without another pass over y. */
@@ -46,7 +50,7 @@ int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias
                      int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride, int pad,
                      int dil, int mode, int act, float* ypre, long ldypre, const float* res, long ldres,
                      const float* res_scale, const float* kscale, const float* aux, long ldaux, int out_nchw,
-                     int out_ctot, int out_coff, int accumulate, double* stats, void* stream);
+                     int out_ctot, int out_coff, int accumulate, double* stats, int precision, void* stream);
 
 /* Weight (+ bias) gradient of the same convolutions (autograd of nn.Conv2d): dw in OIHW layout
  * [Cout][Cin][kh][kw], dbias[Cout] (NULL = none), both scaled by row_scale[Cout] when given (layer scale).
@@ -57,6 +61,9 @@ int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy, long lddy,
                            int kw, int stride, int pad, int dil, int accumulate, void* workspace,
                            long workspace_bytes, void* stream);
 int vrnet_pack_weight_f32(const float* w_oihw, float* w_tnc, int Cout, int Cin, int kh, int kw, void* stream);
+/* [kh*kw][Cin][Cout] = w_oihw[n][c][t] * kscale[n] (kscale NULL = 1): the data-gradient operand of the bf16 path. */
+int vrnet_pack_weight_t_f32(const float* w_oihw, const float* kscale, float* w_tcn, int Cout, int Cin, int kh, int kw,
+                            void* stream);
 
 /* ---- per-(sample, channel) moments in fp64 ---------------------------------------------------------
  * out[b][c] = { sum_p x, sum_p x*x }                    (x2 == NULL)

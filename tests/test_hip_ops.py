@@ -515,3 +515,33 @@ def test_conv_output_statistics(hip):
     with pytest.raises(RuntimeError, match="statistics"):
         hip.conv2d(out, Co, w.cuda(), None, torch.empty(B, H, W, Ci, device="cuda"), Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1,
                    mode=1, stats=pairs)                               # data gradients have no GroupNorm consumer
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 96, 1, 1, 0, 1), (2, 16, 16, 80, 128, 3, 1, 1, 1), (2, 32, 32, 64, 64, 3, 2, 1, 1),
+                                  (1, 8, 8, 320, 48, 1, 1, 0, 1), (2, 16, 16, 128, 64, 3, 1, 6, 6)])
+def test_conv_bf16_operands(hip, case):
+    """precision = 1: operands rounded to bf16 (round-to-nearest-even) when staged, fp32 accumulate.  Reference =
+    the fp32 convolution of the bf16-rounded tensors, so the comparison is tight (summation order only)."""
+    B, H, W, Ci, Co, k, s, p, d = case
+    x, w = rnd(B, Ci, H, W, seed=1), rnd(Co, Ci, k, k, seed=2) * (1.0 / (Ci * k * k) ** 0.5)
+    bias = rnd(Co, seed=3)
+    rb = lambda t: t.bfloat16().float()
+    y = F.conv2d(rb(x), rb(w), bias, s, p, d)
+    OH, OW = y.shape[2:]
+    assert hip.bf16_conv_ok(Ci, Ci, Co, 0)
+    out = torch.empty(B, OH, OW, Co, device="cuda")
+    hip.conv2d(nhwc(x), Ci, pack(hip, w), bias.cuda(), out, Co, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, mode=0, precision=1)
+    close(nchw(out), y, tol=2e-5, what="bf16 conv fwd")
+    # data gradient with a layer scale folded into the transposed pack
+    g, ks = rnd(B, Co, OH, OW, seed=4), rnd(Co, seed=5) * 0.3 + 1
+    wt = torch.empty(k * k, Ci, Co, device="cuda")
+    hip.pack_weight_t(w.contiguous().cuda(), ks.cuda(), wt, Co, Ci, k, k)
+    xr = rb(x).requires_grad_(True)
+    F.conv2d(xr, rb(w * ks.view(-1, 1, 1, 1)), None, s, p, d).backward(rb(g))
+    if hip.bf16_conv_ok(Co, Ci, Co, 1):
+        dx = torch.empty(B, H, W, Ci, device="cuda")
+        hip.conv2d(nhwc(g), Co, wt, None, dx, Ci, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, mode=1, precision=1)
+        close(nchw(dx), xr.grad, tol=2e-5, what="bf16 conv dgrad")
+    with pytest.raises(RuntimeError, match="bf16"):
+        hip.conv2d(nhwc(x), Ci, pack(hip, w), None, out, Co, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, mode=0, precision=1,
+                   kscale=ks.cuda())
