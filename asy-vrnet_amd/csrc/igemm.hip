@@ -553,14 +553,6 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
 // ------------------------------------------------------------------------------------------------
 // Weight gradient: dW[t][n][c] = sum_m dy[m, n] * x[src(m, t), c], contraction over output pixels,
 // split over `S` row ranges into fp32 slabs (deterministic; reduced by wgrad_reduce_kernel).
-struct WgradArgs {
-  const float* x; long ldx;
-  const float* dy; long lddy;
-  float* slab; float* bslab;
-  int M, OH, OW, H, W, Cin, Cout;
-  int kh, kw, stride, pad, dil;
-  int rows_per_split, n_tiles, c_tiles;
-};
 
 // IDENT: 1x1 / stride 1 / pad 0 -- the gathered x row of output pixel m is row m itself (no index math).
 constexpr int BK = 16;   // wgrad contraction step
@@ -889,6 +881,7 @@ __global__ void pack_weight_kernel(const float* w, float* out, int Cout, int Cin
 
 // igemm_bf16.hip
 int vr_igemm_bf16_launch(const void* args, int mode, hipStream_t st);
+int vr_wgrad_bf16_launch(const void* args, int ident, int blocks_x, int splits, hipStream_t st);
 
 // tinyconv.hip
 int vr_tiny_conv(int mode, const float* a, long lda, const float* w, const float* bias, float* y, long ldy, int B, int H,
@@ -1044,7 +1037,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
 // small-M stages).  Every split costs one slab of |dW| floats written and read back by the reduce pass,
 // so splits are bounded by >= 128 contraction rows each and <= 48 MB of slabs.
 static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int* n_tiles, int* c_tiles, int* S,
-                       int* rows) {
+                       int* rows, int bf16 = 0) {
   const long wsz = (long)T * Cout * Cin;
   auto splits = [&](long tiles) {
     long s = vr_cdiv(1024, tiles);
@@ -1066,11 +1059,12 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
   const bool small_ok = Cin > 32 && Cout > 32;
   // Measured (tools/tune_igemm.py --wgrad): 64 x 64 tiles win except for the large weight matrices whose
   // 128-wide tiling already yields >= 64 tiles (2560x640, 3x3 512x512, ...).
-  if ((force < 0 && tiles128 < 64 && small_ok) || (force == 1 && small_ok)) {
-    *cfg = 1; *bn = 64;
+  if (bf16 || (force < 0 && tiles128 < 64 && small_ok) || (force == 1 && small_ok)) {
+    *cfg = small_ok ? 1 : 0; *bn = 64;          // (bf16 without small_ok is rejected by the caller)
     *n_tiles = (int)vr_cdiv(Cout, 64); *c_tiles = (int)vr_cdiv(Cin, 64);
     const long s = splits(tiles64);
-    const long r = vr_cdiv(vr_cdiv(M, s), 32) * 32;     // 32: contraction rows per stage of the DMA kernel
+    const long q = bf16 ? 64 : 32;              // contraction rows per step of the bf16 / DMA kernels
+    const long r = vr_cdiv(vr_cdiv(M, s), q) * q;
     *rows = (int)r; *S = (int)vr_cdiv(M, r);
   } else {
     *cfg = 0; *bn = bn128;
@@ -1084,6 +1078,9 @@ extern "C" long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int
   int cfg, bn, nt, ct, S, rows;
   wgrad_plan((long)B * OH * OW, Cin, Cout, kh * kw, &cfg, &bn, &nt, &ct, &S, &rows);
   long need = ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
+  wgrad_plan((long)B * OH * OW, Cin, Cout, kh * kw, &cfg, &bn, &nt, &ct, &S, &rows, 1);      // the bf16 plan may split more
+  const long need16 = ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
+  if (need16 > need) need = need16;
   if (Cin <= 8 && Cout <= 8) {
     const long t = vr_tiny_wgrad_workspace((long)B * OH * OW, Cin, Cout, kh * kw);
     if (t > need) need = t;
@@ -1094,13 +1091,13 @@ extern "C" long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int
 extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, float* dbias,
                                       const float* row_scale, int B, int H, int W, int Cin, int OH, int OW,
                                       int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
-                                      void* workspace, long workspace_bytes, void* stream) {
+                                      int precision, void* workspace, long workspace_bytes, void* stream) {
   VR_CHECK_ARG(x && dy && dw && workspace, "conv2d_wgrad: null tensor");
   const long M = (long)B * OH * OW;
   VR_CHECK_ARG(M < (1L << 31) && (long)B * H * W < (1L << 31), "conv2d_wgrad: too many pixels");
   const int T = kh * kw;
   int cfg, bn, nt, ct, S, rows;
-  wgrad_plan(M, Cin, Cout, T, &cfg, &bn, &nt, &ct, &S, &rows);
+  wgrad_plan(M, Cin, Cout, T, &cfg, &bn, &nt, &ct, &S, &rows, precision == 1);
   const long need = vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw);
   if (workspace_bytes < need) {
     vr_set_error("conv2d_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
@@ -1127,6 +1124,12 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
     else if (vec) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, TM_, TN_, WM_, WN_, false, true>), grid, block, 0, st, p);     \
     else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, TM_, TN_, WM_, WN_, false, false>), grid, block, 0, st, p);             \
   } while (0)
+  VR_CHECK_ARG(precision == 0 || precision == 1, "conv2d_wgrad: precision 0 (fp32 MFMA) or 1 (bf16 operands)");
+  if (precision == 1) {
+    VR_CHECK_ARG(vec && cfg == 1 && rows % 64 == 0, "conv2d_wgrad: the bf16 path needs 16-byte aligned rows, channel counts that "
+                                                    "are multiples of 4 and more than 32 channels on both sides");
+    vr_wgrad_bf16_launch(&p, ident ? 1 : 0, nt * ct * T, S, st);
+  } else {
   static const int use_dma = getenv("VRNET_WGRAD_DMA") ? atoi(getenv("VRNET_WGRAD_DMA")) : 1;   // tuning aid
   // measured (bench.py --detail): the ring wins only for the smallest weight matrices (<= 4 tiles: +5..19 %); with
   // more tiles the row-split grid already fills the chip and the 8-workgroups-per-CU kernel is 5-15 % faster
@@ -1137,6 +1140,7 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   else if (bn == 128) VR_WGRAD(128, 128, 2, 2, 2, 2);
   else if (bn == 64) VR_WGRAD(128, 64, 2, 1, 2, 2);
   else VR_WGRAD(128, 32, 1, 1, 4, 1);
+  }
 #undef VR_WGRAD
   VR_LAUNCH_CHECK("conv2d_wgrad");
   const bool rvec = (Cin % 4 == 0);                 // slabs are 16-byte aligned (workspace arena), rows of Cin floats

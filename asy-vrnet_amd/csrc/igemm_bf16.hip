@@ -144,6 +144,113 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmArgs p) {
   igemm_epilogue<1, 1, 2, 2>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0);
 }
 
+// Weight gradient on the bf16 MFMA: dW[t][n][c] = sum_m dy[m, n] * x[src(m, t), c].  The contraction index is the ROW
+// of both operands, so the fragments (8 consecutive m of one column) are columns of the staged tiles: dy and x tiles
+// are stored row-major ([m][64 channels], 144-byte rows, coalesced b64 stores) and read with gfx950's transposing
+// ds_read_b64_tr_b16 (per 16-lane group a 4-row x 16-column block arrives column-major: lane i gets column i of the
+// 4 rows) -- no transposing stores, no shuffles.  Same slabs / reduce pass as the fp32 weight gradient.
+template <bool IDENT>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs p) {
+  constexpr int BKM = 64, LD = 72;
+  __shared__ __attribute__((aligned(16))) __bf16 Ys[BKM * LD];
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[BKM * LD];
+  __shared__ float bred[16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bid = blockIdx.x;
+  const int ct = bid % p.c_tiles; bid /= p.c_tiles;
+  const int nt = bid % p.n_tiles; bid /= p.n_tiles;
+  const int t = bid;
+  const int ky = t / p.kw, kx = t - ky * p.kw;
+  const int n0 = nt * 64, c0 = ct * 64;
+  const int split = blockIdx.y;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const bool do_bias = p.bslab != nullptr && ct == 0 && t == 0;
+  const int q4 = 4 * (tid & 15), r0 = tid >> 4;          // this thread's channel quad, rows r0 + 16 i of a step
+  f32x4 yreg[4], xreg[4];
+  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
+  auto load_tiles = [&](int mb) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + r0 + 16 * i;
+      yreg[i] = (m < m_end && n0 + q4 < p.Cout) ? *reinterpret_cast<const f32x4*>(p.dy + (long)m * p.lddy + n0 + q4) : zero;
+      f32x4 v = zero;
+      if (m < m_end && c0 + q4 < p.Cin) {
+        if (IDENT) {
+          v = *reinterpret_cast<const f32x4*>(p.x + (long)m * p.ldx + c0 + q4);
+        } else {
+          const int ox = m % p.OW;
+          const int q = m / p.OW;
+          const int oy = q % p.OH, b = q / p.OH;
+          const int sy = oy * p.stride - p.pad + ky * p.dil, sx = ox * p.stride - p.pad + kx * p.dil;
+          if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
+            v = *reinterpret_cast<const f32x4*>(p.x + ((long)(b * p.H + sy) * p.W + sx) * p.ldx + c0 + q4);
+        }
+      }
+      xreg[i] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (do_bias) bacc += yreg[i];
+      const bf16x4 py = {(__bf16)yreg[i][0], (__bf16)yreg[i][1], (__bf16)yreg[i][2], (__bf16)yreg[i][3]};
+      const bf16x4 px = {(__bf16)xreg[i][0], (__bf16)xreg[i][1], (__bf16)xreg[i][2], (__bf16)xreg[i][3]};
+      *reinterpret_cast<bf16x4*>(Ys + (r0 + 16 * i) * LD + q4) = py;
+      *reinterpret_cast<bf16x4*>(Xs + (r0 + 16 * i) * LD + q4) = px;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // transposed-read addresses: lane 4q + pp of its 16-lane group g supplies row (8 h + q) [+ 4], columns 16 g + 4 pp
+  const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+  const __bf16* y_tr = Ys + (8 * h + q) * LD + wm * 32 + 16 * g + 4 * pp;
+  const __bf16* x_tr = Xs + (8 * h + q) * LD + wn * 32 + 16 * g + 4 * pp;
+  typedef __attribute__((address_space(3))) bf16x4* lds4;
+
+  if (m_begin < m_end) load_tiles(m_begin);
+  for (int mb = m_begin; mb < m_end; mb += BKM) {
+    store_tiles();
+    __syncthreads();
+    if (mb + BKM < m_end) load_tiles(mb + BKM);
+#pragma unroll
+    for (int kk = 0; kk < BKM / 16; ++kk) {
+      const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(y_tr + (16 * kk) * LD));
+      const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(y_tr + (16 * kk + 4) * LD));
+      const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(x_tr + (16 * kk) * LD));
+      const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(x_tr + (16 * kk + 4) * LD));
+      const bf16x8 fa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const bf16x8 fb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const long T = (long)p.kh * p.kw;
+  float* slab = p.slab + ((long)split * T + t) * p.Cout * p.Cin;
+  const int c = c0 + wn * 32 + (lane & 31);
+  if (c < p.Cin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (n < p.Cout) slab[(long)n * p.Cin + c] = acc[r];
+    }
+  }
+  if (do_bias) {      // fp32 column sums of dy: 16 row groups x 64 columns through LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bred[r0][q4 + j] = bacc[j];
+    __syncthreads();
+    if (tid < 64 && n0 + tid < p.Cout) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += bred[r][tid];
+      p.bslab[(long)split * p.Cout + n0 + tid] = sum;
+    }
+  }
+}
+
 // [t][c][n] = w_oihw[n][c][t] * kscale[n]: the data gradient's Bt (rows = input channels, contraction over Cout)
 __global__ void pack_weight_t_kernel(const float* w, const float* kscale, float* out, int Cout, int Cin, int T) {
   const long total = (long)T * Cout * Cin;
@@ -164,6 +271,15 @@ int vr_igemm_bf16_launch(const void* args, int mode, hipStream_t st) {
   dim3 grid(vr_cdiv(p.M, 64), vr_cdiv(p.CN, 64)), block(256);
   if (mode == 0) hipLaunchKernelGGL((igemm_bf16_kernel<0>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((igemm_bf16_kernel<1>), grid, block, 0, st, p);
+  return VR_OK;
+}
+
+// internal entry used by vrnet_conv2d_wgrad_f32 (igemm.hip) when precision == 1
+int vr_wgrad_bf16_launch(const void* args, int ident, int blocks_x, int splits, hipStream_t st) {
+  const WgradArgs& p = *reinterpret_cast<const WgradArgs*>(args);
+  dim3 grid(blocks_x, splits), block(256);
+  if (ident) hipLaunchKernelGGL((wgrad_bf16_kernel<true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((wgrad_bf16_kernel<false>), grid, block, 0, st, p);
   return VR_OK;
 }
 

@@ -191,4 +191,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
   }
 }
 
+// Weight gradient: dW[t][n][c] = sum_m dy[m, n] * x[src(m, t), c], contraction over output pixels, split over row
+// ranges into fp32 slabs (deterministic; reduced by wgrad_reduce_kernel).
+struct WgradArgs {
+  const float* x; long ldx;
+  const float* dy; long lddy;
+  float* slab; float* bslab;
+  int M, OH, OW, H, W, Cin, Cout;
+  int kh, kw, stride, pad, dil;
+  int rows_per_split, n_tiles, c_tiles;
+};
+
 }  // namespace

@@ -28,7 +28,7 @@ _SIGS = {
     "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
     "vrnet_conv2d_wgrad_workspace": ([I] * 7, L),
-    "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 13 + [P, L, P], I),
+    "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 14 + [P, L, P], I),
     "vrnet_pack_weight_f32": ([P, P, I, I, I, I, P], I),
     "vrnet_moments_workspace": ([I, L, I], L),
     "vrnet_moments_f32": ([P, L, P, L, P, L, I, L, I, P, P, L, P], I),
@@ -166,12 +166,16 @@ def conv_stats_buffer(B, HW, Cout, device):
 
 
 def conv2d_wgrad(x, ldx, dy, lddy, dw, dbias, row_scale, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil,
-                 accumulate=0):
+                 accumulate=0, precision=0):
     nbytes = _lib.vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw)
     ws = _ws.get(nbytes, x.device)
     _check(_lib.vrnet_conv2d_wgrad_f32(ptr(x), ldx, ptr(dy), lddy, ptr(dw), ptr(dbias), ptr(row_scale), B, H, W, Cin,
-                                       OH, OW, Cout, kh, kw, stride, pad, dil, accumulate, ptr(ws), ws.numel(),
-                                       stream()), "conv2d_wgrad")
+                                       OH, OW, Cout, kh, kw, stride, pad, dil, accumulate, precision, ptr(ws),
+                                       ws.numel(), stream()), "conv2d_wgrad")
+
+
+def bf16_wgrad_ok(ldx, lddy, Cin, Cout):
+    return Cin % 4 == 0 and Cout % 4 == 0 and ldx % 4 == 0 and lddy % 4 == 0 and Cin > 32 and Cout > 32
 
 
 def pack_weight(w_oihw, out, Cout, Cin, kh, kw):

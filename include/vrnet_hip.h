@@ -54,11 +54,13 @@ int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias
 
 /* Weight (+ bias) gradient of the same convolutions (autograd of nn.Conv2d): dw in OIHW layout
  * [Cout][Cin][kh][kw], dbias[Cout] (NULL = none), both scaled by row_scale[Cout] when given (layer scale).
- * Deterministic split over output pixels into fp32 slabs in `workspace` (size from ..._workspace). */
+ * Deterministic split over output pixels into fp32 slabs in `workspace` (size from ..._workspace).
+ * precision 1: dy and x rounded to bf16 while staged, v_mfma_f32_32x32x16_bf16 with transposing LDS reads, fp32
+ * accumulate / slabs / bias sums (needs 16-byte rows, Cin, Cout multiples of 4 and > 32). */
 long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int Cout, int kh, int kw);
 int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, float* dbias,
                            const float* row_scale, int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh,
-                           int kw, int stride, int pad, int dil, int accumulate, void* workspace,
+                           int kw, int stride, int pad, int dil, int accumulate, int precision, void* workspace,
                            long workspace_bytes, void* stream);
 int vrnet_pack_weight_f32(const float* w_oihw, float* w_tnc, int Cout, int Cin, int kh, int kw, void* stream);
 /* [kh*kw][Cin][Cout] = w_oihw[n][c][t] * kscale[n] (kscale NULL = 1): the data-gradient operand of the bf16 path. */

@@ -545,3 +545,27 @@ def test_conv_bf16_operands(hip, case):
     with pytest.raises(RuntimeError, match="bf16"):
         hip.conv2d(nhwc(x), Ci, pack(hip, w), None, out, Co, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, mode=0, precision=1,
                    kscale=ks.cuda())
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 96, 1, 1, 0, 1), (4, 32, 32, 128, 64, 1, 1, 0, 1), (2, 16, 16, 80, 128, 3, 1, 1, 1),
+                                  (2, 32, 32, 64, 64, 3, 2, 1, 1)])
+def test_wgrad_bf16_operands(hip, case):
+    """Weight gradient with bf16-rounded dy and x (transposing LDS reads): against autograd on the rounded tensors."""
+    B, H, W, Ci, Co, k, s, p, d = case
+    x, w = rnd(B, Ci, H, W, seed=1), (rnd(Co, Ci, k, k, seed=2) * 0.1).requires_grad_(True)
+    bias = rnd(Co, seed=3).requires_grad_(True)
+    rb = lambda t: t.bfloat16().float()
+    y = F.conv2d(rb(x), w, bias, s, p, d)
+    g = rnd(*y.shape, seed=4)
+    OH, OW = y.shape[2:]
+    y.backward(rb(g))
+    dw_ref = w.grad.clone()
+    w.grad = None; bias.grad = None
+    F.conv2d(rb(x), w, bias, s, p, d).backward(g)            # bias gradient: fp32 sums of the unrounded dy
+    assert hip.bf16_wgrad_ok(Ci, Co, Ci, Co)
+    dw, db = torch.empty(Co, Ci, k, k, device="cuda"), torch.empty(Co, device="cuda")
+    hip.conv2d_wgrad(nhwc(x), Ci, nhwc(g), Co, dw, db, None, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, precision=1)
+    close(dw, dw_ref, tol=3e-5, what="bf16 wgrad dw")
+    close(db, bias.grad, tol=1e-5, what="bf16 wgrad db")
+    hip.conv2d_wgrad(nhwc(x), Ci, nhwc(g), Co, dw, db, None, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, accumulate=1, precision=1)
+    close(dw, 2 * dw_ref, tol=3e-5, what="bf16 wgrad accumulate")
