@@ -19,6 +19,11 @@ class EfficientVRNet(nn.Module):
             img_size = (img_size, img_size)
         self.phi, self.width, self.img_size = phi, width, tuple(img_size)
         self.num_classes, self.num_seg_classes = num_classes, num_seg_classes
+        # "f32": every dense conv on the fp32 MFMA (the parity path, 1e-3 against the reference).  "bf16": operands of
+        # the dense convs (activations, weights, output gradients) are rounded to bf16 when staged and multiplied on
+        # the bf16 MFMA with fp32 accumulation -- BASELINE configs "bf16 with MFMA conv path"; tensors in HBM, norms,
+        # clustering and every reduction stay fp32.  The reference's counterpart is torch.cuda.amp.autocast.
+        self.compute_dtype = "f32"
         self.backbone = CoCFpnDual(width=width, num_seg_class=num_seg_classes, img_size=self.img_size)
         self.head = DecoupleHead(num_classes, width, depthwise=True)
 

@@ -49,6 +49,8 @@ class RT:
         self.tape = []
         self.pgrads = {}
         self.packed = {}
+        self.packed_t = {}
+        self.bf16 = False           # dense convs with bf16-rounded operands on the bf16 MFMA (model.compute_dtype)
         self.consts = {}
         self.idx_maps = {}
         self.on_param_grad = None
@@ -209,6 +211,26 @@ class RT:
             self.packed[conv] = p
         return p
 
+    def prec_fwd(self, lda, ci, co):
+        """precision flag of a forward conv launch."""
+        return 1 if self.bf16 and hip.bf16_conv_ok(lda, ci, co, 0) else 0
+
+    def prec_wgrad(self, ldx, lddy, ci, co):
+        return 1 if self.bf16 and hip.bf16_wgrad_ok(ldx, lddy, ci, co) else 0
+
+    def dgrad_operands(self, key, w_oihw, w_packed, co, ci, kh, kw, kscale, lddy):
+        """(weights, kscale, precision) of a data-gradient launch: the bf16 path contracts over Cout with the
+        TRANSPOSED pack [t][Cin][Cout], into which kscale is folded."""
+        if self.bf16 and hip.bf16_conv_ok(lddy, ci, co, 1):
+            ck = (key, None if kscale is None else kscale.data_ptr())
+            wt = self.packed_t.get(ck)
+            if wt is None:
+                wt = self.buf(kh * kw, ci, co)
+                hip.pack_weight_t(w_oihw, kscale, wt, co, ci, kh, kw)
+                self.packed_t[ck] = wt
+            return wt, None, 1
+        return w_packed, kscale, 0
+
     def pgrad(self, param):
         """(gradient buffer, accumulate flag) for a parameter; None if it needs no gradient."""
         if not param.requires_grad or param.numel() == 0:
@@ -272,13 +294,13 @@ def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw
         hip.conv2d(x.t, x.ld, rt.weight(conv), b, out.t, out.ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
                    mode=0, act=act, ypre=None if ypre is None else ypre.t, ldypre=0 if ypre is None else ypre.ld,
                    res=None if res is None else res.t, ldres=0 if res is None else res.ld, res_scale=res_scale,
-                   stats=pairs)
+                   stats=pairs, precision=rt.prec_fwd(x.ld, ci, co))
         if pairs is not None:       # statistics of the stored output: the consumer's GroupNorm skips its moments pass
             out.pairs = (pairs, per)
     else:
         t, ctot, coff = nchw
         hip.conv2d(x.t, x.ld, rt.weight(conv), b, t, 0, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=0, act=act,
-                   out_nchw=1, out_ctot=ctot, out_coff=coff)
+                   out_nchw=1, out_ctot=ctot, out_coff=coff, precision=rt.prec_fwd(x.ld, ci, co))
 
 
 def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, skip_bias=False, dx_to=None,
@@ -294,7 +316,7 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
 
         def wgrad():
             hip.conv2d_wgrad(x.t, x.ld, dy, lddy, gw, gb, row_scale, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
-                             accumulate=accw)
+                             accumulate=accw, precision=rt.prec_wgrad(x.ld, lddy, ci, co))
             if rt.on_param_grad:
                 rt.on_param_grad(conv.weight)
                 if gb is not None:
@@ -310,8 +332,10 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
         else:
             buf, acc = rt.grad_target(x)
             ld = x.C
-        hip.conv2d(dy, lddy, rt.weight(conv), None, buf, ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=1,
-                   kscale=kscale, aux=None if aux is None else aux.t, ldaux=0 if aux is None else aux.ld, accumulate=acc)
+        wd, ks, prec = rt.dgrad_operands(conv, conv.weight, rt.weight(conv), co, ci, kh, kw, kscale, lddy)
+        hip.conv2d(dy, lddy, wd, None, buf, ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=1,
+                   kscale=ks, aux=None if aux is None else aux.t, ldaux=0 if aux is None else aux.ld, accumulate=acc,
+                   precision=prec)
 
 
 def simple_conv(rt, x, conv, out=None):
@@ -456,7 +480,8 @@ def cluster_block(rt, x, m, name=None):
     xn, ms1 = gn_forward(rt, x, m.norm1)
     wcat, bcat = tm._fused_qkv                                   # [fc1 ; fc_v]: one GEMM, f | v side by side
     fv = rt.new(B, H, W, 2 * ED)
-    hip.conv2d(xn.t, xn.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0)
+    hip.conv2d(xn.t, xn.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0,
+               precision=rt.prec_fwd(xn.ld, C, 2 * ED))
     f_t, v_t = fv.t, fv.t[..., ED:]
     o = rt.new(B, H, W, ED)
     idx = rt.buf(B, H, W, E, dtype=torch.uint8)
@@ -510,7 +535,8 @@ def cluster_block(rt, x, m, name=None):
             rt.on_param_grad(tm.sim_beta)
         _fused_qkv_wgrad(rt, tm, xn, dfv, wcat)
         dxn = rt.new(B, H, W, C)                                 # d xn = [df | dv] . [fc1 ; fc_v]: one data-gradient GEMM
-        hip.conv2d(dfv.t, 2 * ED, wcat, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1)
+        wd, _, prec = rt.dgrad_operands(tm, wcat, wcat, 2 * ED, C, 1, 1, None, 2 * ED)
+        hip.conv2d(dfv.t, 2 * ED, wd, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1, precision=prec)
         gn_backward(rt, m.norm1, x, ms1, dxn.t, dx2, accumulate=1)             # dx2 now holds dx
         rt.give_grad(x, dx2)
     rt.push(bwd)
@@ -532,7 +558,8 @@ def _fused_qkv_wgrad(rt, tm, xn, dfv, wcat):
         rt.pgrads[tm.fc1.bias], rt.pgrads[tm.fc_v.bias] = gbias[:ed], gbias[ed:]
 
         def wgrad_direct():
-            hip.conv2d_wgrad(xn.t, xn.ld, dfv.t, 2 * ed, gw, gbias, None, B, H, W, c, H, W, 2 * ed, 1, 1, 1, 0, 1)
+            hip.conv2d_wgrad(xn.t, xn.ld, dfv.t, 2 * ed, gw, gbias, None, B, H, W, c, H, W, 2 * ed, 1, 1, 1, 0, 1,
+                             precision=rt.prec_wgrad(xn.ld, 2 * ed, c, 2 * ed))
         rt.aside(wgrad_direct, (xn.t, dfv.t))
         return
     grads = [(prm,) + rt.pgrad(prm) + (row0, width) for prm, row0, width in targets]
@@ -541,7 +568,8 @@ def _fused_qkv_wgrad(rt, tm, xn, dfv, wcat):
 
     def wgrad():
         gw, gbias = rt.buf(2 * ed, c), rt.buf(2 * ed)
-        hip.conv2d_wgrad(xn.t, xn.ld, dfv.t, 2 * ed, gw, gbias, None, B, H, W, c, H, W, 2 * ed, 1, 1, 1, 0, 1)
+        hip.conv2d_wgrad(xn.t, xn.ld, dfv.t, 2 * ed, gw, gbias, None, B, H, W, c, H, W, 2 * ed, 1, 1, 1, 0, 1,
+                         precision=rt.prec_wgrad(xn.ld, 2 * ed, c, 2 * ed))
         for prm, g, acc, row0, width in grads:
             if g is None:
                 continue
@@ -831,7 +859,8 @@ def backbone_forward(rt, bb, x, r):
         w2 = rt.buf(co, KT)                                       # OHWI: [n][(ky,kx)][c]
         hip.weight_ohwi(conv.weight, w2, co, ci, kh, kw, 0)
         y = rt.new(B, OH, OW, co)
-        hip.conv2d(patches.t, KT, w2, conv.bias, y.t, y.ld, B, OH, OW, KT, OH, OW, co, 1, 1, 1, 0, 1, mode=0)
+        hip.conv2d(patches.t, KT, w2, conv.bias, y.t, y.ld, B, OH, OW, KT, OH, OW, co, 1, 1, 1, 0, 1, mode=0,
+                   precision=rt.prec_fwd(KT, KT, co))
 
         def bwd(act=act, patches=patches, w2=w2, y=y):
             g = take_grad(y)
@@ -845,7 +874,7 @@ def backbone_forward(rt, bb, x, r):
                 if gb is not None and accb:       # one accumulate flag covers dw and dbias: start the scratch dw at 0
                     hip.fill_(gw2, 0.0)
                 hip.conv2d_wgrad(patches.t, KT, g, co, gw2, gb, None, B, OH, OW, KT, OH, OW, co, 1, 1, 1, 0, 1,
-                                 accumulate=0 if gb is None else accb)
+                                 accumulate=0 if gb is None else accb, precision=rt.prec_wgrad(KT, co, KT, co))
                 hip.weight_ohwi(gw2, gw, co, ci, kh, kw, 1, accumulate=accw)
                 if rt.on_param_grad:
                     rt.on_param_grad(conv.weight)
@@ -853,7 +882,8 @@ def backbone_forward(rt, bb, x, r):
                         rt.on_param_grad(conv.bias)
             if act.need_grad:
                 dp = rt.buf(B, OH, OW, KT)
-                hip.conv2d(g, co, w2, None, dp, KT, B, OH, OW, KT, OH, OW, co, 1, 1, 1, 0, 1, mode=1)
+                wd, _, prec = rt.dgrad_operands(conv, w2, w2, co, KT, 1, 1, None, co)
+                hip.conv2d(g, co, wd, None, dp, KT, B, OH, OW, KT, OH, OW, co, 1, 1, 1, 0, 1, mode=1, precision=prec)
                 buf, acc = rt.grad_target(act)
                 hip.patch_scatter(dp, buf, act.C, B, H, W, C, CP, k, accumulate=acc)
         rt.push(bwd)
@@ -994,6 +1024,7 @@ class _VRNetFunction(torch.autograd.Function):
         record = any(ctx.needs_input_grad)
         rt = RT(x.device, model.training, record)
         rt.concurrent = bool(getattr(model, "concurrent", True))
+        rt.bf16 = str(getattr(model, "compute_dtype", "f32")).lower() in ("bf16", "bfloat16", "torch.bfloat16")
         rt.bucketer = getattr(model, "_grad_bucketer", None)
         rt.aside_ok = rt.bucketer is None or rt.bucketer.deferred
         rt.on_param_grad = getattr(model, "_on_param_grad", None) if rt.bucketer is not None else None

@@ -30,6 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense bf16 MFMA (no sparsity)
 
 
 def pmc_traffic_bytes(phi):
@@ -169,6 +170,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape kernel breakdown on stderr (tuning aid)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 (headline metric, BASELINE configs[1]) or bf16-operand dense convs (configs[2..4])")
     ap.add_argument("--serial", action="store_true", help="one stream: no concurrent chains (diagnostic)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     args = ap.parse_args()
@@ -189,6 +192,7 @@ def main():
     from asy_vrnet_amd.parallel import DataParallelVRNet
     model = A.EfficientVRNet(4, 9, args.phi, img_size=args.size).to(dev).train()
     A.randomize_state_dict(model.state_dict(), seed=0)
+    model.compute_dtype = args.dtype
     if args.serial:
         model.concurrent = False
     net = DataParallelVRNet(model) if world > 1 else model
@@ -255,10 +259,16 @@ def main():
                 ct.detail("cluster_bwd", 1e9, "GB/s")
         model.concurrent = True
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "igemm_dma_kernel + igemm_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32; LDS-DMA ring / register-staged variants)",
-                "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic_bytes(args.phi) if (args.batch == 8 and args.size == 512) else None,
+        bf16 = args.dtype == "bf16"
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+        kern = ("igemm_bf16_kernel (implicit-GEMM conv forward + data-gradient, operands rounded to bf16 when staged, "
+                "v_mfma_f32_32x32x16_bf16, fp32 accumulate)") if bf16 else (
+            "igemm_dma_kernel + igemm_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32; "
+            "LDS-DMA ring / register-staged variants)")
+        roof = {"bound": "mfma", "kernel": kern,
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4),
+                "traffic": pmc_traffic_bytes(args.phi) if (args.batch == 8 and args.size == 512 and not bf16) else None,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
                 "launches_per_step": n // args.steps, "avg_launch_us": round(1e3 * ms / n, 2),
                 "avg_launch_gflop": round(flops / n / 1e9, 3),
@@ -277,13 +287,19 @@ def main():
         cpu = cpu_baseline(args.phi, args.size, args.cpu_batch, 0)
 
     if rank == 0:
-        line = {"metric": "images/sec fwd+bwd, 512x512 img+4ch radar, bs=8/GPU", "value": round(value, 3),
+        metric = "images/sec fwd+bwd, 512x512 img+4ch radar, bs=8/GPU"
+        if (args.batch, args.size, args.dtype) != (8, 512, "f32"):       # not BASELINE.json's headline configuration
+            metric = f"images/sec fwd+bwd, {args.size}x{args.size} img+4ch radar, bs={args.batch}/GPU, {args.dtype} [not the headline config]"
+        line = {"metric": metric, "value": round(value, 3),
                 "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
+                "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": f"EfficientVRNet(phi={args.phi}) forward+backward, {args.size}x{args.size} image + "
-                                       f"4x{args.size}x{args.size} radar, bs={args.batch}/GPU, fp32, det+seg heads "
-                                       "(BASELINE.json configs[1]); random weights",
+                                       f"4x{args.size}x{args.size} radar, bs={args.batch}/GPU, "
+                                       + ("fp32, det+seg heads (BASELINE.json configs[1])" if args.dtype == "f32" else
+                                          "bf16-operand dense convs with fp32 accumulation, everything else fp32 "
+                                          "(BASELINE.json configs[2] family; NOT the headline fp32 metric)")
+                                       + "; random weights",
                            "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}", "launch": launch},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line))

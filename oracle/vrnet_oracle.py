@@ -51,8 +51,26 @@ class Ctx:
         self.idx_report = {}
 
 
+# Operand rounding of the dense convolutions, mirroring the build's `compute_dtype = "bf16"` mode (BASELINE configs
+# "bf16 with MFMA conv path"; the reference's counterpart is autocast): None, or "bf16" = activations and weights are
+# rounded to bfloat16 (round-to-nearest-even, straight-through gradient) before an fp32/fp64 convolution, for exactly
+# the layers the build runs on its bf16 kernels (hip.bf16_conv_ok: contraction % 4 == 0, more than 32 output channels).
+OPERAND_ROUND = None
+
+
+def _round_ste(t):
+    return t + (t.detach().float().bfloat16().to(t.dtype) - t.detach())
+
+
 def conv(P, pre, x, stride=1, pad=0, dil=1, groups=1):
-    return F.conv2d(x, P[pre + ".weight"], P.get(pre + ".bias"), stride, pad, dil, groups)
+    w = P[pre + ".weight"]
+    if OPERAND_ROUND == "bf16" and groups == 1:
+        co, ci, kh, kw = w.shape
+        patch = kh == stride and kh > 1 and pad == 0            # patch embedding: the build contracts over kh*kw*ci at once
+        ck = ci * kh * kw if patch else ci
+        if ck % 4 == 0 and co > 32 and co % 4 == 0:
+            x, w = _round_ste(x), _round_ste(w)
+    return F.conv2d(x, w, P.get(pre + ".bias"), stride, pad, dil, groups)
 
 
 def batch_norm(P, pre, x, ctx, eps=1e-5, momentum=0.1):

@@ -34,7 +34,15 @@ def hip_idx_maps(model):
 
 
 def compare_with_oracle(model, batch, size, iseed, check_grads=True, oracle_dtype=torch.float32, tol=1e-3,
-                        gtol=5e-3):
+                        gtol=5e-3, conv_round=None):
+    O.OPERAND_ROUND = conv_round
+    try:
+        return _compare_with_oracle(model, batch, size, iseed, check_grads, oracle_dtype, tol, gtol)
+    finally:
+        O.OPERAND_ROUND = None
+
+
+def _compare_with_oracle(model, batch, size, iseed, check_grads, oracle_dtype, tol, gtol):
     dev = next(model.parameters()).device
     x, r = A.synthetic_inputs(batch, size, iseed)
     sd0 = {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}

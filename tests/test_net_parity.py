@@ -169,3 +169,45 @@ def test_deepcopy_and_updated_weights_use_fresh_fused_weights(A):
         w2.add_(0.01)
         det4, seg4 = model(x, r)
         assert not torch.equal(seg4, seg0)
+
+
+@pytest.mark.parametrize("phi,size,batch", [("nano", 128, 2), ("l", 128, 2), ("nano", 256, 2)])
+def test_bf16_operand_mode_against_oracle(A, phi, size, batch):
+    """model.compute_dtype = "bf16" (BASELINE configs "bf16 with MFMA conv path"): dense convs multiply bf16-rounded
+    operands with fp32 accumulation (the kernels' rounding itself is pinned to 2e-5 in test_hip_ops.py).  The oracle
+    applies the same rounding to the same layers (O.OPERAND_ROUND) and is teacher-forced with the kernels' Cluster
+    assignments.  Rounding is a discontinuity too: fp32 and fp64 values that straddle a bf16 boundary round apart
+    (2^-8 relative, once per ~4000 operands), and ~100 layers compound that to ~1e-2 -- the bound of this test; the
+    gradients are compared in aggregate (relative L2 over all parameters, cosine)."""
+    from tests.parity import hip_idx_maps, rel_err
+    from oracle import vrnet_oracle as O
+    m = build(A, phi, size, 21, True)
+    m.compute_dtype = "bf16"
+    x, r = A.synthetic_inputs(batch, size, 31)
+    sd0 = {k: v.detach().clone().cpu() for k, v in m.state_dict().items()}
+    m.zero_grad(set_to_none=True)
+    det, seg = m(x.cuda(), r.cuda())
+    O.synthetic_loss(det, seg).backward()
+    forced = hip_idx_maps(m)
+    pn = {k for k, _ in m.named_parameters()}
+    P = {k: (v.double().requires_grad_(k in pn and v.numel() > 0) if v.dtype.is_floating_point else v) for k, v in sd0.items()}
+    O.OPERAND_ROUND = "bf16"
+    try:
+        det_o, seg_o, ctx = O.forward(P, x.double(), r.double(), phi, True, forced_idx=forced)
+        O.synthetic_loss(det_o, seg_o).backward()
+    finally:
+        O.OPERAND_ROUND = None
+    flips = sum(v.get("mismatch", 0) for v in ctx.idx_report.values())
+    points = sum(v.get("points", 0) for v in ctx.idx_report.values())
+    num = den = dot = n1 = 0.0
+    for k, p in m.named_parameters():
+        if p.numel() == 0 or P[k].grad is None:
+            continue
+        a, b = p.grad.double().cpu(), P[k].grad
+        num += float(((a - b) ** 2).sum()); den += float((b ** 2).sum()); dot += float((a * b).sum()); n1 += float((a ** 2).sum())
+    rep = {"flips": flips, "points": points, "det_err": max(rel_err(a, b) for a, b in zip(det, det_o)),
+           "seg_err": rel_err(seg, seg_o), "grad_rel_l2": (num / den) ** 0.5, "grad_cos": dot / (n1 * den) ** 0.5}
+    print(rep)
+    assert flips <= max(30, points // 1000), rep
+    assert rep["det_err"] < 4e-2 and rep["seg_err"] < 4e-2, rep
+    assert rep["grad_cos"] > 0.97 and rep["grad_rel_l2"] < 0.25, rep
