@@ -6,10 +6,14 @@
 // head/decouplehead.py:21-40) in both directions:
 //   mode 0 (forward)       y[m, n]  = sum_{t, c} x[src(m, t), c] * w[t][n][c]      m over output pixels
 //   mode 1 (data gradient) dx[m, c] = sum_{t, n} dy[src'(m, t), n] * w[t][n][c]    m over input pixels
-// Block tile 128 x BN x 16, 4 waves, each wave a TM x TN grid of 32x32 MFMA tiles.  Operand tiles
-// are staged global -> registers -> LDS (k-major images, so every MFMA fragment read is a
-// conflict-free ds_read_b32); the next tile's global loads are in flight during the MFMAs.
-// Exact fp32: the MFMA is an fmaf chain in k order (guide: cdna_hip_programming.md section 3).
+// Three kernels, chosen per shape by vrnet_conv2d_f32 (measured table: profiles/*per_shape_detail*):
+//   igemm_kernel      register-staged (global -> registers -> k-major LDS images, ds_read_b32 fragments), 64 x 64 x 16
+//                     tiles at 8 workgroups per CU (128 x {32,64,128} variants for narrow outputs / non-vector shapes);
+//   igemm_dma_kernel  LDS-DMA ring (global_load_lds_dwordx4, 3 stages, XOR-swizzled ds_read_b128 fragments) for the
+//                     layers whose grid cannot fill the chip at 8 workgroups per CU, and for long contractions;
+//   igemm_bf16_kernel (igemm_bf16.hip) bf16-rounded operands on v_mfma_f32_32x32x16_bf16 (precision = 1).
+// The epilogue (igemm_common.h) is shared.  Exact fp32: the MFMA is an fmaf chain in a fixed k order (guide:
+// cdna_hip_programming.md section 3).  The weight gradient (wgrad_* below) contracts over pixels into fp32 slabs.
 #include "igemm_common.h"
 
 #include <cstdlib>

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvrnet_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------- */
-int vrnet_abi_version(void);                 /* == 1 */
+int vrnet_abi_version(void);                 /* == 2 */
 const char* vrnet_last_error(void);          /* host string, thread local */
 int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sramecc+:xnack-" (synchronous) */
 
