@@ -1014,6 +1014,8 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
     return VR_OK;
   }
   int cfg = p.CN > 32 ? 2 : 3;
+  static const int narrow = getenv("VRNET_IGEMM_NARROW") ? atoi(getenv("VRNET_IGEMM_NARROW")) : 1;   // tuning aid
+  if (narrow && vec && p.CN > 32 && p.CN <= 192 && ktot >= 512) cfg = 1;      // 128 x 64 tiles for narrow outputs
   if (force_cfg >= 0 && p.CN > 32) cfg = (force_cfg == 0 && p.CN <= 64) ? 1 : force_cfg;
   if (cfg == 2) {
     dim3 grid(vr_cdiv(M, 64), vr_cdiv(p.CN, 64));

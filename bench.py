@@ -179,7 +179,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dp = os.environ.get("VRNET_BENCH_FORCE_DP") == "1"    # exercise the RCCL path on a 1-GPU box (torchrun, 1 rank)
+    if world > 1 or (force_dp and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
@@ -195,12 +196,12 @@ def main():
     model.compute_dtype = args.dtype
     if args.serial:
         model.concurrent = False
-    net = DataParallelVRNet(model) if world > 1 else model
+    net = DataParallelVRNet(model) if (world > 1 or dist.is_initialized()) else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 
     def eager_step(i):
         x, r = batches[i]
-        if world == 1:
+        if net is model:
             model.zero_grad(set_to_none=True)
         det, seg = net(x, r)
         loss_of(det, seg).backward()
@@ -223,7 +224,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -235,7 +236,7 @@ def main():
         step(args.warmup + i)
     fence()
     el = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -303,7 +304,7 @@ def main():
                            "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}", "launch": launch},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
