@@ -28,6 +28,7 @@ class GradBucketer:
         self.group = process_group
         self.average = average
         self.deferred = False      # True: no collective inside backward (HIP-graph capture); call allreduce_all()
+        self.force_collective = False   # issue the collectives even with one rank (single-GPU test of the RCCL path)
         self.params = [p for p in params_in_backward_order if p.requires_grad and p.numel() > 0]
         self.bucket_of, self.views, self.buckets, self.pending0 = {}, {}, [], []
         cur, cur_bytes = [], 0
@@ -40,9 +41,16 @@ class GradBucketer:
                 cur, cur_bytes = [], 0
         if cur:
             groups.append(cur)
+        # one contiguous arena, buckets are consecutive slices of it: the deferred (HIP-graph) mode reduces the whole
+        # arena with a single collective, the overlapped mode one slice at a time (slices start 256-byte aligned)
+        sizes = [-(-sum(p.numel() for p in g) // 64) * 64 for g in groups]
+        ref = self.params[0] if self.params else None
+        self.arena = torch.zeros(sum(sizes), dtype=ref.dtype, device=ref.device) if ref is not None else None
+        base = 0
         for bi, g in enumerate(groups):
             n = sum(p.numel() for p in g)
-            flat = torch.zeros(n, dtype=g[0].dtype, device=g[0].device)
+            flat = self.arena[base:base + n]
+            base += sizes[bi]
             off = 0
             for p in g:
                 self.views[p] = flat[off:off + p.numel()].view_as(p)
@@ -73,7 +81,9 @@ class GradBucketer:
     def _launch(self, bi):
         if self.deferred:
             return
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size(self.group) == 1 and not self.force_collective:
             return
         flat = self.buckets[bi]
         if self.average and dist.get_backend(self.group) == "nccl":
@@ -102,19 +112,19 @@ class GradBucketer:
 
 
 def _allreduce_all(self):
-    """Deferred mode: all buckets at once, after the captured step has been replayed."""
-    was, self.deferred = self.deferred, False
-    try:
-        for bi in range(len(self.buckets)):
-            self._launch(bi)
-        ws = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        for w, scale in self.works:
-            w.wait()
-            if scale is not None:
-                scale.div_(ws)
-        self.works = []
-    finally:
-        self.deferred = was
+    """Deferred mode: ONE collective over the whole gradient arena, after the captured step has been replayed (a
+    single large message drives all xGMI links; seven 32 MiB ones would pay the ring latency seven times)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    ws = dist.get_world_size(self.group)
+    if ws == 1 and not self.force_collective:
+        return
+    if self.average and dist.get_backend(self.group) == "nccl":
+        dist.all_reduce(self.arena, op=dist.ReduceOp.AVG, group=self.group)
+    else:
+        dist.all_reduce(self.arena, op=dist.ReduceOp.SUM, group=self.group)
+        if self.average:
+            self.arena.div_(ws)
 
 
 GradBucketer.allreduce_all = _allreduce_all

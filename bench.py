@@ -197,6 +197,8 @@ def main():
     if args.serial:
         model.concurrent = False
     net = DataParallelVRNet(model) if (world > 1 or dist.is_initialized()) else model
+    if net is not model and force_dp:
+        net.bucketer.force_collective = True
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 
     def eager_step(i):

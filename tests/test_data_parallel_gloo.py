@@ -47,6 +47,16 @@ def _worker(rank, world, port, q):
         bk.mark_ready(p)
     bk.finish()
     ok = ok and all(torch.allclose(p.grad, torch.full_like(p, (world - 1) / 2)) for p in bk.params)
+    # deferred mode (HIP-graph step): nothing is sent during the pass, one collective over the whole arena afterwards
+    bk.deferred = True
+    for i, p in enumerate(bk.params):
+        bk.view(p).fill_(float(rank + 1) * (1 + i % 3))
+        bk.mark_ready(p)
+    ok = ok and not bk.works
+    bk.allreduce_all()
+    bk.reset()
+    ok = ok and all(torch.allclose(bk.view(p), torch.full_like(p, (1 + i % 3) * 1.5)) for i, p in enumerate(bk.params))
+    ok = ok and all(bk.view(p).data_ptr() >= bk.arena.data_ptr() for p in bk.params)
     q.put((rank, ok))
     dist.destroy_process_group()
 

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--cold", action="store_true", help="flush L2/MALL (1 GiB fill) before every timed launch: in-net rates")
     args = ap.parse_args()
     import asy_vrnet_amd as A
     from asy_vrnet_amd import hip
@@ -52,18 +53,29 @@ def main():
             key = (kind, 2, B, H, W, Ci, OH, OW, Co, kh, s, d, 0, False, False, False, False)
         groups.setdefault(key, []).append((kind, a, k))
     rows = []
+    flush = torch.zeros(1 << 28, device=dev) if args.cold else None
     for key, lst in groups.items():
         kind, a, k = lst[0]
         fn = o_conv if kind == "conv" else o_wgrad
         fn(*a, **k)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.reps):
-            fn(*a, **k)
-        e1.record()
-        torch.cuda.synchronize()
-        us = 1e3 * e0.elapsed_time(e1) / args.reps
+        if args.cold:
+            us = 0.0
+            for _ in range(args.reps):
+                flush.add_(1.0)
+                e0.record()
+                fn(*a, **k)
+                e1.record()
+                torch.cuda.synchronize()
+                us += 1e3 * e0.elapsed_time(e1) / args.reps
+        else:
+            e0.record()
+            for _ in range(args.reps):
+                fn(*a, **k)
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / args.reps
         _, mode, B, H, W, Ci, OH, OW, Co, kh, s, d = key[:12]
         gf = 2.0 * B * OH * OW * Co * Ci * kh * kh / 1e9
         rows.append((us * len(lst), len(lst), us, gf, key))
