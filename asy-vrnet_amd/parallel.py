@@ -139,17 +139,20 @@ def backward_param_order(model):
 class DataParallelVRNet(torch.nn.Module):
     """Drop-in for DistributedDataParallel(EfficientVRNet) on one node (one process per GPU)."""
 
-    def __init__(self, module, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, module, bucket_bytes=32 << 20, process_group=None, force_collective=False):
         super().__init__()
         self.module = module
         self.bucketer = GradBucketer(backward_param_order(module), bucket_bytes, process_group)
+        self.bucketer.force_collective = force_collective   # collectives even with one rank (single-GPU RCCL rehearsal)
         module._grad_bucketer = self.bucketer
         module._on_param_grad = self.bucketer.mark_ready
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force_collective):
             with torch.no_grad():                       # replicas start identical (DDP broadcasts at wrap time)
                 for t in list(module.parameters()) + list(module.buffers()):
                     if t.numel():
                         dist.broadcast(t, src=0, group=process_group)
+            if t.is_cuda:
+                torch.cuda.synchronize(t.device)        # no collective left in flight when a HIP-graph capture starts
 
     def forward(self, x, x_radar):
         return self.module(x, x_radar)

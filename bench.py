@@ -196,9 +196,7 @@ def main():
     model.compute_dtype = args.dtype
     if args.serial:
         model.concurrent = False
-    net = DataParallelVRNet(model) if (world > 1 or dist.is_initialized()) else model
-    if net is not model and force_dp:
-        net.bucketer.force_collective = True
+    net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 
     def eager_step(i):
