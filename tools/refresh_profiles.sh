@@ -1,0 +1,20 @@
+#!/bin/bash
+# Regenerates the evidence under profiles/ (run on the MI355X box; outputs land in gpurun_out/refresh/, copy them to
+# profiles/ with the round prefix afterwards):  bash tools/refresh_profiles.sh
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+out=gpurun_out/refresh
+rm -rf $out; mkdir -p $out
+python3 bench.py > $out/bench_phi-l_bs8_512.json 2> $out/bench_l.err
+python3 bench.py --phi nano --no-cpu-baseline > $out/bench_phi-nano_bs8_512.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --dtype bf16 > $out/bench_phi-l_bs8_512_bf16.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --dtype bf16 --batch 16 > $out/bench_phi-l_bs16_512_bf16.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --detail 2> $out/per_shape_detail_phi-l_bs8_512.txt > /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/graph -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > $out/graph.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --serial --no-graph > $out/serial.log 2>&1
+cp $(ls $out/graph/*/*kernel_stats.csv | head -1) $out/kernel_stats_phi-l_bs8_512_hipgraph.csv
+cp $(ls $out/serial/*/*kernel_stats.csv | head -1) $out/kernel_stats_phi-l_bs8_512_serial.csv
+rm -rf $out/graph $out/serial
+bash tools/pmc_traffic.sh $out/hbm_traffic_pmc_phi-l_bs8_512.csv > $out/pmc.log 2>&1
+rm -rf gpurun_out/pmc_traffic
+ls -la $out
