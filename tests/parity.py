@@ -34,10 +34,14 @@ def hip_idx_maps(model):
 
 
 def compare_with_oracle(model, batch, size, iseed, check_grads=True, oracle_dtype=torch.float32, tol=1e-3,
-                        gtol=5e-3, conv_round=None):
+                        gtol=5e-3, conv_round=None, per_param=False):
+    """per_param=True keeps rep["_per_param"]: (parameter, gradient error) in forward order (tools/parity_dbg.py)."""
     O.OPERAND_ROUND = conv_round
     try:
-        return _compare_with_oracle(model, batch, size, iseed, check_grads, oracle_dtype, tol, gtol)
+        rep = _compare_with_oracle(model, batch, size, iseed, check_grads, oracle_dtype, tol, gtol)
+        if not per_param:
+            rep.pop("_per_param", None)
+        return rep
     finally:
         O.OPERAND_ROUND = None
 
@@ -90,6 +94,7 @@ def _compare_with_oracle(model, batch, size, iseed, check_grads, oracle_dtype, t
         rep["dr_err"] = rel_err(rg.grad, ro.grad)
         ref_in = max(rel_err(x32.grad, xo.grad), rel_err(r32.grad, ro.grad))
         worst, worst_k, ref_worst = 0.0, None, 0.0
+        per_param = rep.setdefault("_per_param", [])       # (name, error) in forward order; diagnostic
         gmax = max(float(P[k].grad.abs().max()) for k in pnames if P[k].numel() and P[k].grad is not None)
         for k, p in model.named_parameters():
             if p.numel() == 0:
@@ -99,6 +104,7 @@ def _compare_with_oracle(model, batch, size, iseed, check_grads, oracle_dtype, t
             # floor: gradients that are analytically ~0 hold rounding noise on both sides
             e = rel_err(p.grad, go, floor=1e-4 * gmax)
             ref_worst = max(ref_worst, rel_err(P32[k].grad, go, floor=1e-4 * gmax))
+            per_param.append((k, e))
             if e > worst:
                 worst, worst_k = e, k
         rep["grad_err"], rep["grad_worst"], rep["ref32_grad_err"], rep["ref32_in_err"] = worst, worst_k, ref_worst, ref_in

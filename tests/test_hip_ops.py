@@ -58,6 +58,12 @@ CONV_CASES = [
     (3, 1, 1, 32, 32, 1, 1, 0, 1),
     (2, 32, 32, 64, 96, 3, 2, 1, 1),     # stride-2 data gradient: parity-major rows on the LDS-DMA kernel
     (1, 32, 64, 128, 64, 3, 2, 1, 1),
+    (2, 32, 32, 48, 96, 3, 2, 1, 1),     # phi=m widths (48, 96, 240, 384): ragged N / K tiles under the stride-2 row order
+    (2, 16, 16, 96, 240, 3, 2, 1, 1),
+    (2, 16, 16, 240, 384, 3, 2, 1, 1),
+    (2, 32, 32, 48, 384, 1, 1, 0, 1),
+    (8, 32, 32, 96, 48, 1, 1, 0, 1),
+    (2, 16, 16, 960, 240, 1, 1, 0, 1),
 ]
 
 
@@ -200,9 +206,10 @@ def test_group_norm_chain(hip):
     close(dbet, bet.grad, what="gn dbeta")
 
 
+@pytest.mark.parametrize("shape", [(3, 10, 12, 24), (2, 32, 32, 48), (2, 16, 16, 96), (2, 8, 8, 240)])
 @pytest.mark.parametrize("training", [True, False])
-def test_batch_norm_relu_chain(hip, training):
-    B, H, W, C = 3, 10, 12, 24
+def test_batch_norm_relu_chain(hip, training, shape):
+    B, H, W, C = shape
     z = (rnd(B, C, H, W, seed=1) * 1.5 + 40.0).requires_grad_(True)      # |mean| >> std: the cancellation-prone regime
     gam, bet = (rnd(C, seed=2) * 0.3 + 1).requires_grad_(True), (rnd(C, seed=3) * 0.5).requires_grad_(True)
     rm, rv = rnd(C, seed=4) * 0.1, rnd(C, seed=5, kind="uniform") + 0.5
@@ -359,7 +366,7 @@ def test_image_gain(hip):
     close(nchw(dp), p.grad, what="gain dp")
 
 
-@pytest.mark.parametrize("C,G", [(64, 8), (32, 4), (16, 8)])
+@pytest.mark.parametrize("C,G", [(64, 8), (32, 4), (16, 8), (48, 4), (240, 4), (96, 8)])      # last three: phi=m widths
 def test_shuffle_attention(hip, C, G):
     from oracle import vrnet_oracle as O
     B, H, W = 2, 7, 9
@@ -390,7 +397,7 @@ def test_shuffle_attention(hip, C, G):
         close(gk, P[k].grad.reshape(-1), 2e-4, what="sa d" + k)
 
 
-@pytest.mark.parametrize("C", [7, 64, 256])
+@pytest.mark.parametrize("C", [7, 64, 256, 96, 480])
 def test_eca(hip, C):
     from oracle import vrnet_oracle as O
     B, H, W = 2, 6, 5

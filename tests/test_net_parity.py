@@ -25,13 +25,18 @@ def build(A, phi, size, pseed, training):
     return m.train(training)
 
 
-@pytest.mark.parametrize("phi,size,batch,training", [
-    ("nano", 64, 2, True), ("nano", 64, 2, False), ("nano", 128, 2, True), ("tiny", 128, 3, True),
-    ("nano", 256, 2, True), ("l", 128, 2, True)])
-def test_against_oracle(A, phi, size, batch, training):
+@pytest.mark.parametrize("phi,size,batch,training,seeds", [
+    ("nano", 64, 2, True, (21, 31)), ("nano", 64, 2, False, (21, 31)), ("nano", 128, 2, True, (21, 31)),
+    ("tiny", 128, 3, True, (21, 31)), ("nano", 256, 2, True, (21, 31)), ("l", 128, 2, True, (21, 31)),
+    ("s", 128, 2, True, (21, 31)), ("m", 128, 2, True, (3, 9))])
+def test_against_oracle(A, phi, size, batch, training, seeds):
+    """Seeds: with (21, 31) phi=m has ONE BatchNorm+ReLU pre-activation (of 98 304 in that layer) within fp32 rounding
+    of zero; its mask bit differs between this path and the fp64 oracle -- and between the LDS-DMA and the
+    register-staged igemm (tools/conv_trace.py shows exactly that one bit) -- which moves the gradients behind it
+    by ~1e-2 (discontinuities).  (3, 9) has no such element."""
     from tests.parity import compare_with_oracle
-    m = build(A, phi, size, 21, training)
-    rep = compare_with_oracle(m, batch, size, iseed=31, check_grads=training, oracle_dtype=torch.float64)
+    m = build(A, phi, size, seeds[0], training)
+    rep = compare_with_oracle(m, batch, size, iseed=seeds[1], check_grads=training, oracle_dtype=torch.float64)
     print(rep)
     assert rep["ok"], rep
 
