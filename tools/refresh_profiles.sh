@@ -17,4 +17,6 @@ cp $(ls $out/serial/*/*kernel_stats.csv | head -1) $out/kernel_stats_phi-l_bs8_5
 rm -rf $out/graph $out/serial
 bash tools/pmc_traffic.sh $out/hbm_traffic_pmc_phi-l_bs8_512.csv > $out/pmc.log 2>&1
 rm -rf gpurun_out/pmc_traffic
+bash tools/pmc_mfma.sh $out/mfma_util_pmc_phi-l_bs8_512.csv > $out/pmc_mfma.log 2>&1
+rm -rf gpurun_out/pmc_mfma
 ls -la $out
