@@ -296,6 +296,11 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
   const int tid = threadIdx.x, lane = tid & 63;
   // wave id as a scalar: the LDS destinations of the DMAs (M0) then come from SALU arithmetic, not from a
   // v_readfirstlane per piece
+  // The zero page's address is taken ONCE and made opaque: left to itself hipcc re-derives it from the GOT
+  // (s_getpc + s_load_dwordx2 + s_waitcnt lgkmcnt(0)) in front of EVERY DMA of the main loop, and that wait also
+  // drains the fragment ds_reads in flight.
+  const float* zero_page = vr_zero_page;
+  asm volatile("" : "+s"(zero_page));
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int L = blockIdx.x, jj = L >> 3;
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     for (int i = 0; i < 2; ++i) {
       int sy, sx;
       const bool ok = src_of(i, ky, kx, sy, sx) && 4 * a_q[i] < p.CK;
-      a_run[i] = ok ? p.a + ((long)(a_b[i] * p.SH + sy) * p.SW + sx) * p.lda + 4 * a_q[i] : vr_zero_page;
+      a_run[i] = ok ? p.a + ((long)(a_b[i] * p.SH + sy) * p.SW + sx) * p.lda + 4 * a_q[i] : zero_page;
       a_inc[i] = ok ? BK : 0;
       a_k[i] = 4 * a_q[i];
     }
@@ -388,13 +393,13 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
       if (MODE == 0) {           // rows n, contiguous contraction: same image as A
         const int r = sl / QPR, q = (sl % QPR) ^ ((r >> RSH) & (QPR - 1));
         const bool ok = n0 + r < p.CN && 4 * q < p.CK;
-        b_run[i] = ok ? wt + (long)(n0 + r) * p.Cin + 4 * q : vr_zero_page;
+        b_run[i] = ok ? wt + (long)(n0 + r) * p.Cin + 4 * q : zero_page;
         b_inc[i] = ok ? BK : 0;
         b_k[i] = 4 * q;
       } else {                   // rows = contraction index, contiguous output channels: linear [BK][BN]
         const int kr = sl / (BN / 4), col = n0 + 4 * (sl % (BN / 4));
         const bool ok = col < p.CN && kr < p.CK;
-        b_run[i] = ok ? wt + (long)kr * p.Cin + col : vr_zero_page;
+        b_run[i] = ok ? wt + (long)kr * p.Cin + col : zero_page;
         b_inc[i] = ok ? BK * p.Cin : 0;
         b_k[i] = kr;
       }
@@ -413,13 +418,13 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     const bool last = k_tail && ld_kb == nkb - 1;          // block-uniform
     const int c0 = ld_kb * BK;
     if (i < 2) {
-      const float* src = (last && c0 + a_k[i] >= p.CK) ? vr_zero_page : a_run[i];
+      const float* src = (last && c0 + a_k[i] >= p.CK) ? zero_page : a_run[i];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(stage + (wave * 2 + i) * 256), 16, 0, 0);
       a_run[i] += a_inc[i];
     } else {
       const int j = i - 2;
-      const float* src = (last && c0 + b_k[j] >= p.CK) ? vr_zero_page : b_run[j];
+      const float* src = (last && c0 + b_k[j] >= p.CK) ? zero_page : b_run[j];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(stage + A_FLOATS + (wave * 2 + j) * 256),
                                        16, 0, 0);
@@ -734,20 +739,22 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradArgs p) {
     s_kr[i] = sl >> 4;
     s_cq[i] = 4 * (sl & 15);
   }
+  const float* zero_page = vr_zero_page;          // taken once and opaque: see igemm_dma_kernel
+  asm volatile("" : "+s"(zero_page));
   int ld_m = m_begin, ld_buf = 0;
   auto issue = [&]() {
     float* stage = smem + ld_buf * ST_FLOATS;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = ld_m + s_kr[i];
-      const float* src = (m < m_end && n0 + s_cq[i] < p.Cout) ? p.dy + (long)m * p.lddy + n0 + s_cq[i] : vr_zero_page;
+      const float* src = (m < m_end && n0 + s_cq[i] < p.Cout) ? p.dy + (long)m * p.lddy + n0 + s_cq[i] : zero_page;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(stage + (wave * 2 + i) * 256), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = ld_m + s_kr[i];
-      const float* src = vr_zero_page;
+      const float* src = zero_page;
       if (m < m_end && c0 + s_cq[i] < p.Cin) {
         if (IDENT) {
           src = p.x + (long)m * p.ldx + c0 + s_cq[i];
