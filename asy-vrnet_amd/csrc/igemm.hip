@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     ntaps = __popc(*tapmask_s);
   }
   if (MODE == 1 && p.kscale) {
-    for (int i = tid; i < p.CK; i += 256) ks_s[i] = p.kscale[i];
+    for (int i = tid; i < nkb * BK; i += 256) ks_s[i] = i < p.CK ? p.kscale[i] : 0.f;   // padded: the loop reads it unguarded
     __syncthreads();     // ordinary loads retire here, before the first DMA is issued
   }
   const int nsteps = ntaps * nkb;
@@ -510,16 +510,14 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
         for (int j = 0; j < KQ; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) bq[i][j][e] = Bs[(4 * KQ * h + 4 * j + e) * BN + b_off[i]];
-      if (p.kscale) {
+      if (p.kscale) {      // all quads of the (zero-padded) stash first: one LDS wait for the stage, not one per quad
+        f32x4 ks[KQ];
 #pragma unroll
-        for (int j = 0; j < KQ; ++j) {
-          const int k = kb * BK + 4 * KQ * h + 4 * j;     // CK % 4 == 0: a quad is inside the stash or all-zero data
-          if (k < p.CK) {
-            const f32x4 ks = *reinterpret_cast<const f32x4*>(ks_s + k);
+        for (int j = 0; j < KQ; ++j) ks[j] = *reinterpret_cast<const f32x4*>(ks_s + kb * BK + 4 * KQ * h + 4 * j);
 #pragma unroll
-            for (int i = 0; i < T; ++i) bq[i][j] *= ks;
-          }
-        }
+        for (int j = 0; j < KQ; ++j)
+#pragma unroll
+          for (int i = 0; i < T; ++i) bq[i][j] *= ks[j];
       }
     }
 #ifdef VR_IGEMM_STAMP
