@@ -53,6 +53,7 @@ class RT:
         self.bf16 = False           # dense convs with bf16-rounded operands on the bf16 MFMA (model.compute_dtype)
         self.consts = {}
         self.idx_maps = {}
+        self.relu_masks = None      # {BatchNorm module: ReLU output Act} when model.record_relu_masks (parity tests)
         self.on_param_grad = None
         self.bucketer = None        # parallel.GradBucketer: gradients are written into its flat buckets
         self.det_grads, self.seg_grad = (None, None, None), None
@@ -364,6 +365,8 @@ def bn_forward(rt, z, bn, relu, out=None, residual=None):
     y = out if out is not None else rt.new(z.B, z.H, z.W, C)
     hip.affine(y.t, y.ld, B, HW, C, x1=z.t, ld1=z.ld, A=A, D1=D, S1=S, pre=1 if relu else 0,
                x2=None if residual is None else residual.t, ld2=0 if residual is None else residual.ld)
+    if relu and rt.relu_masks is not None:
+        rt.relu_masks[bn] = y
     return y, ms
 
 
@@ -1028,6 +1031,8 @@ class _VRNetFunction(torch.autograd.Function):
         rt.bucketer = getattr(model, "_grad_bucketer", None)
         rt.aside_ok = rt.bucketer is None or rt.bucketer.deferred
         rt.on_param_grad = getattr(model, "_on_param_grad", None) if rt.bucketer is not None else None
+        if getattr(model, "record_relu_masks", False):
+            rt.relu_masks = {}
         fq = getattr(model, "_fused_qkv", None)
         if fq is None or fq.owner != id(model) or fq.dst[0].device != x.device:
             fq = model._fused_qkv = FusedQKV(model, x.device)
@@ -1046,6 +1051,9 @@ class _VRNetFunction(torch.autograd.Function):
         ctx.model = model
         ctx.set_materialize_grads(False)
         model._last_idx_maps = rt.idx_maps
+        if rt.relu_masks is not None:        # {BatchNorm state_dict prefix: (B,H,W,C) bool}: which ReLU inputs were > 0
+            names = {mod: k for k, mod in model.named_modules()}
+            model._last_relu_masks = {names[bn]: (a.t > 0) for bn, a in rt.relu_masks.items()}
         return (*dets, seg)
 
     @staticmethod

@@ -38,8 +38,14 @@ def stage_dims(width):
 class Ctx:
     """Carries mode + side outputs (BN running-stat updates, Cluster assignment maps)."""
 
-    def __init__(self, training, forced_idx=None):
+    def __init__(self, training, forced_idx=None, forced_relu=None):
         self.training = training
+        # Teacher forcing of the ReLU masks behind BatchNorm (the other discontinuity of the path): when given,
+        # relu site `key` (= its BatchNorm's state_dict prefix) multiplies by forced_relu[key] (B,C,H,W bool) instead
+        # of its own (z > 0) and records in relu_report[key] how many elements disagree and the largest |z| among
+        # them: a legitimate flip is a pre-activation within rounding of zero.
+        self.forced_relu = forced_relu
+        self.relu_report = {}
         self.new_stats = {}
         self.idx = {}
         self.taps = {}
@@ -102,10 +108,25 @@ def group_norm1(P, pre, x, eps=1e-5):
     return xh * P[pre + ".weight"][None, :, None, None] + P[pre + ".bias"][None, :, None, None]
 
 
+def relu_site(ctx, key, z):
+    """ReLU behind the BatchNorm `key`; mask-aware when ctx.forced_relu holds a mask for it."""
+    forced = None if ctx.forced_relu is None else ctx.forced_relu.get(key)
+    if forced is None:
+        return torch.relu(z)
+    forced = forced.to(z.device)
+    own = z.detach() > 0
+    diff = own != forced
+    n = int(diff.sum())
+    ctx.relu_report[key] = {"elements": z.numel(), "mismatch": n,
+                            "max_abs": float(z.detach().abs()[diff].max()) if n else 0.0,
+                            "scale": float(z.detach().abs().max())}
+    return z * forced.to(z.dtype)
+
+
 def base_conv(P, pre, x, k, ctx, stride=1):
     """BaseConv (backbone/conv_utils/normal_conv.py:37-49): conv(no bias) -> BN(1e-3, .03) -> ReLU."""
     z = conv(P, pre + ".conv", x, stride, (k - 1) // 2)
-    return torch.relu(batch_norm(P, pre + ".bn", z, ctx, eps=1e-3, momentum=0.03))
+    return relu_site(ctx, pre + ".bn", batch_norm(P, pre + ".bn", z, ctx, eps=1e-3, momentum=0.03))
 
 
 def ds_base_conv(P, pre, x, ctx):
@@ -113,7 +134,7 @@ def ds_base_conv(P, pre, x, ctx):
     c = x.shape[1]
     z = conv(P, pre + ".conv.dconv", x, 1, 1, 1, groups=c)
     z = conv(P, pre + ".conv.pconv", z)
-    return torch.relu(batch_norm(P, pre + ".bn", z, ctx, eps=1e-3, momentum=0.03))
+    return relu_site(ctx, pre + ".bn", batch_norm(P, pre + ".bn", z, ctx, eps=1e-3, momentum=0.03))
 
 
 def shuffle2(x):
@@ -276,13 +297,13 @@ def aspp(P, pre, x, ctx):
     """ASPP.forward (coc_fpn_dual.py:79-104)."""
     def branch(name, d):
         z = conv(P, f"{pre}.{name}.0", x, 1, 0 if d == 0 else d, max(d, 1))
-        return torch.relu(batch_norm(P, f"{pre}.{name}.1", z, ctx))
+        return relu_site(ctx, f"{pre}.{name}.1", batch_norm(P, f"{pre}.{name}.1", z, ctx))
     outs = [branch("branch1", 0), branch("branch2", 6), branch("branch3", 12), branch("branch4", 18)]
     g = x.mean(dim=(2, 3), keepdim=True)
-    g = torch.relu(batch_norm(P, pre + ".branch5_bn", conv(P, pre + ".branch5_conv", g), ctx))
+    g = relu_site(ctx, pre + ".branch5_bn", batch_norm(P, pre + ".branch5_bn", conv(P, pre + ".branch5_conv", g), ctx))
     outs.append(g.expand(-1, -1, x.shape[2], x.shape[3]))      # bilinear from 1x1, align_corners: constant
     z = conv(P, pre + ".conv_cat.0", torch.cat(outs, dim=1))
-    return torch.relu(batch_norm(P, pre + ".conv_cat.1", z, ctx))
+    return relu_site(ctx, pre + ".conv_cat.1", batch_norm(P, pre + ".conv_cat.1", z, ctx))
 
 
 # ----------------------------------------------------------------------------- assembly
@@ -344,9 +365,9 @@ def head(P, pre, feats, ctx):
     return outs
 
 
-def forward(P, x, x_radar, phi="nano", training=True, forced_idx=None):
+def forward(P, x, x_radar, phi="nano", training=True, forced_idx=None, forced_relu=None):
     """EfficientVRNet.forward (nets/efficient_vrnet.py:24-27).  Returns (det list[3], seg, ctx)."""
-    ctx = Ctx(training, forced_idx)
+    ctx = Ctx(training, forced_idx, forced_relu)
     width = WIDTH[phi]
     feats, seg = neck(P, "backbone", x, x_radar, width, ctx)
     det = head(P, "head", feats, ctx)

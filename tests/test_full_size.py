@@ -55,9 +55,13 @@ def test_l_512_against_oracle(A):
     assert rep["ok"], rep
 
 
-def test_bs8_train_step_is_repeatable_linear_and_permutation_equivariant(A, net):
+def check_train_step_properties(A, net, batch, size, lin_tol, perm_tol):
+    """Size-independent properties of one forward+backward: (1) two runs are identical bit for bit (outputs, every
+    parameter gradient, BatchNorm running statistics: all reductions are order-fixed); (2) the backward pass is
+    linear in the upstream gradient; (3) a permutation of the batch permutes the outputs and leaves the parameter
+    gradients unchanged (to rounding: BatchNorm statistics / weight gradients sum over the batch in another order)."""
     net.train()
-    x, r = A.synthetic_inputs(8, 512, 11, "cuda")
+    x, r = A.synthetic_inputs(batch, size, 11, "cuda")
     bn_state = {k: v.clone() for k, v in net.state_dict().items()}
 
     def fresh():
@@ -75,25 +79,78 @@ def test_bs8_train_step_is_repeatable_linear_and_permutation_equivariant(A, net)
     assert torch.equal(seg_a, seg_b) and all(torch.equal(p, q) for p, q in zip(det_a, det_b))
     assert ga.keys() == gb.keys() and all(torch.equal(ga[k], gb[k]) for k in ga)
     assert all(torch.equal(v, sd_a[k]) for k, v in net.state_dict().items())
+    assert all(torch.isfinite(v).all() for v in ga.values()) and torch.isfinite(seg_a).all()
     # 2. the backward pass is linear in the upstream gradient
     fresh(); _, _, g2 = run(net, x, r, g2d, g2s)
     fresh(); _, _, g12 = run(net, x, r, [2.0 * a - 0.5 * b for a, b in zip(g1d, g2d)], 2.0 * g1s - 0.5 * g2s)
-    errs = {k: rel(g12[k], 2.0 * ga[k] - 0.5 * g2[k]) for k in ga if ga[k].abs().max() > 0}
-    bad = sorted(((e, k, float(ga[k].abs().max()), float(g2[k].abs().max())) for k, e in errs.items() if e > 1e-3), reverse=True)
-    print("linearity outliers:", bad[:12], len(bad), len(errs))
     num = sum(float(((g12[k].double() - (2.0 * ga[k].double() - 0.5 * g2[k].double())) ** 2).sum()) for k in ga)
     den = sum(float((g12[k].double() ** 2).sum()) for k in ga)
     print("linearity aggregate", (num / den) ** 0.5)
-    assert (num / den) ** 0.5 < 1e-4
-    # 3. permuting the batch permutes the outputs and leaves the parameter gradients alone (BatchNorm statistics
-    #    and weight gradients are sums over the batch: only the summation order moves)
-    perm = torch.tensor([5, 2, 7, 0, 3, 6, 1, 4], device="cuda")
+    assert (num / den) ** 0.5 < lin_tol
+    # 3. permuting the batch permutes the outputs and leaves the parameter gradients alone
+    perm = torch.randperm(batch, generator=torch.Generator().manual_seed(5)).cuda()
+    assert not torch.equal(perm, torch.arange(batch, device="cuda"))
     fresh(); det_p, seg_p, gp = run(net, x[perm].contiguous(), r[perm].contiguous(), [g[perm].contiguous() for g in g1d], g1s[perm].contiguous())
-    assert rel(seg_p, seg_a[perm]) < 1e-3 and all(rel(p, q[perm]) < 1e-3 for p, q in zip(det_p, det_a)), \
-        (rel(seg_p, seg_a[perm]), [rel(p, q[perm]) for p, q in zip(det_p, det_a)])
+    errs = (rel(seg_p, seg_a[perm]), [rel(p, q[perm]) for p, q in zip(det_p, det_a)])
+    print("permutation", errs)
+    assert errs[0] < perm_tol and all(e < perm_tol for e in errs[1]), errs
     num = sum(float(((gp[k].double() - ga[k].double()) ** 2).sum()) for k in ga)
     den = sum(float((ga[k].double() ** 2).sum()) for k in ga)
-    assert (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5
+    print("permutation grads aggregate", (num / den) ** 0.5)
+    assert (num / den) ** 0.5 < perm_tol
+
+
+def test_bs8_train_step_is_repeatable_linear_and_permutation_equivariant(A, net):
+    """BASELINE configs[1]: phi=l, 512 px, bs 8, fp32."""
+    check_train_step_properties(A, net, 8, 512, lin_tol=1e-4, perm_tol=1e-3)
+
+
+def test_bs16_bf16_train_step_properties(A, net):
+    """BASELINE configs[2]: phi=l, 512 px, bs 16, bf16-operand dense convs.  Rounding the operands (incl. the upstream
+    gradients) to bf16 is not linear and not order-free, so properties 2 and 3 hold to the bf16 step (2^-8), not to
+    fp32 rounding; bitwise repeatability holds unchanged."""
+    net.compute_dtype = "bf16"
+    try:
+        check_train_step_properties(A, net, 16, 512, lin_tol=2e-2, perm_tol=3e-2)
+    finally:
+        net.compute_dtype = "f32"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_1024_bs4_train_step_properties(A, dtype):
+    """BASELINE configs[4] (per-GPU share): phi=l, 1024 px, bs 4 -- 32x32-point regions in every backbone stage, the
+    streaming Cluster kernel in neck p4 / p3 (vr_coc.py:390,402-406 sizes fea_pos for the input)."""
+    m = A.EfficientVRNet(4, 9, "l", img_size=1024).cuda()
+    A.randomize_state_dict(m.state_dict(), seed=4)
+    m.compute_dtype = dtype
+    if dtype == "f32":
+        check_train_step_properties(A, m, 4, 1024, lin_tol=1e-4, perm_tol=1e-3)
+    else:
+        check_train_step_properties(A, m, 4, 1024, lin_tol=2e-2, perm_tol=3e-2)
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_nano_1024_train_against_oracle(A):
+    """configs[4]'s resolution with forward AND backward against the fp64 oracle (nano, bs 1: the oracle needs ~20 s)."""
+    from tests.parity import compare_with_oracle
+    m = A.EfficientVRNet(4, 9, "nano", img_size=1024).cuda().train()
+    A.randomize_state_dict(m.state_dict(), seed=13)
+    rep = compare_with_oracle(m, 1, 1024, iseed=17, check_grads=True, oracle_dtype=torch.float64)
+    print(rep)
+    assert rep["ok"], rep
+
+
+def test_nano_1024_bf16_train_against_oracle(A):
+    """The same at bf16 operands: the oracle rounds the same operands of the same layers (O.OPERAND_ROUND)."""
+    from tests.parity_bf16 import bf16_report
+    m = A.EfficientVRNet(4, 9, "nano", img_size=1024).cuda().train()
+    A.randomize_state_dict(m.state_dict(), seed=13)
+    rep = bf16_report(A, m, "nano", 1, 1024, iseed=17)
+    print(rep)
+    assert rep["flips"] <= max(30, rep["points"] // 1000), rep
+    assert rep["det_err"] < 4e-2 and rep["seg_err"] < 4e-2, rep
+    assert rep["grad_cos"] > 0.97 and rep["grad_rel_l2"] < 0.25, rep
 
 
 def test_bs8_eval_is_permutation_equivariant_bit_for_bit(A, net):

@@ -79,18 +79,23 @@ STAT_KEYS = [
 ]
 
 
-def whole_net(name, phi, size, batch, training, pseed, iseed, seg_stride=1, with_grads=True):
+def whole_net(name, phi, size, batch, training, pseed, iseed, seg_stride=1, with_grads=True, dtype=torch.float32):
+    """dtype=torch.float64: the reference itself evaluated in double (`m.double()`), i.e. the exact outputs and
+    gradients of the reference ALGORITHM -- the pin for the oracle's backward at the benchmark resolution, where
+    the reference's fp32 backward is 1-25 % away from the exact gradient."""
     m = build_reference_model(phi=phi, img_size=size)
     A.randomize_state_dict(m.state_dict(), seed=pseed)
     m.train(training)
     x, r = A.synthetic_inputs(batch, size, iseed)
+    if dtype != torch.float32:
+        m, x, r = m.to(dtype), x.to(dtype), r.to(dtype)
     x.requires_grad_(with_grads)
     r.requires_grad_(with_grads)
     det, seg = m(x, r)
     rec = {"det0": det[0], "det1": det[1], "det2": det[2], "seg": seg[:, :, ::seg_stride, ::seg_stride],
            "seg_sum": seg.double().sum(), "seg_abs_sum": seg.double().abs().sum()}
     meta = dict(phi=phi, size=size, batch=batch, training=training, pseed=pseed, iseed=iseed,
-                seg_stride=seg_stride)
+                seg_stride=seg_stride, dtype=str(dtype).replace("torch.", ""))
     if with_grads:
         loss_of(det, seg).backward()
         rec["loss"] = loss_of(det, seg)
@@ -150,6 +155,9 @@ def rnd(shape, seed, kind="normal"):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "fp64":        # only the double-precision 512 px case
+        whole_net("net_nano_512_train_fp64", "nano", 512, 2, True, 3, 9, seg_stride=16, dtype=torch.float64)
+        return
     # ---- state_dict surface (names, shapes, dtypes) for nano and l
     for phi in ("nano", "l"):
         m = build_reference_model(phi=phi, img_size=512)
@@ -163,6 +171,7 @@ def main():
     whole_net("net_nano_128_train", "nano", 128, 2, True, 2, 8)
     whole_net("net_tiny_128_eval", "tiny", 128, 1, False, 4, 10, with_grads=False)
     whole_net("net_nano_512_train", "nano", 512, 2, True, 3, 9, seg_stride=8)
+    whole_net("net_nano_512_train_fp64", "nano", 512, 2, True, 3, 9, seg_stride=16, dtype=torch.float64)
     # ---- sub-modules (seeded inputs: shape, seed, kind recorded in meta)
     def case(name, mod, shapes, kinds=None, **meta):
         kinds = kinds or ["normal"] * len(shapes)
