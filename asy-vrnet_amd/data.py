@@ -61,18 +61,18 @@ def letterbox_geometry(iw, ih, w, h):
 
 
 def adjust_boxes(box, iw, ih, w, h):
-    """dataloader.py:170-180 without the in-place shuffle: map xyxy boxes into the letterboxed canvas, clip, and drop
-    boxes of width or height <= 1."""
+    """Boxes (x1, y1, x2, y2, cls) of an iw x ih image -> the letterboxed w x h canvas: scaled and shifted like the
+    pixels, clipped to the canvas, and boxes thinner than 2 px dropped (semantics of dataloader.py:170-180, minus
+    its in-place shuffle)."""
     nw, nh, dx, dy = letterbox_geometry(iw, ih, w, h)
-    box = np.array(box, dtype=np.float64).reshape(-1, 5)
-    if len(box) == 0:
-        return box
-    box[:, [0, 2]] = box[:, [0, 2]] * nw / iw + dx
-    box[:, [1, 3]] = box[:, [1, 3]] * nh / ih + dy
-    box[:, 0:2][box[:, 0:2] < 0] = 0
-    box[:, 2][box[:, 2] > w] = w
-    box[:, 3][box[:, 3] > h] = h
-    return box[np.logical_and(box[:, 2] - box[:, 0] > 1, box[:, 3] - box[:, 1] > 1)]
+    out = np.array(box, dtype=np.float64).reshape(-1, 5)
+    if out.shape[0] == 0:
+        return out
+    gain = np.array([nw / iw, nh / ih, nw / iw, nh / ih])
+    shift = np.array([dx, dy, dx, dy], dtype=np.float64)
+    out[:, :4] = np.clip(out[:, :4] * gain + shift, 0.0, np.array([np.inf, np.inf, w, h]))
+    keep = ((out[:, 2] - out[:, 0]) > 1) & ((out[:, 3] - out[:, 1]) > 1)
+    return out[keep]
 
 
 def boxes_xyxy_to_cxcywh(box):

@@ -23,19 +23,17 @@ def decode_outputs(outputs, input_shape, local_rank=None):
 
 
 def yolo_correct_boxes(box_xy, box_wh, input_shape, image_shape, letterbox_image):
-    """utils_bbox.py:5-30: normalised centre/size -> (y1, x1, y2, x2) in pixels of the original image."""
-    box_yx = box_xy[..., ::-1]
-    box_hw = box_wh[..., ::-1]
-    input_shape = np.array(input_shape)
-    image_shape = np.array(image_shape)
+    """Normalised (cx, cy), (w, h) of the network input -> (y1, x1, y2, x2) in pixels of the original image, undoing
+    the letterbox when there was one (interface of utils/utils_bbox.py:5-30; host side, on the few boxes NMS keeps).
+    input_shape / image_shape are (H, W)."""
+    net_hw = np.asarray(input_shape, dtype=np.float64)
+    img_hw = np.asarray(image_shape, dtype=np.float64)
+    centre = np.asarray(box_xy, dtype=np.float64)[..., ::-1]          # (cy, cx)
+    size = np.asarray(box_wh, dtype=np.float64)[..., ::-1]            # (h, w)
     if letterbox_image:
-        new_shape = np.round(image_shape * np.min(input_shape / image_shape))
-        offset = (input_shape - new_shape) / 2. / input_shape
-        scale = input_shape / new_shape
-        box_yx = (box_yx - offset) * scale
-        box_hw = box_hw * scale
-    box_mins = box_yx - (box_hw / 2.)
-    box_maxes = box_yx + (box_hw / 2.)
-    boxes = np.concatenate([box_mins[..., 0:1], box_mins[..., 1:2], box_maxes[..., 0:1], box_maxes[..., 1:2]], axis=-1)
-    boxes = boxes * np.concatenate([image_shape, image_shape], axis=-1)
-    return boxes
+        # the image occupies a centred `inner` window of the network input: map window coordinates to [0, 1]
+        inner = np.round(img_hw * (net_hw / img_hw).min())
+        centre = (centre - 0.5 * (net_hw - inner) / net_hw) * (net_hw / inner)
+        size = size * (net_hw / inner)
+    top_left, bottom_right = centre - 0.5 * size, centre + 0.5 * size
+    return np.concatenate([top_left * img_hw, bottom_right * img_hw], axis=-1)

@@ -2,51 +2,106 @@
 
 The step is ~2000 kernel launches issued from Python; eager execution is launch-bound for the
 narrow widths.  Shapes, buffers and the launch sequence are static (no host sync anywhere on the
-path -- the reference's `if d_min < 0` sync, vr_coc.py:61, is dead code and dropped), so the whole step
-is captured once into a hipGraph and replayed: one graph launch per step.
+path -- the reference's `if d_min < 0` sync, vr_coc.py:61, is dead code and dropped), so the step
+is captured once and replayed.
+
+Single GPU: one hipGraph per step.  Data parallel (the reference: DDP's reducer overlapping the
+bucket all-reduces with autograd, train.py:367-368): the backward is cut at section boundaries into
+2-3 consecutive hipGraphs that share one memory pool; after segment k has been enqueued, the RCCL
+all-reduce of the gradient-arena slice it completed is issued (RCCL's stream waits for the work
+enqueued so far) and overlaps the replay of segment k+1.  Collectives stay outside the captured
+graphs.  Any change of shape (last batch of an epoch, validation loop) needs its own GraphedStep;
+the plain `model(x, r)` path stays available for those.
 """
 import torch
+
+from . import program
 
 
 class GraphedStep:
     """step(x, x_radar) -> loss tensor; parameter .grad tensors are static and rewritten by each replay.
 
-    `net` is EfficientVRNet or parallel.DataParallelVRNet.  With data parallelism the captured graph
-    writes the gradient buckets and the RCCL all-reduce of all buckets is issued right after the replay
-    (a collective inside a captured graph is avoided on purpose)."""
+    `net` is EfficientVRNet or parallel.DataParallelVRNet; loss_fn(det list, seg) -> scalar tensor."""
 
-    def __init__(self, net, loss_fn, batch, size, device, warmup=2):
+    def __init__(self, net, loss_fn, batch, size, device, warmup=2, segments=None):
         self.net, self.loss_fn = net, loss_fn
         self.model = getattr(net, "module", net)
         self.bucketer = getattr(self.model, "_grad_bucketer", None)
+        self.device = torch.device(device)
         self.x = torch.zeros((batch, 3, size, size), device=device)
         self.r = torch.zeros((batch, 4, size, size), device=device)
-        if self.bucketer is not None:
-            self.bucketer.deferred = True
         cur = torch.cuda.current_stream(device)
-        side = torch.cuda.Stream(device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):          # allocates workspaces / caches outside the capture
-                self._run()
-        cur.wait_stream(side)
+        self.stream = torch.cuda.Stream(device)          # warm-up AND capture run here: scratch arenas (hip.Workspace is
+        self.stream.wait_stream(cur)                     # keyed by stream) exist before the capture and belong to no graph pool
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(1, warmup)):              # allocates workspaces / caches outside the capture
+                self._eager()
+                if self.bucketer is not None and self.bucketer.recording:
+                    self.bucketer.rebuild_from_recording()      # arena in execution order before anything is captured
+        cur.wait_stream(self.stream)
         torch.cuda.synchronize(device)
         if self.bucketer is None:
             self.model.zero_grad(set_to_none=True)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._run()
+            cuts = []
+        else:
+            self.bucketer.deferred = True
+            cuts = list(self.bucketer.cuts) if (segments is None or segments > 1) else []
+        self.graphs = []
+        self._capture(cuts)
 
-    def _run(self):
+    def _eager(self):
         det, seg = self.net(self.x, self.r)
         loss = self.loss_fn(det, seg)
         loss.backward()
         return loss.detach()
 
+    def _capture(self, cuts):
+        """cuts: descending tape positions; segment 0 = forward + loss + backward down to cuts[0], ..."""
+        model = self.model
+        pool = None
+        state = {}
+
+        def seg0():
+            rt, inputs, dets, seg = program.forward_pass(model, self.x, self.r, record=True)
+            leaves = [d.requires_grad_(True) for d in dets] + [seg.requires_grad_(True)]
+            loss = self.loss_fn(leaves[:3], leaves[3])
+            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+            program.backward_begin(rt, grads[:3], grads[3])
+            state.update(rt=rt, inputs=inputs, n=len(rt.tape))
+            self.loss = loss.detach()
+
+        bounds = None
+        for k in range(len(cuts) + 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=self.stream):
+                if k == 0:
+                    seg0()
+                    n = state["n"]
+                    bounds = [n] + [c for c in cuts if 0 < c < n] + [0]
+                rt = state["rt"]
+                if k + 1 < len(bounds):
+                    program.backward_range(rt, bounds[k + 1], bounds[k])
+                if k + 2 == len(bounds):
+                    program.backward_end(rt, model, state["inputs"], (False, False))
+                else:
+                    program.backward_cut(rt)
+            pool = g.pool()
+            self.graphs.append(g)
+            if k + 2 >= len(bounds):
+                break
+
     def __call__(self, x, x_radar):
         self.x.copy_(x, non_blocking=True)
         self.r.copy_(x_radar, non_blocking=True)
-        self.graph.replay()
-        if self.bucketer is not None:
-            self.bucketer.allreduce_all()
+        bk = self.bucketer
+        if bk is None:
+            self.graphs[0].replay()
+        elif len(self.graphs) == 1:
+            self.graphs[0].replay()
+            bk.allreduce_all()
+        else:
+            for k, g in enumerate(self.graphs):
+                g.replay()
+                bk.allreduce_segment(k)
+            bk.wait()
         return self.loss

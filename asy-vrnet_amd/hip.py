@@ -94,20 +94,27 @@ def _check(rc, name):
         raise RuntimeError(f"{name}: {_lib.vrnet_last_error().decode()}")
 
 
+_DTYPES = frozenset((torch.float32, torch.float64, torch.uint8, torch.int64, torch.int32))
+
+
 def ptr(t):
-    return None if t is None else t.data_ptr()
+    """Device address of a tensor argument.  Every wrapper below passes its tensors through here, so a CPU tensor, an
+    unsupported dtype or a view whose innermost stride is not 1 (the kernels take a ROW stride, never an element
+    stride) raises instead of handing a meaningless pointer to a kernel."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("vrnet HIP path needs tensors on a HIP device (there is no CPU fallback)")
+    if t.dtype not in _DTYPES:
+        raise RuntimeError(f"vrnet HIP path: unsupported dtype {t.dtype}")
+    if t.dim() and t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise RuntimeError(f"vrnet HIP path: innermost dimension must be contiguous (shape {tuple(t.shape)}, "
+                           f"strides {t.stride()})")
+    return t.data_ptr()
 
 
 def stream():
     return torch.cuda.current_stream().cuda_stream
-
-
-def _require_gpu(*ts):
-    for t in ts:
-        if t is not None and not t.is_cuda:
-            raise RuntimeError("vrnet HIP path needs tensors on a HIP device (there is no CPU fallback)")
-        if t is not None and t.dtype not in (torch.float32, torch.float64, torch.uint8, torch.int64):
-            raise RuntimeError(f"unsupported dtype {t.dtype}")
 
 
 def empty(*shape, dtype=torch.float32, like=None, device=None):

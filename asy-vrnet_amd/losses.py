@@ -13,15 +13,26 @@ from . import hip
 
 
 def _pack_labels(labels, device):
-    """list of (n_i, 5) [cx, cy, w, h, cls] -> (B, Gmax, 5) float32 + counts (B,) int32 on `device`."""
+    """list of (n_i, 5) [cx, cy, w, h, cls] -> (B, Gmax, 5) float32 + counts (B,) int32 on `device`.  No host
+    synchronisation: the counts come from the shapes; labels that already live on the GPU (utils_fit.py:43 moves them
+    there) are packed by device-side slice copies, host labels go through ONE pinned staging buffer."""
     B = len(labels)
     counts = [int(l.shape[0]) if l is not None and l.numel() else 0 for l in labels]
     G = max(counts) if counts else 0
-    packed = torch.zeros((B, max(G, 1), 5), dtype=torch.float32)
-    for b, l in enumerate(labels):
-        if counts[b]:
-            packed[b, :counts[b]] = l.detach().to("cpu", torch.float32).reshape(-1, 5)
-    return packed.to(device, non_blocking=True), torch.tensor(counts, dtype=torch.int32).to(device, non_blocking=True), G
+    on_gpu = any(l is not None and l.is_cuda for l in labels)
+    if on_gpu:
+        packed = torch.zeros((B, max(G, 1), 5), dtype=torch.float32, device=device)
+        for b, l in enumerate(labels):
+            if counts[b]:
+                packed[b, :counts[b]] = l.detach().to(device, torch.float32).reshape(-1, 5)
+    else:
+        host = torch.zeros((B, max(G, 1), 5), dtype=torch.float32).pin_memory()
+        for b, l in enumerate(labels):
+            if counts[b]:
+                host[b, :counts[b]] = l.detach().to(torch.float32).reshape(-1, 5)
+        packed = host.to(device, non_blocking=True)
+    cnt = torch.tensor(counts, dtype=torch.int32).pin_memory().to(device, non_blocking=True)
+    return packed, cnt, G
 
 
 def _gpu_maps(inputs):
@@ -29,6 +40,14 @@ def _gpu_maps(inputs):
     if not outs or not all(o.is_cuda and o.dim() == 4 and o.shape[:2] == outs[0].shape[:2] for o in outs):
         raise RuntimeError("expects a list of (B, C, h, w) GPU tensors of one batch")
     return outs
+
+
+def _is_one(g):
+    """True when the upstream gradient is known WITHOUT a device sync to be the scalar 1 (a python number or a host
+    tensor); a device tensor is multiplied in (no sync)."""
+    if isinstance(g, (int, float)):
+        return g == 1
+    return (not g.is_cuda) and g.numel() == 1 and float(g) == 1.0
 
 
 class _YoloLossFn(torch.autograd.Function):
@@ -47,7 +66,8 @@ class _YoloLossFn(torch.autograd.Function):
     def backward(ctx, g):
         gs = ctx.grads
         ctx.grads = None
-        return (None, None, None, None, None) + tuple(x * g for x in gs)
+        # the kernel already scaled the gradients by `scale`; `g` is the upstream factor (1 for a plain sum of losses)
+        return (None, None, None, None, None) + tuple(gs if _is_one(g) else [x * g for x in gs])
 
 
 class YOLOLoss(nn.Module):

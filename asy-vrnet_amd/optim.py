@@ -7,7 +7,6 @@ of several elementwise launches per tensor (887 state_dict entries at any phi). 
 live on the GPU."""
 import math
 from copy import deepcopy
-from functools import partial
 
 import torch
 import torch.nn as nn
@@ -65,7 +64,6 @@ class _Table:
         self.sizes = torch.tensor(sizes, dtype=torch.int64, device=device)
         self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=device)
         self.chunk_index = torch.tensor(ci, dtype=torch.int32, device=device)
-        self.host = torch.zeros((n_roles, self.n), dtype=torch.int64).pin_memory()
         self.addrs = torch.zeros((n_roles, self.n), dtype=torch.int64, device=device)
         self.rows = [None] * n_roles
         self.sig = sig
@@ -75,8 +73,11 @@ class _Table:
         """Uploads the addresses of one role if they changed."""
         ptrs = [t.data_ptr() for t in tensors]
         if ptrs != self.rows[role]:
-            self.host[role] = torch.tensor(ptrs, dtype=torch.int64)
-            self.addrs[role].copy_(self.host[role], non_blocking=True)
+            # a FRESH pinned staging buffer per change: the caching host allocator keeps it alive until the async copy
+            # has run, so a host that is a step ahead never overwrites addresses a queued copy has yet to read (eager
+            # mode hands out new .grad tensors every backward; under a hipGraph the addresses never change)
+            staged = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
+            self.addrs[role].copy_(staged, non_blocking=True)
             self.rows[role] = ptrs
 
 
@@ -167,8 +168,18 @@ class _FusedOptimizer:
         flat = [p for g in self.param_groups for p in g["params"]]
         for g, sg in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in sg.items() if k != "params"})
-        self.state = {flat[int(i)]: {k: (v.to(flat[int(i)].device) if torch.is_tensor(v) else v) for k, v in st.items()}
-                      for i, st in sd["state"].items()}
+        state = {}
+        for i, st in sd["state"].items():
+            p, mine = flat[int(i)], {}
+            for k, v in st.items():
+                if k == "step":                       # torch.optim.Adam checkpoints carry a tensor step
+                    mine[k] = int(v.item()) if torch.is_tensor(v) else int(v)
+                elif v is None:                       # torch.optim.SGD before its first step: momentum_buffer None
+                    mine[k] = torch.zeros_like(p)
+                else:
+                    mine[k] = v.to(p.device) if torch.is_tensor(v) else v
+            state[p] = mine
+        self.state = state
         self._table.sig = None
 
 
@@ -210,15 +221,14 @@ class Adam(_FusedOptimizer):
         if tab is None:
             return
         lr, (b1, b2), eps = self._uniform("lr"), self._uniform("betas"), self._uniform("eps")
-        steps = set()
-        for st in tab.states:
-            st["step"] = st.get("step", 0) + 1
-            steps.add(st["step"])
-        if len(steps) != 1:
+        nxt = [int(st.get("step", 0)) + 1 for st in tab.states]
+        if len(set(nxt)) != 1:               # validated BEFORE any counter moves: an error leaves the state untouched
             raise RuntimeError("fused Adam: parameters with different step counts in one table (un-freeze with a new "
                                "optimizer, as train.py:575-590 does)")
+        for st in tab.states:
+            st["step"] = nxt[0]
         hip.mt_adam(tab.addrs, tab.sizes, tab.chunk_tensor, tab.chunk_index, tab.wd, tab.n, tab.n_chunks, CHUNK, float(lr),
-                    float(b1), float(b2), float(eps), int(steps.pop()))
+                    float(b1), float(b2), float(eps), nxt[0])
 
 
 def build_optimizer(model, optimizer_type, lr, momentum, weight_decay):
@@ -236,35 +246,49 @@ def build_optimizer(model, optimizer_type, lr, momentum, weight_decay):
 
 
 # ------------------------------------------------------------------------------------------- EMA
+_WRAPPERS = (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel)
+
+
 def is_parallel(model):
-    return type(model) in (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel)
+    """True for torch's own multi-device wrappers (interface of nets/yolo_training.py:430)."""
+    return isinstance(model, _WRAPPERS) and type(model) in _WRAPPERS
 
 
 def de_parallel(model):
-    return model.module if is_parallel(model) or hasattr(model, "module") and hasattr(model, "bucketer") else model
+    """The bare network behind torch's wrappers or this package's DataParallelVRNet (interface of yolo_training.py:435)."""
+    ours = hasattr(model, "bucketer") and hasattr(model, "module")
+    return model.module if (ours or is_parallel(model)) else model
 
 
 def copy_attr(a, b, include=(), exclude=()):
-    for k, v in b.__dict__.items():
-        if (len(include) and k not in include) or k.startswith("_") or k in exclude:
+    """Copies the public instance attributes of `b` onto `a` (interface of yolo_training.py:440): private names and
+    `exclude` are skipped; a non-empty `include` is a whitelist."""
+    wanted = set(include)
+    skipped = set(exclude)
+    for name in list(vars(b)):
+        if name.startswith("_") or name in skipped or (wanted and name not in wanted):
             continue
-        setattr(a, k, v)
+        setattr(a, name, getattr(b, name))
 
 
 class ModelEMA:
-    """nets/yolo_training.py:447-479: moving average of every floating entry of the state_dict (parameters AND
-    buffers, i.e. BatchNorm running statistics too); decay ramps as decay * (1 - exp(-updates / tau)).
-    The (ema, model) tensor pairs are resolved once per model object; call `refresh()` after replacing parameter
-    objects of the live model (load_state_dict copies in place and needs nothing)."""
+    """Moving average of every floating entry of the state_dict -- parameters AND buffers, i.e. BatchNorm running
+    statistics too -- with the decay ramp decay * (1 - exp(-updates / tau)) (semantics of nets/yolo_training.py:447-479).
+    One multi-tensor HIP launch per update (887 tensors); the (ema, model) tensor pairs are resolved once per model
+    object; call `refresh()` after replacing parameter objects of the live model (load_state_dict copies in place and
+    needs nothing)."""
 
     def __init__(self, model, decay=0.9999, tau=2000, updates=0):
-        self.ema = deepcopy(de_parallel(model)).eval()
-        self.updates = updates
-        self.decay = lambda x: decay * (1 - math.exp(-x / tau))
-        for p in self.ema.parameters():
-            p.requires_grad_(False)
+        self.ema = deepcopy(de_parallel(model))
+        self.ema.eval()
+        self.ema.requires_grad_(False)
+        self.updates = int(updates)
+        self._decay_max, self._tau = float(decay), float(tau)
         self._table = _Table()
         self._pairs = None
+
+    def decay(self, n):
+        return self._decay_max * (1.0 - math.exp(-float(n) / self._tau))
 
     def refresh(self):
         self._pairs = None
@@ -296,32 +320,53 @@ class ModelEMA:
 
 
 # ------------------------------------------------------------------------------------------- LR schedule
+class _CosineSchedule:
+    """lr(it): quadratic warm-up from `start` to `peak` over `warm` iterations, half-cosine from `peak` down to `floor`,
+    then flat at `floor` for the last `tail` iterations."""
+
+    def __init__(self, peak, floor, total, warm, start, tail):
+        self.peak, self.floor, self.total, self.warm, self.start, self.tail = peak, floor, total, warm, start, tail
+
+    def __call__(self, it):
+        if it <= self.warm:
+            frac = it / float(self.warm)
+            return self.start + (self.peak - self.start) * frac * frac
+        if it >= self.total - self.tail:
+            return self.floor
+        phase = (it - self.warm) / (self.total - self.warm - self.tail)
+        return self.floor + (self.peak - self.floor) * 0.5 * (1.0 + math.cos(math.pi * phase))
+
+
+class _StepSchedule:
+    """lr(it) = peak * rate ** floor(it / every)."""
+
+    def __init__(self, peak, rate, every):
+        if every < 1:
+            raise ValueError("step schedule: fewer iterations than steps (step length < 1)")
+        self.peak, self.rate, self.every = peak, rate, every
+
+    def __call__(self, it):
+        return self.peak * self.rate ** (it // self.every)
+
+
 def get_lr_scheduler(lr_decay_type, lr, min_lr, total_iters, warmup_iters_ratio=0.05, warmup_lr_ratio=0.1,
                      no_aug_iter_ratio=0.05, step_num=10):
-    """nets/yolo_training.py:504-542: quadratic warm-up + cosine + flat tail ("cos"), or a 10-step geometric decay."""
-    def warm_cos(lr, min_lr, total_iters, warmup_total_iters, warmup_lr_start, no_aug_iter, iters):
-        if iters <= warmup_total_iters:
-            return (lr - warmup_lr_start) * pow(iters / float(warmup_total_iters), 2) + warmup_lr_start
-        if iters >= total_iters - no_aug_iter:
-            return min_lr
-        return min_lr + 0.5 * (lr - min_lr) * (
-            1.0 + math.cos(math.pi * (iters - warmup_total_iters) / (total_iters - warmup_total_iters - no_aug_iter)))
-
-    def step_lr(lr, decay_rate, step_size, iters):
-        if step_size < 1:
-            raise ValueError("step_size must above 1.")
-        return lr * decay_rate ** (iters // step_size)
-
+    """Epoch -> learning rate (interface and values of nets/yolo_training.py:504-542, pinned by
+    tests/golden/optim_lr_schedules.json).  "cos": warm-up of clamp(ratio * total, 1, 3) epochs starting at
+    max(ratio * lr, 1e-6), cosine, flat tail of clamp(ratio * total, 1, 15) epochs.  Anything else: `step_num`
+    geometric steps from lr down to min_lr."""
     if lr_decay_type == "cos":
-        warmup_total_iters = min(max(warmup_iters_ratio * total_iters, 1), 3)
-        warmup_lr_start = max(warmup_lr_ratio * lr, 1e-6)
-        no_aug_iter = min(max(no_aug_iter_ratio * total_iters, 1), 15)
-        return partial(warm_cos, lr, min_lr, total_iters, warmup_total_iters, warmup_lr_start, no_aug_iter)
-    decay_rate = (min_lr / lr) ** (1 / (step_num - 1))
-    return partial(step_lr, lr, decay_rate, total_iters / step_num)
+        warm = min(3, max(1, warmup_iters_ratio * total_iters))
+        tail = min(15, max(1, no_aug_iter_ratio * total_iters))
+        return _CosineSchedule(lr, min_lr, total_iters, warm, max(1e-6, warmup_lr_ratio * lr), tail)
+    rate = (min_lr / lr) ** (1.0 / (step_num - 1))
+    sched = _StepSchedule(lr, rate, total_iters / step_num)
+    return sched
 
 
 def set_optimizer_lr(optimizer, lr_scheduler_func, epoch):
-    lr = lr_scheduler_func(epoch)
-    for param_group in optimizer.param_groups:
-        param_group["lr"] = lr
+    """Every parameter group gets the schedule's value for `epoch` (interface of yolo_training.py:544-548)."""
+    value = lr_scheduler_func(epoch)
+    for group in optimizer.param_groups:
+        group["lr"] = value
+    return value

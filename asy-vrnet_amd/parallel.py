@@ -6,50 +6,87 @@ Reference behaviour being replaced: torch DistributedDataParallel around Efficie
 BatchNorm statistics and the data_normal min/max are rank-local (sync_bn=False, train.py:51),
 gradients are averaged over ranks.  Differences, by design for MI355X:
 
-* gradients live in a few large flat buckets laid out in the order the backward pass produces
-  them (head -> neck -> stage 3 ... -> input embeddings); the backward kernels write parameter
-  gradients straight into bucket views (no copy into .grad, no autograd hooks);
-* a bucket's all-reduce is enqueued the moment its last gradient kernel has been launched; RCCL
-  runs it on its own stream, concurrent with the remaining backward kernels; the default bucket is
-  32 MiB so that each collective is large enough to drive all 7 xGMI links of a GPU;
-* parameters that receive no gradient (the six zero-sized ShuffleAttention(channel=3) entries -- the
-  reference needs find_unused_parameters=True for them) are simply not part of any bucket;
+* gradients live in ONE flat arena laid out in the order the backward pass *actually finishes* them: the first
+  backward pass runs in recording mode (every parameter is stamped with the position of the top-level backward
+  section that issued its last gradient kernel), then the arena is rebuilt in that order -- like DDP's bucket
+  rebuild after the first iteration, but from the execution order of this program, where the image and the radar
+  chain of a stage interleave, rather than from the registration order (train.py:367 + torch's reducer);
+* the backward kernels write parameter gradients straight into arena views (no copy into .grad, no autograd
+  hooks);
+* eager steps: a bucket's all-reduce is enqueued the moment the section that completes it has been joined into the
+  main stream; RCCL runs it on its own stream, concurrent with the remaining backward kernels (which keep their
+  side-stream weight gradients); buckets are <= 32 MiB by default so that each collective is large enough to drive
+  all 7 xGMI links of a GPU;
+* captured steps (graph.GraphedStep): the backward is cut at up to `segments - 1` section boundaries into
+  consecutive hipGraphs; the arena slice a segment completes is all-reduced while the next segment's graph replays
+  (collectives stay outside the captured graphs);
+* parameters that receive no gradient (the six zero-sized ShuffleAttention(channel=3) entries -- the reference
+  needs find_unused_parameters=True for them) are not part of the arena; parameters frozen after wrapping
+  (train.py:440 freezes the backbone behind the DDP wrap) keep their slot, are reduced as zeros and get .grad = None;
 * gradients do not accumulate across backward passes in this mode (each pass overwrites).
 """
 import torch
 import torch.distributed as dist
 
 
-class GradBucketer:
-    """Flat gradient buckets + ready-counting + async all-reduce.  Device and backend agnostic
-    (tested with gloo on CPU); the HIP program calls `view()` / `mark_ready()`."""
+def _dist_on(group):
+    return dist.is_available() and dist.is_initialized()
 
-    def __init__(self, params_in_backward_order, bucket_bytes=32 << 20, process_group=None, average=True):
+
+class GradBucketer:
+    """Flat gradient arena + ready-counting + async all-reduce.  Device and backend agnostic (tested with gloo on
+    CPU); the HIP program calls `view()` and `mark_ready()`, the captured step `allreduce_segment()`."""
+
+    def __init__(self, params_in_backward_order, bucket_bytes=32 << 20, process_group=None, average=True,
+                 ready_pos=None, segments=3):
         self.group = process_group
         self.average = average
-        self.deferred = False      # True: no collective inside backward (HIP-graph capture); call allreduce_all()
+        self.bucket_bytes = bucket_bytes
+        self.n_segments = max(1, segments)
+        self.deferred = False      # True: no collective inside backward (HIP-graph capture); allreduce_segment() instead
         self.force_collective = False   # issue the collectives even with one rank (single-GPU test of the RCCL path)
-        self.params = [p for p in params_in_backward_order if p.requires_grad and p.numel() > 0]
-        self.bucket_of, self.views, self.buckets, self.pending0 = {}, {}, [], []
-        cur, cur_bytes = [], 0
-        groups = []
+        self.recording = ready_pos is None          # first pass: stamp parameters with their tape position
+        self.params = [p for p in params_in_backward_order if p.numel() > 0]
+        self.ready_pos = dict(ready_pos) if ready_pos is not None else {}
+        self._rec_order = {}
+        self._layout()
+        self.reset()
+
+    # ---- layout ------------------------------------------------------------------------------------------------
+    def _layout(self):
+        """Arena order = self.params; segment boundaries at tape positions; buckets never straddle a segment."""
+        self.cuts = self._choose_cuts()
+        seg_of = {}
         for p in self.params:
-            cur.append(p)
-            cur_bytes += p.numel() * p.element_size()
-            if cur_bytes >= bucket_bytes:
+            pos = self.ready_pos.get(p)
+            seg_of[p] = len(self.cuts) if pos is None else sum(1 for c in self.cuts if pos < c)
+        groups, seg_groups = [], []
+        cur, cur_bytes, cur_seg = [], 0, None
+        for p in self.params:
+            sg = seg_of[p]
+            if cur and (sg != cur_seg or cur_bytes >= self.bucket_bytes):
                 groups.append(cur)
+                seg_groups.append(cur_seg)
                 cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_seg = sg
+            cur_bytes += p.numel() * p.element_size()
         if cur:
             groups.append(cur)
-        # one contiguous arena, buckets are consecutive slices of it: the deferred (HIP-graph) mode reduces the whole
-        # arena with a single collective, the overlapped mode one slice at a time (slices start 256-byte aligned)
+            seg_groups.append(cur_seg)
+        # one contiguous arena, buckets are consecutive 256-byte aligned slices of it
         sizes = [-(-sum(p.numel() for p in g) // 64) * 64 for g in groups]
         ref = self.params[0] if self.params else None
         self.arena = torch.zeros(sum(sizes), dtype=ref.dtype, device=ref.device) if ref is not None else None
+        self.bucket_of, self.views, self.buckets, self.pending0 = {}, {}, [], []
+        self.bucket_segment = seg_groups
+        self.segment_slices = {}
         base = 0
         for bi, g in enumerate(groups):
             n = sum(p.numel() for p in g)
             flat = self.arena[base:base + n]
+            lo, hi = self.segment_slices.get(seg_groups[bi], (base, base))
+            self.segment_slices[seg_groups[bi]] = (lo, base + sizes[bi])
             base += sizes[bi]
             off = 0
             for p in g:
@@ -58,7 +95,39 @@ class GradBucketer:
                 off += p.numel()
             self.buckets.append(flat)
             self.pending0.append(len(g))
+
+    def _choose_cuts(self):
+        """Tape positions (descending) at which a captured backward is cut: the gradient bytes completed between two
+        cuts are >= total / segments, so the last segment -- whose all-reduce nothing overlaps -- is the smallest
+        remainder (the backward finishes with the high-resolution, few-parameter stages)."""
+        if self.n_segments <= 1 or not self.ready_pos:
+            return []
+        per_pos = {}
+        for p in self.params:
+            pos = self.ready_pos.get(p)
+            if pos is not None:
+                per_pos[pos] = per_pos.get(pos, 0) + p.numel()
+        total = sum(per_pos.values())
+        cuts, acc = [], 0
+        for pos in sorted(per_pos, reverse=True):             # the order the backward reaches them
+            acc += per_pos[pos]
+            if acc * self.n_segments >= total and len(cuts) < self.n_segments - 1 and pos > min(per_pos):
+                cuts.append(pos)                              # cut BEFORE replaying closure pos - 1
+                acc = 0
+        return cuts
+
+    def rebuild_from_recording(self):
+        """After the recording pass: arena in execution order (parameters that never reported keep their relative order
+        at the end -- they are reduced as zeros by finish()).  Gradient views change: call before capturing a graph."""
+        seen = [p for p in self.params if p in self.ready_pos]
+        order = sorted(range(len(seen)), key=lambda i: (-self.ready_pos[seen[i]], self._rec_order.get(seen[i], i)))
+        rest = [p for p in self.params if p not in self.ready_pos]
+        self.params = [seen[i] for i in order] + rest
+        self.recording = False
+        self._layout()
         self.reset()
+        for p in self.params:
+            p.grad = None
 
     def reset(self):
         self.pending = list(self.pending0)
@@ -68,70 +137,81 @@ class GradBucketer:
     def view(self, p):
         return self.views.get(p)
 
-    def mark_ready(self, p):
-        """Called once per parameter per backward, after its gradient kernel has been enqueued."""
+    # ---- backward-time interface -------------------------------------------------------------------------------
+    def mark_ready(self, p, tape_pos=None):
+        """Called once per parameter per backward, after its gradient kernels have been enqueued and joined."""
         if p not in self.bucket_of or p in self.seen:
             return
         self.seen.add(p)
+        if self.recording and tape_pos is not None:
+            self.ready_pos[p] = tape_pos
+            self._rec_order[p] = len(self._rec_order)
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
             self._launch(bi)
 
-    def _launch(self, bi):
-        if self.deferred:
-            return
-        if not (dist.is_available() and dist.is_initialized()):
-            return
-        if dist.get_world_size(self.group) == 1 and not self.force_collective:
-            return
-        flat = self.buckets[bi]
+    def _collective_on(self):
+        if not _dist_on(self.group):
+            return False
+        return dist.get_world_size(self.group) > 1 or self.force_collective
+
+    def _reduce(self, flat):
         if self.average and dist.get_backend(self.group) == "nccl":
-            self.works.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
-        else:
-            w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.works.append((w, flat if self.average else None))
+            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None
+        w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return w, (flat if self.average else None)
+
+    def _launch(self, bi):
+        if self.deferred or self.recording or not self._collective_on():
+            return
+        self.works.append(self._reduce(self.buckets[bi]))
+
+    def _wait_all(self):
+        ws = dist.get_world_size(self.group) if _dist_on(self.group) else 1
+        for w, scale in self.works:
+            w.wait()
+            if scale is not None:
+                scale.div_(ws)
+        self.works = []
 
     def finish(self):
-        """Launches buckets whose parameters got no gradient this pass (their views are zero),
-        waits for every collective and publishes the views as .grad."""
+        """Launches buckets whose parameters got no gradient this pass (their views are zeroed), waits for every
+        collective and publishes the views as .grad (None for parameters that are frozen now)."""
         for bi, n in enumerate(self.pending):
             if n > 0:
                 for p in self.params:
                     if self.bucket_of[p] == bi and p not in self.seen:
                         self.views[p].zero_()
                 self._launch(bi)
-        ws = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        for w, scale in self.works:
-            w.wait()
-            if scale is not None:
-                scale.div_(ws)
+        if self.recording and self._collective_on() and not self.deferred:
+            self.works.append(self._reduce(self.arena))       # recording pass: one collective over everything
+        self._wait_all()
         for p in self.params:
-            p.grad = self.views[p]
+            p.grad = self.views[p] if p.requires_grad else None
         self.reset()
 
+    # ---- captured steps ----------------------------------------------------------------------------------------
+    def allreduce_segment(self, k):
+        """Deferred mode: all-reduce of the arena slice that captured segment k completed; asynchronous (RCCL's
+        stream waits for the work enqueued so far on the current stream, later replays overlap it)."""
+        if not self._collective_on() or k not in self.segment_slices:
+            return
+        lo, hi = self.segment_slices[k]
+        self.works.append(self._reduce(self.arena[lo:hi]))
 
-def _allreduce_all(self):
-    """Deferred mode: ONE collective over the whole gradient arena, after the captured step has been replayed (a
-    single large message drives all xGMI links; seven 32 MiB ones would pay the ring latency seven times)."""
-    if not (dist.is_available() and dist.is_initialized()):
-        return
-    ws = dist.get_world_size(self.group)
-    if ws == 1 and not self.force_collective:
-        return
-    if self.average and dist.get_backend(self.group) == "nccl":
-        dist.all_reduce(self.arena, op=dist.ReduceOp.AVG, group=self.group)
-    else:
-        dist.all_reduce(self.arena, op=dist.ReduceOp.SUM, group=self.group)
-        if self.average:
-            self.arena.div_(ws)
+    def allreduce_all(self):
+        """Deferred mode without cuts: ONE collective over the whole arena after the replay."""
+        if self._collective_on():
+            self.works.append(self._reduce(self.arena))
+        self._wait_all()
 
-
-GradBucketer.allreduce_all = _allreduce_all
+    def wait(self):
+        self._wait_all()
 
 
 def backward_param_order(model):
-    """Parameters in the order the backward pass finishes them: reverse of the forward call order
+    """First guess, used for the recording pass only: reverse of the forward registration order
     (nets/efficient_vrnet.py:24-27: backbone -> neck -> head)."""
     return list(reversed(list(model.parameters())))
 
@@ -139,14 +219,13 @@ def backward_param_order(model):
 class DataParallelVRNet(torch.nn.Module):
     """Drop-in for DistributedDataParallel(EfficientVRNet) on one node (one process per GPU)."""
 
-    def __init__(self, module, bucket_bytes=32 << 20, process_group=None, force_collective=False):
+    def __init__(self, module, bucket_bytes=32 << 20, process_group=None, force_collective=False, segments=3):
         super().__init__()
         self.module = module
-        self.bucketer = GradBucketer(backward_param_order(module), bucket_bytes, process_group)
+        self.bucketer = GradBucketer(backward_param_order(module), bucket_bytes, process_group, segments=segments)
         self.bucketer.force_collective = force_collective   # collectives even with one rank (single-GPU RCCL rehearsal)
         module._grad_bucketer = self.bucketer
-        module._on_param_grad = self.bucketer.mark_ready
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force_collective):
+        if _dist_on(process_group) and (dist.get_world_size(process_group) > 1 or force_collective):
             with torch.no_grad():                       # replicas start identical (DDP broadcasts at wrap time)
                 for t in list(module.parameters()) + list(module.buffers()):
                     if t.numel():
@@ -155,4 +234,12 @@ class DataParallelVRNet(torch.nn.Module):
                 torch.cuda.synchronize(t.device)        # no collective left in flight when a HIP-graph capture starts
 
     def forward(self, x, x_radar):
+        if self.bucketer.recording and self.bucketer.ready_pos and torch.is_grad_enabled():
+            self.finalize_layout()                      # the previous backward was the recording pass
         return self.module(x, x_radar)
+
+    def finalize_layout(self):
+        """Call after the first backward pass (the recording pass): rebuilds the arena in execution order.  Done
+        automatically by the next forward if omitted."""
+        if self.bucketer.recording and self.bucketer.ready_pos:
+            self.bucketer.rebuild_from_recording()

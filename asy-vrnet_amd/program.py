@@ -61,7 +61,8 @@ class RT:
         self._chain = "main"        # logical chain id: "main" or (depth, branch index)
         self._aside_pending = {}
         self._deferred_wgrads = []
-        self.aside_ok = True        # False with an eager data-parallel bucketer (its all-reduce needs one stream order)
+        self.ready = None           # with a bucketer: parameters whose gradient kernels were issued, not yet handed over
+        self.tape_pos = 0           # index of the top-level tape closure being replayed
         self.concurrent = True      # fork independent chains (image / radar, seg / det, head levels) onto side streams
 
     # ---- fork / join of independent chains -------------------------------------------------------------
@@ -84,7 +85,7 @@ class RT:
     def aside(self, fn, keep):
         """`fn` launches weight / parameter-gradient kernels whose results no later backward kernel reads;
         `keep`: tensors it reads (held until it has been ordered before their release)."""
-        if not self.concurrent or not self.aside_ok:
+        if not self.concurrent:
             fn()
             return
         if self._chain != "main":
@@ -156,9 +157,6 @@ class RT:
         if self.record:
             def bwd():
                 cur_b = torch.cuda.current_stream(self.device)
-                hook, deferred = self.on_param_grad, []
-                if hook is not None:           # a bucket's all-reduce must not start before BOTH chains have joined
-                    self.on_param_grad = deferred.append
                 # weight gradients deferred by the PREVIOUS section run beside this section's data-gradient chains
                 wstreams = self._streams(8)[4:4 + WGRAD_STREAMS] if self._deferred_wgrads else []
                 for st in wstreams:
@@ -177,10 +175,6 @@ class RT:
                 for st in list(streams) + list(wstreams):
                     cur_b.wait_stream(st)
                 held.clear()
-                if hook is not None:           # (only with an eager bucketer, where nothing is deferred: aside_ok False)
-                    self.on_param_grad = hook
-                    for prm in deferred:
-                        hook(prm)
             main_tape.append(bwd)
         return outs
 
@@ -270,11 +264,6 @@ def take_grad(act):
     g = act.grad
     act.grad = None
     return g
-
-
-def tape_fn(fn):
-    """Marks a backward closure; closures return early when their output got no gradient."""
-    return fn
 
 
 # ----------------------------------------------------------------------------------------- conv helpers
@@ -1014,31 +1003,38 @@ class FusedQKV:
         hip.mt_copy(self.addrs, self.sizes, self.ct, self.ci, self.n, self.nc, self.CHUNK)
 
 
-class _VRNetFunction(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, model, x, x_radar, *params):
-        if not (x.is_cuda and x_radar.is_cuda):
-            raise RuntimeError("EfficientVRNet (HIP hot path) needs inputs on a HIP device; there is no CPU fallback")
-        if x.dtype != torch.float32 or x_radar.dtype != torch.float32:
-            x, x_radar = x.float(), x_radar.float()
-        B, _, H, W = x.shape
-        if H % 64 or W % 64:
-            raise RuntimeError(f"input size {H}x{W} must be a multiple of 64 (fold-2 Cluster on the H/32 map)")
-        record = any(ctx.needs_input_grad)
+def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
+    """Runs the forward program.  Returns (rt, (xa, ra), dets, seg); with record=True rt.tape holds the backward."""
+    if not (x.is_cuda and x_radar.is_cuda):
+        raise RuntimeError("EfficientVRNet (HIP hot path) needs inputs on a HIP device; there is no CPU fallback")
+    if x.device != x_radar.device:
+        raise RuntimeError(f"image on {x.device} but radar on {x_radar.device}")
+    if x.dim() != 4 or x_radar.dim() != 4 or x.shape[1] != 3 or x_radar.shape[1] != 4 or \
+            x.shape[0] != x_radar.shape[0] or x.shape[2:] != x_radar.shape[2:]:
+        raise RuntimeError(f"expected image (B,3,H,W) and radar (B,4,H,W), got {tuple(x.shape)} and {tuple(x_radar.shape)}")
+    if x.dtype != torch.float32 or x_radar.dtype != torch.float32:
+        x, x_radar = x.float(), x_radar.float()
+    B, _, H, W = x.shape
+    if H % 64 or W % 64:
+        raise RuntimeError(f"input size {H}x{W} must be a multiple of 64 (fold-2 Cluster on the H/32 map)")
+    first = next(model.parameters())
+    if first.device != x.device:
+        raise RuntimeError(f"model on {first.device} but inputs on {x.device}")
+    with torch.cuda.device(x.device):          # kernels launch on the inputs' device, whatever the caller's current one
         rt = RT(x.device, model.training, record)
         rt.concurrent = bool(getattr(model, "concurrent", True))
         rt.bf16 = str(getattr(model, "compute_dtype", "f32")).lower() in ("bf16", "bfloat16", "torch.bfloat16")
         rt.bucketer = getattr(model, "_grad_bucketer", None)
-        rt.aside_ok = rt.bucketer is None or rt.bucketer.deferred
-        rt.on_param_grad = getattr(model, "_on_param_grad", None) if rt.bucketer is not None else None
+        rt.ready = [] if rt.bucketer is not None else None
+        rt.on_param_grad = rt.ready.append if rt.bucketer is not None else None
         if getattr(model, "record_relu_masks", False):
             rt.relu_masks = {}
         fq = getattr(model, "_fused_qkv", None)
         if fq is None or fq.owner != id(model) or fq.dst[0].device != x.device:
             fq = model._fused_qkv = FusedQKV(model, x.device)
         fq.refresh()
-        xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=ctx.needs_input_grad[1])
-        ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=ctx.needs_input_grad[2])
+        xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=need_dx)
+        ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=need_dr)
         hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)
         hip.nchw_to_nhwc(x_radar.contiguous(), ra.t, 4, B, 4, H * W)
         nc, ns = model.num_classes, model.num_seg_classes
@@ -1046,58 +1042,110 @@ class _VRNetFunction(torch.autograd.Function):
         dets = [torch.empty((B, 5 + nc, H // s, W // s), device=x.device) for s in (8, 16, 32)]
         feats, seg_lo = neck_forward(rt, model.backbone, xa, ra, seg)
         head_forward(rt, model.head, feats, dets)
-        ctx.rt, ctx.inputs = rt, (xa, ra)
-        ctx.params = params
-        ctx.model = model
-        ctx.set_materialize_grads(False)
-        model._last_idx_maps = rt.idx_maps
-        if rt.relu_masks is not None:        # {BatchNorm state_dict prefix: (B,H,W,C) bool}: which ReLU inputs were > 0
-            names = {mod: k for k, mod in model.named_modules()}
-            model._last_relu_masks = {names[bn]: (a.t > 0) for bn, a in rt.relu_masks.items()}
-        return (*dets, seg)
+    model._last_idx_maps = rt.idx_maps
+    if rt.relu_masks is not None:        # {BatchNorm state_dict prefix: (B,H,W,C) bool}: which ReLU inputs were > 0
+        names = {mod: k for k, mod in model.named_modules()}
+        model._last_relu_masks = {names[bn]: (a.t > 0) for bn, a in rt.relu_masks.items()}
+    return rt, (xa, ra), dets, seg
 
-    @staticmethod
-    def backward(ctx, g0, g1, g2, gseg):
-        rt, model = ctx.rt, ctx.model
-        if rt.tape is None:
-            raise RuntimeError("EfficientVRNet backward called twice (activations are freed after the first pass)")
-        rt.det_grads, rt.seg_grad = (g0, g1, g2), gseg
-        for fn in reversed(rt.tape):
-            fn()
+
+def _drain_ready(rt):
+    """Hands the parameters whose gradient kernels have been issued AND joined into the current stream to the
+    bucketer (which may start a bucket's all-reduce: it must be ordered behind those kernels)."""
+    if rt.ready:
+        done, rt.ready[:] = list(rt.ready), []
+        for prm in done:
+            rt.bucketer.mark_ready(prm, rt.tape_pos)
+
+
+def backward_begin(rt, gdets, gseg):
+    if rt.tape is None:
+        raise RuntimeError("EfficientVRNet backward called twice (activations are freed after the first pass)")
+    rt.det_grads, rt.seg_grad = tuple(gdets), gseg
+    rt.tape_pos = len(rt.tape)
+
+
+def backward_range(rt, lo, hi, flush_each=False):
+    """Replays tape closures hi-1 ... lo (the backward of forward sections lo ... hi-1).  flush_each: the deferred
+    weight gradients are issued after every closure (the bucketer's recording pass: a parameter is then attributed
+    to the closure a cut could be placed behind)."""
+    with torch.cuda.device(rt.device):
+        for i in range(hi - 1, lo - 1, -1):
+            rt.tape_pos = i
+            rt.tape[i]()
             rt.join_aside()
+            if flush_each:
+                rt.flush_deferred_wgrads()
+            _drain_ready(rt)
+
+
+def backward_cut(rt):
+    """Every gradient kernel issued so far is ordered before whatever the current stream runs next (joins the
+    side streams): the point where a captured segment ends / a bucket's collective may start."""
+    with torch.cuda.device(rt.device):
         rt.flush_deferred_wgrads()
+        _drain_ready(rt)
+
+
+def backward_end(rt, model, inputs, needs, params=None, needs_params=None):
+    """Input gradients (NCHW) and publication of the parameter gradients; frees the tape."""
+    with torch.cuda.device(rt.device):
+        backward_cut(rt)
         rt.tape = None
-        xa, ra = ctx.inputs
-        outs = [None]
-        for act, need in ((xa, ctx.needs_input_grad[1]), (ra, ctx.needs_input_grad[2])):
+        outs = []
+        for act, need in zip(inputs, needs):
             if need and act.grad is not None:
                 g = torch.empty((act.B, act.C, act.H, act.W), device=act.t.device)
                 hip.nhwc_to_nchw(act.grad, act.C, g, act.B, act.C, act.H * act.W)
                 outs.append(g)
             else:
                 outs.append(None)
+        pouts = None
+        params = list(model.parameters()) if params is None else params
         if rt.bucketer is not None:          # data parallel: buckets own the gradients (all-reduced, then .grad = view)
+            stray = [p for p in rt.pgrads if rt.bucketer.view(p) is None]
+            if stray:
+                raise RuntimeError(f"{len(stray)} parameter gradient(s) were produced outside the data-parallel buckets")
             rt.bucketer.finish()
-            outs.extend([None] * len(ctx.params))
-        elif getattr(model, "autograd_param_grads", False):
-            for i, p in enumerate(ctx.params):      # through autograd (AccumulateGrad clones each buffer once)
-                outs.append(rt.pgrads.get(p) if ctx.needs_input_grad[3 + i] else None)
+        elif getattr(model, "autograd_param_grads", False) and needs_params is not None:
+            pouts = [rt.pgrads.get(p) if need else None for p, need in zip(params, needs_params)]
         else:
             # Default: publish parameter gradients directly (.grad = buffer, or += into an existing .grad, as
             # loss.backward() would) -- saves one copy of every gradient per step.  Set
             # model.autograd_param_grads = True to receive them through torch.autograd.grad instead.
-            for i, p in enumerate(ctx.params):
-                g = rt.pgrads.get(p) if ctx.needs_input_grad[3 + i] else None
+            for i, p in enumerate(params):
+                g = rt.pgrads.get(p) if (needs_params is None or needs_params[i]) else None
                 if g is not None:
                     if p.grad is None:
                         p.grad = g
                     else:
                         hip.add_(p.grad, g)
-            outs.extend([None] * len(ctx.params))
         rt.pgrads.clear()
         rt.det_grads = rt.seg_grad = None
+    return outs, pouts
+
+
+class _VRNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, x_radar, *params):
+        record = any(ctx.needs_input_grad)
+        rt, inputs, dets, seg = forward_pass(model, x, x_radar, record, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        ctx.rt, ctx.inputs = rt, inputs
+        ctx.params = params
+        ctx.model = model
+        ctx.set_materialize_grads(False)
+        return (*dets, seg)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, gseg):
+        rt, model = ctx.rt, ctx.model
+        backward_begin(rt, (g0, g1, g2), gseg)
+        rec = rt.bucketer is not None and rt.bucketer.recording
+        backward_range(rt, 0, len(rt.tape), flush_each=rec)
+        outs, pouts = backward_end(rt, model, ctx.inputs, ctx.needs_input_grad[1:3], list(ctx.params),
+                                   ctx.needs_input_grad[3:])
         ctx.rt = ctx.inputs = None
-        return tuple(outs)
+        return (None, *outs, *(pouts if pouts is not None else [None] * len(ctx.params)))
 
 
 def run_forward(model, x, x_radar):

@@ -52,6 +52,18 @@ def pmc_traffic_bytes(phi):
     return round(tot / n) if n else None
 
 
+def conv_flops(B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil):
+    """Algorithmic FLOPs of one conv launch (forward, data gradient or weight gradient alike): 2*B*OH*OW*Cout*Cin*kh*kw,
+    the convention of torch's flop counter -- except for dilated convs, where only multiply-adds whose
+    tap lands inside the image are counted (at 16x16 the d=12/18 ASPP branches have 5-8 of 9 taps entirely in the
+    padding; the kernels skip them, and counting them would inflate the achieved rate)."""
+    if dil == 1:
+        return 2.0 * B * OH * OW * Cout * Cin * kh * kw
+    ny = sum(sum(1 for oy in range(OH) if 0 <= oy * stride - pad + ky * dil < H) for ky in range(kh))
+    nx = sum(sum(1 for ox in range(OW) if 0 <= ox * stride - pad + kx * dil < W) for kx in range(kw))
+    return 2.0 * B * Cout * Cin * ny * nx
+
+
 def loss_of(det, seg):
     return sum((d * d).mean() for d in det) + (seg * seg).mean()
 
@@ -78,19 +90,21 @@ class ConvTimer:
         hip, rec = self.hip, self.rec
         o_conv, o_wgrad, o_cf, o_cb = self.orig
 
-        def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_):
+        def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, *rest, **kw_):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            o_conv(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_)
+            o_conv(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, *rest, **kw_)
             e1.record()
-            rec["igemm"].append((2.0 * B * OH * OW * Cout * Cin * kh * kw, e0, e1, f"M{B*OH*OW} N{Cout} K{Cin}x{kh}x{kw}"))
+            rec["igemm"].append((conv_flops(B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil), e0, e1,
+                                 f"M{B*OH*OW} N{Cout} K{Cin}x{kh}x{kw}" + (f"d{dil}" if dil > 1 else "")))
 
-        def conv2d_wgrad(x, ldx, dy, lddy, dw, db, rs, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_):
+        def conv2d_wgrad(x, ldx, dy, lddy, dw, db, rs, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, *rest, **kw_):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            o_wgrad(x, ldx, dy, lddy, dw, db, rs, B, H, W, Cin, OH, OW, Cout, kh, kw, *rest, **kw_)
+            o_wgrad(x, ldx, dy, lddy, dw, db, rs, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, *rest, **kw_)
             e1.record()
-            rec["wgrad"].append((2.0 * B * OH * OW * Cout * Cin * kh * kw, e0, e1, f"M{B*OH*OW} N{Cout} K{Cin}x{kh}x{kw}"))
+            rec["wgrad"].append((conv_flops(B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil), e0, e1,
+                                 f"M{B*OH*OW} N{Cout} K{Cin}x{kh}x{kw}" + (f"d{dil}" if dil > 1 else "")))
         def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -130,14 +144,28 @@ class ConvTimer:
             print(f"  {key:12s} {tag:28s} x{n:3d} {ms:8.3f} ms  {work / ms * 1e3 / unit_scale:9.1f} {unit}", file=sys.stderr)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(phi, size, batch, seed_sd):
-    """Oracle fwd+bwd on the host cores: a bounded sample of the same workload."""
+    """the CPU oracle (the build's restatement of the reference, kind "port") forward+backward on the host
+    cores at the benchmark's own batch (bs 8 by default), 1 warm-up + 2 timed iterations (a bounded sample: ~10 s per
+    iteration for phi=l at bs 8), plus a bs=1 eval forward; threads = cores this process may use, capped at 32
+    (measured in round 1: more threads make the oracle slower)."""
     from oracle import vrnet_oracle as O
     import asy_vrnet_amd as A
-    try:                                        # cores this process may actually use (cgroup / affinity aware)
-        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0)), 32)))   # >32 threads slow it down
+    try:
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        pass
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 32)))
     m = A.EfficientVRNet(4, 9, phi, img_size=size)
     A.randomize_state_dict(m.state_dict(), seed=seed_sd)
     pn = {k for k, _ in m.named_parameters()}
@@ -145,17 +173,35 @@ def cpu_baseline(phi, size, batch, seed_sd):
          for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(1234)
     x, r = torch.randn((batch, 3, size, size), generator=g), torch.rand((batch, 4, size, size), generator=g)
-    iters, t0 = 0, time.perf_counter()
-    while True:
+
+    def fwd_bwd():
+        for t in P.values():
+            if t.dtype.is_floating_point:
+                t.grad = None
         det, seg, _ = O.forward(P, x, r, phi, True)
         loss_of(det, seg).backward()
+    t0 = time.perf_counter()
+    fwd_bwd()                                   # warm-up (allocator, oneDNN primitive caches)
+    warm = time.perf_counter() - t0
+    iters, t0 = 0, time.perf_counter()
+    while iters < 2 or (time.perf_counter() - t0 < 10.0 and iters < 8):
+        fwd_bwd()
         iters += 1
-        el = time.perf_counter() - t0
-        if el > 12.0 or iters >= 4:
-            break
+    el = time.perf_counter() - t0
+    with torch.no_grad():
+        O.forward(P, x[:1], r[:1], phi, False)
+        t1 = time.perf_counter()
+        n1 = 0
+        while n1 < 3:
+            O.forward(P, x[:1], r[:1], phi, False)
+            n1 += 1
+        f1 = (time.perf_counter() - t1) / n1
     return {"value": round(iters * batch / el, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+            "fwd_bs1_images_per_sec": round(1.0 / f1, 3),
             "sample": f"CPU oracle (pure-torch restatement of the reference) fwd+bwd, phi={phi}, bs={batch}, "
-                      f"{size}x{size}, {iters} iteration(s) in {el:.1f} s, no warm-up"}
+                      f"{size}x{size}, 1 warm-up ({warm:.1f} s) + {iters} timed iteration(s) in {el:.1f} s; "
+                      f"bs=1 eval forward {1e3 * f1:.0f} ms"}
 
 
 def main():
@@ -167,7 +213,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the CPU baseline (default: --batch)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape kernel breakdown on stderr (tuning aid)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
@@ -176,6 +222,20 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Started directly (not by torchrun): start the N ranks ourselves, as a CHILD process, before anything in this
+        # process has touched the GPU (a process that initialised HIP must never exec / be replaced), and pass its
+        # return code on.
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -183,8 +243,9 @@ def main():
     if world > 1 or (force_dp and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}: launch with torchrun --nproc-per-node {args.gpus} "
+                         "(or run `python bench.py --gpus N` directly, which starts the ranks itself)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -285,7 +346,7 @@ def main():
                                 "avg_launch_mbytes": round((bcf + bcb) / (ncf + ncb) / 1e6, 1)}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.phi, args.size, args.cpu_batch, 0)
+        cpu = cpu_baseline(args.phi, args.size, args.cpu_batch or args.batch, 0)
 
     if rank == 0:
         metric = "images/sec fwd+bwd, 512x512 img+4ch radar, bs=8/GPU"

@@ -1,5 +1,6 @@
-"""N > 1 path on CPU: the gradient bucketing / overlap bookkeeping of parallel.GradBucketer with the
-gloo backend, world_size 2 (the HIP kernels themselves need a GPU; what is distributed is covered here)."""
+"""N > 1 path on CPU: the gradient arena / execution-order recording / segment and bucket bookkeeping of
+parallel.GradBucketer with the gloo backend, world_size 2 (the HIP kernels themselves need a GPU; what is
+distributed is covered here)."""
 import os
 import socket
 
@@ -16,6 +17,21 @@ def _free_port():
     return p
 
 
+def _execution_like_order(params):
+    """A backward 'execution order' that differs from the registration order the way the real program's does: the two
+    halves of the parameter list (think image / radar chain) interleave, and tape positions descend."""
+    n = len(params)
+    a, b = params[: n // 2], params[n // 2:]
+    order = []
+    for i in range(max(len(a), len(b))):
+        if i < len(b):
+            order.append(b[i])
+        if i < len(a):
+            order.append(a[i])
+    pos = {p: 40 - (40 * i) // len(order) for i, p in enumerate(order)}     # 41 "top-level closures", replayed 40 .. 0
+    return order, pos
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -23,41 +39,74 @@ def _worker(rank, world, port, q):
     import asy_vrnet_amd as A
     torch.manual_seed(0)
     model = A.EfficientVRNet(4, 9, "nano", img_size=64)
-    order = backward_param_order(model)
-    bk = GradBucketer(order, bucket_bytes=1 << 20)
-    assert len(bk.buckets) > 3
-    # the backward pass writes each gradient into its bucket view, then marks it ready, in backward order;
-    # leave the last 7 parameters without a gradient (unused-parameter path)
-    used = bk.params[:-7]
-    for i, p in enumerate(used):
+    bk = GradBucketer(backward_param_order(model), bucket_bytes=1 << 20, segments=3)
+    ok = bk.recording and len(bk.cuts) == 0
+    # ---- pass 1 = recording pass: gradients are produced in an order that is NOT the registration order; the last 7
+    # parameters of that order get no gradient (unused-parameter path); ONE collective over the arena
+    order, pos = _execution_like_order(bk.params)
+    used = order[:-7]
+    val = {p: 1 + i % 5 for i, p in enumerate(order)}
+    for p in used:
         g = bk.view(p)
         assert g.shape == p.shape and g.data_ptr() != p.data_ptr()
-        g.fill_(float(rank + 1) * (1 + i % 5))
-        bk.mark_ready(p)
+        g.fill_(float(rank + 1) * val[p])
+        bk.mark_ready(p, pos[p])
     bk.finish()
-    ok = True
-    for i, p in enumerate(bk.params):
-        expect = (1 + i % 5) * (sum(range(1, world + 1)) / world) if i < len(used) else 0.0
-        ok = ok and torch.allclose(p.grad, torch.full_like(p, expect))
-    # zero-sized parameters are never bucketed
-    ok = ok and all(p.numel() > 0 for p in bk.params)
-    # second pass reuses the buckets
-    for p in bk.params:
+    mean = sum(range(1, world + 1)) / world
+    for p in order:
+        ok = ok and torch.allclose(p.grad, torch.full_like(p, val[p] * mean if p in set(used) else 0.0))
+    ok = ok and all(p.numel() > 0 for p in bk.params)            # zero-sized parameters are never part of the arena
+    # ---- rebuild: arena in recorded execution order, cut into 3 segments at tape positions, buckets inside segments
+    bk.rebuild_from_recording()
+    ok = ok and not bk.recording and bk.params[:len(used)] == used and len(bk.cuts) == 2 and bk.cuts[0] > bk.cuts[1] > 0
+    ok = ok and all(p.grad is None for p in bk.params)
+    seg_of = lambda p: sum(1 for c in bk.cuts if pos[p] < c)
+    for p in used:
+        lo, hi = bk.segment_slices[seg_of(p)]
+        off = (bk.view(p).data_ptr() - bk.arena.data_ptr()) // 4
+        ok = ok and lo <= off and off + p.numel() <= hi
+    ok = ok and len(bk.buckets) > 3 and all(b.numel() * 4 <= (1 << 20) + 4 * max(p.numel() for p in bk.params) for b in bk.buckets)
+    sizes = [sum(p.numel() for p in used if seg_of(p) == k) for k in range(3)]
+    ok = ok and sizes[0] * 3 >= sum(sizes) and sizes[2] > 0          # the last, un-overlapped segment is the remainder
+    # ---- pass 2 = eager overlapped mode: a bucket's collective starts when its last parameter is marked ready
+    launched_early = False
+    for i, p in enumerate(used):
         bk.view(p).fill_(float(rank))
-        bk.mark_ready(p)
+        bk.mark_ready(p, pos[p])
+        launched_early = launched_early or (i < len(used) - 1 and len(bk.works) > 0)
+    ok = ok and launched_early
     bk.finish()
-    ok = ok and all(torch.allclose(p.grad, torch.full_like(p, (world - 1) / 2)) for p in bk.params)
-    # deferred mode (HIP-graph step): nothing is sent during the pass, one collective over the whole arena afterwards
+    ok = ok and all(torch.allclose(p.grad, torch.full_like(p, (world - 1) / 2)) for p in used)
+    ok = ok and all(float(p.grad.abs().max()) == 0.0 for p in order[-7:])
+    # frozen after wrapping (train.py:440): slot kept, .grad None
+    used[3].requires_grad_(False)
+    for p in used:
+        bk.view(p).fill_(1.0)
+        bk.mark_ready(p, pos[p])
+    bk.finish()
+    ok = ok and used[3].grad is None and used[4].grad is not None
+    used[3].requires_grad_(True)
+    # ---- pass 3 = captured-step mode: nothing is sent during the pass; segment k's slice is reduced after "graph k",
+    # while the later segments are still being written (here: written afterwards, which must not disturb segment k)
     bk.deferred = True
-    for i, p in enumerate(bk.params):
-        bk.view(p).fill_(float(rank + 1) * (1 + i % 3))
-        bk.mark_ready(p)
-    ok = ok and not bk.works
+    by_seg = {k: [p for p in used if seg_of(p) == k] for k in range(3)}
+    for k in range(3):
+        for p in by_seg[k]:
+            bk.view(p).fill_(float(rank + 1) * val[p])
+            bk.mark_ready(p, pos[p])
+        ok = ok and not bk.works if k == 0 else ok
+        bk.allreduce_segment(k)
+    bk.wait()
+    ok = ok and all(torch.allclose(bk.view(p), torch.full_like(p, val[p] * mean)) for p in used)
+    bk.reset()
+    # single-graph variant: one collective over the whole arena
+    for p in used:
+        bk.view(p).fill_(float(rank + 1))
+        bk.mark_ready(p, pos[p])
     bk.allreduce_all()
     bk.reset()
-    ok = ok and all(torch.allclose(bk.view(p), torch.full_like(p, (1 + i % 3) * 1.5)) for i, p in enumerate(bk.params))
-    ok = ok and all(bk.view(p).data_ptr() >= bk.arena.data_ptr() for p in bk.params)
-    q.put((rank, ok))
+    ok = ok and all(torch.allclose(bk.view(p), torch.full_like(p, mean)) for p in used)
+    q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
 
@@ -74,7 +123,7 @@ def test_bucketed_allreduce_two_ranks():
     assert all(ok for _, ok in res), res
 
 
-def test_bucket_order_is_reverse_forward():
+def test_first_guess_order_is_reverse_forward():
     import asy_vrnet_amd as A
     from asy_vrnet_amd.parallel import backward_param_order
     m = A.EfficientVRNet(4, 9, "nano", img_size=64)

@@ -62,10 +62,15 @@ def test_512_bs2_against_oracle(A):
     assert rep["ok"], rep
 
 
-@pytest.mark.parametrize("name", ["net_nano_64_train", "net_nano_64_eval", "net_nano_128_train", "net_tiny_128_eval"])
+@pytest.mark.parametrize("name", ["net_nano_64_train", "net_nano_64_eval", "net_nano_128_train", "net_tiny_128_eval",
+                                  "net_nano_512_train"])
 def test_against_reference_golden(A, name, golden_dir):
-    """Direct comparison with the reference's own outputs.  These small cases have no numerical
-    near-ties between the reference and this implementation (checked: zero flips), so plain 1e-3 holds."""
+    """Direct comparison with the reference's own outputs.  These cases have no numerical near-ties between the
+    reference and this implementation (checked: zero flips), so plain 1e-3 holds on the outputs -- also at the
+    benchmark resolution (net_nano_512_train, the reference in fp32: measured 2e-6; the reference in fp64 assigns
+    0.07 % of the points differently than ANY fp32 evaluation, which is why that fixture pins the oracle, not this).
+    Gradients at 512 px: the reference's own fp32 backward is 1-25 % off the exact gradient on single parameters
+    (tests/test_oracle_golden.py), so the per-parameter bar there is 3e-2 (measured worst 9e-3)."""
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = json.load(open(os.path.join(golden_dir, name + ".json")))
     m = build(A, meta["phi"], meta["size"], meta["pseed"], meta["training"])
@@ -74,9 +79,11 @@ def test_against_reference_golden(A, name, golden_dir):
     xg, rg = x.cuda().requires_grad_(grads), r.cuda().requires_grad_(grads)
     det, seg = m(xg, rg)
     from tests.parity import rel_err
+    st = meta.get("seg_stride", 1)
+    gtol = 5e-3 if meta["size"] <= 128 else 3e-2
     for i in range(3):
         assert rel_err(det[i], torch.from_numpy(z[f"det{i}"])) < 1e-3
-    assert rel_err(seg, torch.from_numpy(z["seg"])) < 1e-3
+    assert rel_err(seg[:, :, ::st, ::st], torch.from_numpy(z["seg"])) < 1e-3
     if meta["training"]:
         sd = m.state_dict()
         for k in z.files:
@@ -84,8 +91,8 @@ def test_against_reference_golden(A, name, golden_dir):
                 assert rel_err(sd[k[2:]], torch.from_numpy(z[k])) < 1e-3, k
     if grads:
         sum((d * d).mean() for d in det).add((seg * seg).mean()).backward()
-        assert rel_err(xg.grad, torch.from_numpy(z["dx"])) < 5e-3
-        assert rel_err(rg.grad, torch.from_numpy(z["dr"])) < 5e-3
+        assert rel_err(xg.grad[:, :, ::st, ::st], torch.from_numpy(z["dx"])) < 5e-3
+        assert rel_err(rg.grad[:, :, ::st, ::st], torch.from_numpy(z["dr"])) < 5e-3
         pd = dict(m.named_parameters())
         for k in z.files:
             if k.startswith("g:"):
@@ -93,7 +100,7 @@ def test_against_reference_golden(A, name, golden_dir):
                 if ref.abs().max() < 1e-6:
                     assert pd[k[2:]].grad.abs().max() < 1e-4, k
                 else:
-                    assert rel_err(pd[k[2:]].grad, ref) < 5e-3, k
+                    assert rel_err(pd[k[2:]].grad, ref) < gtol, k
 
 
 def test_module_surface_behaviour(A):
@@ -129,22 +136,35 @@ def test_data_parallel_wrapper_single_rank(A):
     loss_of(*ref(x, r)).backward()
     sd_after = {k: v.clone() for k, v in ref.state_dict().items()}
     m = build(A, "nano", 64, 7, True)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     dp = DataParallelVRNet(m, bucket_bytes=1 << 20)
-    assert len(dp.bucketer.buckets) > 3
-    loss_of(*dp(x, r)).backward()
-    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
-        if p.numel():
-            assert p.grad is not None and torch.equal(p.grad, q.grad), k
-            assert p.grad.data_ptr() == dp.bucketer.view(p).data_ptr()
-    for k, v in m.state_dict().items():
-        assert torch.equal(v, sd_after[k]), k
+    assert len(dp.bucketer.buckets) > 3 and dp.bucketer.recording
+    for step in range(2):       # pass 0 records the execution order, pass 1 runs on the rebuilt arena (3 segments)
+        m.load_state_dict(sd0)
+        loss_of(*dp(x, r)).backward()
+        for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            if p.numel():
+                assert p.grad is not None and torch.equal(p.grad, q.grad), (step, k)
+                assert p.grad.data_ptr() == dp.bucketer.view(p).data_ptr()
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, sd_after[k]), k
+    bk = dp.bucketer
+    assert not bk.recording and len(bk.cuts) == 2 and len(bk.segment_slices) == 3
+    names = {p: k for k, p in m.named_parameters()}
+    assert names[bk.params[0]].startswith("head.") and "network" in names[bk.params[len(bk.params) // 2]]
+    # the two chains of a stage interleave in the arena (execution order), unlike the registration order
+    st2 = [names[p] for p in bk.params if ".network.6." in names[p] or ".network_radar.6." in names[p]]
+    flips = sum(1 for a, b in zip(st2, st2[1:]) if ("radar" in a) != ("radar" in b))
+    assert flips >= 2, st2[:8]
     # captured step on a fresh replica
     m2 = build(A, "nano", 64, 7, True)
     dp2 = DataParallelVRNet(m2, bucket_bytes=1 << 20)
-    gs = GraphedStep(dp2, loss_of, 2, 64, x.device, warmup=1)
+    gs = GraphedStep(dp2, loss_of, 2, 64, x.device, warmup=2)
+    assert len(gs.graphs) == 3                                          # backward cut into 3 captured segments
     m2.load_state_dict(build(A, "nano", 64, 7, True).state_dict())      # undo the warm-up's BN statistics
-    gs(x, r)
+    loss = gs(x, r)
     torch.cuda.synchronize()
+    assert torch.equal(loss, loss_of(*ref(x, r)).detach())
     for (k, p), (_, q) in zip(m2.named_parameters(), ref.named_parameters()):
         if p.numel():
             assert torch.equal(p.grad, q.grad), k
