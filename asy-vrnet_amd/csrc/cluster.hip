@@ -14,6 +14,7 @@ namespace {
 struct ClusterArgs {
   const float* f; const float* v; long ld;
   const float* alpha; const float* beta;
+  const float* alpha2; const float* beta2;   // two-stream launch: samples >= B/2 use the second Cluster's similarity scale / shift
   float* out; long ldo;
   unsigned char* idx; float* wgt;
   // backward
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
   const bool dim_ok = 4 * sub < D;
   const int hh = (h + 1) / 2, hl = h / 2, wh = (w + 1) / 2, wl = w / 2;
   const float invq = 1.f / (float)(hh * wh);
-  const float alpha = p.alpha[0], beta = p.beta[0];
+  const bool second = p.alpha2 != nullptr && 2 * b >= p.B;
+  const float alpha = second ? p.alpha2[0] : p.alpha[0], beta = second ? p.beta2[0] : p.beta[0];
 
   float f[NPT][4], v[NPT][4];
   long row[NPT];
@@ -432,7 +434,8 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
   const bool dim_ok = 4 * sub < D;
   const int hh = (h + 1) / 2, hl = h / 2, wh = (w + 1) / 2, wl = w / 2;
   const float invq = 1.f / (float)(hh * wh);
-  const float alpha = p.alpha[0], beta = p.beta[0];
+  const bool second = p.alpha2 != nullptr && 2 * b >= p.B;
+  const float alpha = second ? p.alpha2[0] : p.alpha[0], beta = second ? p.beta2[0] : p.beta[0];
   const int coff = e * D + 4 * sub;
 
   auto locate = [&](int n, long& row, unsigned& inq) -> bool {
@@ -668,8 +671,12 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
 }
 
 __global__ __launch_bounds__(256) void cluster_ab_reduce_kernel(const float* partial, long blocks, float* dalpha,
-                                                                float* dbeta, int accumulate) {
+                                                                float* dbeta, int accumulate, float* dalpha2, float* dbeta2) {
   __shared__ double red[8];
+  if (blockIdx.x) {        // second stream: the second half of the workgroups (region ids are sample-major)
+    partial += 2 * blocks;
+    dalpha = dalpha2; dbeta = dbeta2;
+  }
   double a = 0, b = 0;
   for (long i = threadIdx.x; i < blocks; i += 256) {
     a += partial[2 * i];
@@ -751,13 +758,15 @@ int cluster_check(const char* name, const void* f, const void* v, long ld, int B
 
 extern "C" int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                                      float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E,
-                                     int D, int fold, void* stream) {
+                                     int D, int fold, const float* alpha2, const float* beta2, void* stream) {
   int T, npt;
   int rc = cluster_check("cluster_fwd", f, v, ld, B, H, W, E, D, fold, &T, &npt);
   if (rc) return rc;
   VR_CHECK_ARG(out && idx && alpha && beta && ldo % 4 == 0 && vr_aligned16(out), "cluster_fwd: bad output");
   VR_CHECK_ARG(T != 0 || wgt, "cluster_fwd: regions of more than 256 points need the similarity map `wgt` (B,H,W,E)");
+  VR_CHECK_ARG((!alpha2 == !beta2) && (!alpha2 || B % 2 == 0), "cluster_fwd: a two-stream launch needs alpha2, beta2 and an even batch");
   ClusterArgs p{};
+  p.alpha2 = alpha2; p.beta2 = beta2;
   p.f = f; p.v = v; p.ld = ld; p.alpha = alpha; p.beta = beta; p.out = out; p.ldo = ldo; p.idx = idx; p.wgt = wgt;
   p.B = B; p.H = H; p.W = W; p.E = E; p.D = D; p.fold = fold;
   cluster_launch<false>(p, T, npt, (long)B * E * fold * fold, vr_stream(stream));
@@ -774,7 +783,8 @@ extern "C" long vrnet_cluster_bwd_workspace(int B, int E, int fold) { return (lo
 extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                                      const unsigned char* idx, const float* dout, long lddo, float* df, float* dv,
                                      long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
-                                     int E, int D, int fold, void* workspace, long workspace_bytes, void* stream) {
+                                     int E, int D, int fold, const float* alpha2, const float* beta2, float* dalpha2,
+                                     float* dbeta2, void* workspace, long workspace_bytes, void* stream) {
   int T, npt;
   int rc = cluster_check("cluster_bwd", f, v, ld, B, H, W, E, D, fold, &T, &npt);
   if (rc) return rc;
@@ -787,7 +797,10 @@ extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, co
     vr_set_error("cluster_bwd: workspace %ld < %ld bytes", workspace_bytes, need);
     return VR_ERR_WORKSPACE;
   }
+  VR_CHECK_ARG((!alpha2 == !beta2) && (!alpha2 == !dalpha2) && (!alpha2 == !dbeta2) && (!alpha2 || B % 2 == 0),
+               "cluster_bwd: a two-stream launch needs alpha2, beta2, dalpha2, dbeta2 and an even batch");
   ClusterArgs p{};
+  p.alpha2 = alpha2; p.beta2 = beta2;
   p.f = f; p.v = v; p.ld = ld; p.alpha = alpha; p.beta = beta; p.idx = const_cast<unsigned char*>(idx);
   p.g = dout; p.ldg = lddo; p.df = df; p.dv = dv; p.lddf = lddf;
   p.ab_partial = reinterpret_cast<float*>(workspace);
@@ -796,8 +809,8 @@ extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, co
   hipStream_t st = vr_stream(stream);
   cluster_launch<true>(p, T, npt, blocks, st);
   VR_LAUNCH_CHECK("cluster_bwd");
-  hipLaunchKernelGGL(cluster_ab_reduce_kernel, dim3(1), dim3(256), 0, st, p.ab_partial, blocks, dalpha, dbeta,
-                     accumulate_ab);
+  hipLaunchKernelGGL(cluster_ab_reduce_kernel, dim3(alpha2 ? 2 : 1), dim3(256), 0, st, p.ab_partial,
+                     alpha2 ? blocks / 2 : blocks, dalpha, dbeta, accumulate_ab, dalpha2, dbeta2);
   VR_LAUNCH_CHECK("cluster_ab_reduce");
   return VR_OK;
 }

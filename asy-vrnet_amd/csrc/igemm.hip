@@ -21,8 +21,9 @@
 namespace {
 
 template <int BM, int BN, int BK, int TM, int TN, int WM, int WN, int MODE, bool VEC>
-__global__ __launch_bounds__(256, (BM == 64 && BN == 64 && BK == 16) ? 8 : 1) void igemm_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(256, (BM == 64 && BN == 64 && BK == 16) ? 8 : 1) void igemm_kernel(const IgemmArgs p_in) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile");
+  const IgemmArgs p = igemm_select_stream(p_in, blockIdx.x * BM);
   constexpr int KQ = BK / 4;            // k-quads per row
   constexpr int RPP = 256 / KQ;         // rows covered per pass of the transposing loaders
   constexpr int AS_FLOATS = BK * (BM + 4), BS_FLOATS = BK * (BN + 4);
@@ -277,7 +278,7 @@ __device__ __attribute__((aligned(128))) float vr_zero_page[64];
 // accumulators per wave (32 MFMAs per stage, half the LDS-fill bytes and fragment reads per MFMA) for the layers
 // whose grid still fills the chip with 128-row tiles.  Both stage 16 KB per K step.
 template <int MODE, int NST, int T>
-__global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_dma_kernel(const IgemmArgs p, int MT, int NT) {
+__global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_dma_kernel(const IgemmArgs p_in, int MT, int NT) {
   constexpr int BM = 64 * T, BN = 64 * T, BK = 32 / T;
   constexpr int QPR = BK / 4;                       // 16-byte quads per K-contiguous row of a stage
   constexpr int KQ = QPR / 2;                       // quads each lane owns per stage (k = h*BK/2 .. +BK/2)
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
   const int nt = jj % NT, mt = (jj / NT) * 8 + (L & 7);
   if (mt >= MT) return;
   const int m0 = mt * BM, n0 = nt * BN;
+  const IgemmArgs p = igemm_select_stream(p_in, m0);
   const int nkb = (p.CK + BK - 1) / BK;
   const int TAPS = p.kh * p.kw;
 
@@ -577,9 +579,8 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64) ? 8 : 1) void wgrad_ker
   const int t = bid;
   const int ky = t / p.kw, kx = t - ky * p.kw;
   const int n0 = nt * BM, c0 = ct * BN;
-  const int split = blockIdx.y;
-  const int m_begin = split * p.rows_per_split;
-  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  int m_begin, m_end, split;
+  wgrad_rows(p, m_begin, m_end, split);
   constexpr int AVEC = (BM * BK / 4 + 255) / 256;
   constexpr int BVEC = (BN * BK / 4 + 255) / 256;
   f32x4 areg[AVEC], breg[BVEC];
@@ -725,9 +726,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradArgs p) {
   const int t = bid;
   const int ky = t / p.kw, kx = t - ky * p.kw;
   const int n0 = nt * 64, c0 = ct * 64;
-  const int split = blockIdx.y;
-  const int m_begin = split * p.rows_per_split;
-  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  int m_begin, m_end, split;
+  wgrad_rows(p, m_begin, m_end, split);
   const bool do_bias = p.bslab != nullptr && ct == 0 && t == 0;
   float bsum = 0.f;
   int s_kr[2], s_cq[2];
@@ -822,10 +822,15 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradArgs p) {
 template <int VEC, int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, const float* bslab, const float* row_scale,
                                                            float* dw, float* db, int S, int T, int Cout, int Cin,
-                                                           int accumulate) {
+                                                           int accumulate, const float* row_scale2, float* dw2, float* db2) {
   constexpr int OUTS = 256 / SL;
   __shared__ float red[SL][OUTS][VEC];
   const long per = (long)T * Cout * Cin;
+  if (blockIdx.y) {      // second stream of a two-stream launch: its own S slabs, outputs and row scale
+    slab += (long)S * per;
+    if (bslab) bslab += (long)S * Cout;
+    row_scale = row_scale2; dw = dw2; db = db2;
+  }
   const long nq = per / VEC;
   const int o = threadIdx.x % OUTS, sl = threadIdx.x / OUTS;
   const long e = (long)blockIdx.x * OUTS + o;
@@ -890,7 +895,7 @@ __global__ void pack_weight_kernel(const float* w, float* out, int Cout, int Cin
 
 // igemm_bf16.hip
 int vr_igemm_bf16_launch(const void* args, int mode, hipStream_t st);
-int vr_wgrad_bf16_launch(const void* args, int ident, int blocks_x, int splits, hipStream_t st);
+int vr_wgrad_bf16_launch(const void* args, int ident, int blocks_x, int splits, int streams, hipStream_t st);
 
 // tinyconv.hip
 int vr_tiny_conv(int mode, const float* a, long lda, const float* w, const float* bias, float* y, long ldy, int B, int H,
@@ -911,8 +916,13 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                                 int pad, int dil, int mode, int act, float* ypre, long ldypre, const float* res,
                                 long ldres, const float* res_scale, const float* kscale, const float* aux,
                                 long ldaux, int out_nchw, int out_ctot, int out_coff, int accumulate,
-                                double* stats, int precision, void* stream) {
+                                double* stats, int precision, int pair_rows, const float* w2, const float* bias2,
+                                const float* res_scale2, const float* kscale2, void* stream) {
   VR_CHECK_ARG(a && w && y, "conv2d: null tensor");
+  VR_CHECK_ARG(pair_rows >= 0 && (pair_rows == 0 || (w2 && pair_rows % 128 == 0 && (!bias == !bias2) &&
+                                                     (!res_scale == !res_scale2) && (!kscale == !kscale2))),
+               "conv2d: a two-stream launch needs the second parameter set and a first-stream row count that is a "
+               "multiple of 128");
   VR_CHECK_ARG(precision == 0 || precision == 1, "conv2d: precision 0 (fp32 MFMA) or 1 (bf16 operands, fp32 accumulate)");
   VR_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0, "conv2d: bad shape");
   VR_CHECK_ARG(kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d: bad geometry");
@@ -920,7 +930,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                    (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1 == OW,
                "conv2d: output size %dx%d inconsistent with input %dx%d k%d s%d p%d d%d", OH, OW, H, W, kh,
                stride, pad, dil);
-  const bool plain = !ypre && !res && !kscale && !aux && !out_nchw && act == 0 && !stats && precision == 0;
+  const bool plain = !ypre && !res && !kscale && !aux && !out_nchw && act == 0 && !stats && precision == 0 && !pair_rows;
   if (plain && tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride))
     return vr_tiny_conv(mode, a, lda, w, mode == 0 ? bias : nullptr, y, ldy, B, H, W, Cin, Cout, kh, pad, dil, accumulate,
                         vr_stream(stream));
@@ -952,6 +962,12 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
             (!aux || ((ldaux % 4 == 0) && vr_aligned16(aux)));
   p.stats = stats;
   p.stats_nb = (int)vr_cdiv(p.CN, 32);
+  p.pair_rows = pair_rows; p.w2 = w2; p.bias2 = bias2; p.res_scale2 = res_scale2; p.kscale2 = kscale2;
+  VR_CHECK_ARG(!pair_rows || (pair_rows < M && !p.perm2), "conv2d: two-stream launch with an unsupported row layout");
+  if (pair_rows) {
+    p.b_vec = p.b_vec && vr_aligned16(w2);
+    p.e_vec = p.e_vec && (!bias2 || vr_aligned16(bias2)) && (!res_scale2 || vr_aligned16(res_scale2));
+  }
   VR_CHECK_ARG(!stats || (p.e_vec && !p.perm2 && mode == 0 && ((long)p.MH * p.MW) % 32 == 0 && p.CN > 32),
                "conv2d: output statistics need the vector epilogue, a forward conv, > 32 output channels and a map of a "
                "multiple of 32 pixels");
@@ -1085,12 +1101,15 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
   }
 }
 
-extern "C" long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int Cout, int kh, int kw) {
+// pair = 1: two-stream launch (the B samples are two streams of B/2, each with its own weight gradient)
+extern "C" long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int Cout, int kh, int kw, int pair) {
   int cfg, bn, nt, ct, S, rows;
-  wgrad_plan((long)B * OH * OW, Cin, Cout, kh * kw, &cfg, &bn, &nt, &ct, &S, &rows);
-  long need = ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
-  wgrad_plan((long)B * OH * OW, Cin, Cout, kh * kw, &cfg, &bn, &nt, &ct, &S, &rows, 1);      // the bf16 plan may split more
-  const long need16 = ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
+  const int streams = pair ? 2 : 1;
+  const long Ms = (long)B * OH * OW / streams;
+  wgrad_plan(Ms, Cin, Cout, kh * kw, &cfg, &bn, &nt, &ct, &S, &rows);
+  long need = streams * ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
+  wgrad_plan(Ms, Cin, Cout, kh * kw, &cfg, &bn, &nt, &ct, &S, &rows, 1);      // the bf16 plan may split more
+  const long need16 = streams * ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
   if (need16 > need) need = need16;
   if (Cin <= 8 && Cout <= 8) {
     const long t = vr_tiny_wgrad_workspace((long)B * OH * OW, Cin, Cout, kh * kw);
@@ -1102,25 +1121,32 @@ extern "C" long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int
 extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, float* dbias,
                                       const float* row_scale, int B, int H, int W, int Cin, int OH, int OW,
                                       int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
-                                      int precision, void* workspace, long workspace_bytes, void* stream) {
+                                      int precision, float* dw2, float* dbias2, const float* row_scale2,
+                                      void* workspace, long workspace_bytes, void* stream) {
   VR_CHECK_ARG(x && dy && dw && workspace, "conv2d_wgrad: null tensor");
   const long M = (long)B * OH * OW;
   VR_CHECK_ARG(M < (1L << 31) && (long)B * H * W < (1L << 31), "conv2d_wgrad: too many pixels");
+  const int streams = dw2 ? 2 : 1;
+  VR_CHECK_ARG(streams == 1 || (B % 2 == 0 && (!dbias == !dbias2) && (!row_scale == !row_scale2)),
+               "conv2d_wgrad: a two-stream launch needs an even batch and the second set of outputs");
   const int T = kh * kw;
   int cfg, bn, nt, ct, S, rows;
-  wgrad_plan(M, Cin, Cout, T, &cfg, &bn, &nt, &ct, &S, &rows, precision == 1);
-  const long need = vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw);
+  wgrad_plan(M / streams, Cin, Cout, T, &cfg, &bn, &nt, &ct, &S, &rows, precision == 1);
+  const long need = vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw, streams == 2);
   if (workspace_bytes < need) {
     vr_set_error("conv2d_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
     return VR_ERR_WORKSPACE;
   }
+  VR_CHECK_ARG(streams == 1 || !tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride),
+               "conv2d_wgrad: two-stream launch of a tiny-channel layer");
   if (tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride))
     return vr_tiny_wgrad(x, ldx, dy, lddy, dw, dbias, row_scale, B, H, W, Cin, Cout, kh, pad, dil, accumulate, workspace,
                          vr_stream(stream));
   WgradArgs p{};
   p.x = x; p.ldx = ldx; p.dy = dy; p.lddy = lddy;
   p.slab = reinterpret_cast<float*>(workspace);
-  p.bslab = dbias ? p.slab + (long)S * T * Cout * Cin : nullptr;
+  p.bslab = dbias ? p.slab + (long)streams * S * T * Cout * Cin : nullptr;
+  p.M_half = (int)(M / streams);
   p.M = (int)M; p.OH = OH; p.OW = OW; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
   p.rows_per_split = rows; p.n_tiles = nt; p.c_tiles = ct;
@@ -1128,7 +1154,7 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
                    vr_aligned16(dy);
   const bool ident = kh == 1 && kw == 1 && stride == 1 && pad == 0;
   hipStream_t st = vr_stream(stream);
-  dim3 grid(nt * ct * T, S), block(256);
+  dim3 grid(nt * ct * T, S, streams), block(256);
 #define VR_WGRAD(BM_, BN_, TM_, TN_, WM_, WN_)                                                                      \
   do {                                                                                                              \
     if (ident && vec) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, TM_, TN_, WM_, WN_, true, true>), grid, block, 0, st, p);   \
@@ -1139,7 +1165,7 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   if (precision == 1) {
     VR_CHECK_ARG(vec && cfg == 1 && rows % 64 == 0, "conv2d_wgrad: the bf16 path needs 16-byte aligned rows, channel counts that "
                                                     "are multiples of 4 and more than 32 channels on both sides");
-    vr_wgrad_bf16_launch(&p, ident ? 1 : 0, nt * ct * T, S, st);
+    vr_wgrad_bf16_launch(&p, ident ? 1 : 0, nt * ct * T, S, streams, st);
   } else {
   static const int use_dma = getenv("VRNET_WGRAD_DMA") ? atoi(getenv("VRNET_WGRAD_DMA")) : 1;   // tuning aid
   // measured (bench.py --detail): the ring wins only for the smallest weight matrices (<= 4 tiles: +5..19 %); with
@@ -1157,8 +1183,8 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   const bool rvec = (Cin % 4 == 0);                 // slabs are 16-byte aligned (workspace arena), rows of Cin floats
   const long total = (long)T * Cout * Cin / (rvec ? 4 : 1) + (dbias ? Cout : 0);
 #define VR_WREDUCE(VEC_, SL_)                                                                                        \
-  hipLaunchKernelGGL((wgrad_reduce_kernel<VEC_, SL_>), dim3(vr_cdiv(total, 256 / SL_)), dim3(256), 0, st, p.slab, p.bslab, \
-                     row_scale, dw, dbias, S, T, Cout, Cin, accumulate)
+  hipLaunchKernelGGL((wgrad_reduce_kernel<VEC_, SL_>), dim3(vr_cdiv(total, 256 / SL_), streams), dim3(256), 0, st, p.slab, \
+                     p.bslab, row_scale, dw, dbias, S, T, Cout, Cin, accumulate, row_scale2, dw2, dbias2)
   // lanes per output: enough of them to cover the serial slab loop of the small matrices, one thread per output
   // once the matrix alone yields >= 64K threads (a 16-lane block there is 6 K workgroups of 256 B of output each)
   const int sl = (total >= 65536 || S <= 2) ? 1 : ((total >= 16384 || S <= 8) ? 4 : 16);

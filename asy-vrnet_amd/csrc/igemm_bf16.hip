@@ -15,7 +15,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmArgs p_in) {
+  const IgemmArgs p = igemm_select_stream(p_in, blockIdx.x * 64);
   constexpr int BM = 64, BN = 64, BK = 64, LD = BK + 8;
   constexpr int OPER_BYTES = 2 * BM * LD * 2, EPI_BYTES = 4 * 32 * STAGE_LD * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[OPER_BYTES > EPI_BYTES ? OPER_BYTES : EPI_BYTES];
@@ -163,9 +164,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs p) {
   const int t = bid;
   const int ky = t / p.kw, kx = t - ky * p.kw;
   const int n0 = nt * 64, c0 = ct * 64;
-  const int split = blockIdx.y;
-  const int m_begin = split * p.rows_per_split;
-  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  int m_begin, m_end, split;
+  wgrad_rows(p, m_begin, m_end, split);
   const bool do_bias = p.bslab != nullptr && ct == 0 && t == 0;
   const int q4 = 4 * (tid & 15), r0 = tid >> 4;          // this thread's channel quad, rows r0 + 16 i of a step
   f32x4 yreg[4], xreg[4];
@@ -275,9 +275,9 @@ int vr_igemm_bf16_launch(const void* args, int mode, hipStream_t st) {
 }
 
 // internal entry used by vrnet_conv2d_wgrad_f32 (igemm.hip) when precision == 1
-int vr_wgrad_bf16_launch(const void* args, int ident, int blocks_x, int splits, hipStream_t st) {
+int vr_wgrad_bf16_launch(const void* args, int ident, int blocks_x, int splits, int streams, hipStream_t st) {
   const WgradArgs& p = *reinterpret_cast<const WgradArgs*>(args);
-  dim3 grid(blocks_x, splits), block(256);
+  dim3 grid(blocks_x, splits, streams), block(256);
   if (ident) hipLaunchKernelGGL((wgrad_bf16_kernel<true>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((wgrad_bf16_kernel<false>), grid, block, 0, st, p);
   return VR_OK;

@@ -23,7 +23,21 @@ struct IgemmArgs {
   int perm2;   // data gradient of a stride-2 conv: GEMM rows enumerate the 4 pixel parity classes one after another
   double* stats;   // [ceil(M/32)][ceil(CN/32)][2]: (sum, sum of squares) of the stored outputs per 32x32 tile, or NULL
   int stats_nb;    // ceil(CN/32)
+  // Two-stream launch (the image and the radar chain of a backbone stage as ONE batch of 2B samples,
+  // vr_coc.py:589-600): GEMM rows >= pair_rows belong to the second stream and use its own parameter set.
+  // pair_rows is a multiple of every row-tile size, so a workgroup never straddles the two halves.
+  int pair_rows;   // 0 = single parameter set
+  const float* w2; const float* bias2; const float* res_scale2; const float* kscale2;
 };
+
+// The argument block a workgroup whose first row is m0 works with: the second stream's parameters behind pair_rows.
+__device__ __forceinline__ IgemmArgs igemm_select_stream(const IgemmArgs& in, int m0) {
+  IgemmArgs p = in;
+  if (in.pair_rows && m0 >= in.pair_rows) {
+    p.w = in.w2; p.bias = in.bias2; p.res_scale = in.res_scale2; p.kscale = in.kscale2;
+  }
+  return p;
+}
 
 // GEMM row -> (sample, y, x) of the M-side pixel grid.  With perm2 the rows are parity-major: class (y&1, x&1)
 // occupies a contiguous quarter of the rows, so every 64-row tile has ONE parity and the live-tap list drops
@@ -200,6 +214,17 @@ struct WgradArgs {
   int M, OH, OW, H, W, Cin, Cout;
   int kh, kw, stride, pad, dil;
   int rows_per_split, n_tiles, c_tiles;
+  int M_half;      // rows per stream: gridDim.z = 2 streams each contract their own M_half rows into their own slabs
 };
+
+// (first row, end row, slab index) of this workgroup: blockIdx.y = split within the stream, blockIdx.z = stream
+__device__ __forceinline__ void wgrad_rows(const WgradArgs& p, int& m_begin, int& m_end, int& split) {
+  const int z = blockIdx.z;
+  const int base = z * p.M_half;
+  m_begin = base + blockIdx.y * p.rows_per_split;
+  const int limit = gridDim.z > 1 ? base + p.M_half : p.M;
+  m_end = min(limit, m_begin + p.rows_per_split);
+  split = z * gridDim.y + blockIdx.y;
+}
 
 }  // namespace

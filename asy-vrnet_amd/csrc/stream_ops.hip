@@ -217,9 +217,11 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 
 __global__ __launch_bounds__(256) void gn_coef_fwd_kernel(const double* mom, const float* gamma, const float* beta,
                                                           float eps, long HW, int C, float* A, float* D,
-                                                          float* S, float* mean_rstd) {
+                                                          float* S, float* mean_rstd, const float* gamma2,
+                                                          const float* beta2) {
   __shared__ double red[4];
   const int b = blockIdx.x;
+  if (gamma2 && 2 * b >= (int)gridDim.x) { gamma = gamma2; beta = beta2; }     // two-stream launch: second half of the samples
   double s1 = 0, s2 = 0;
   for (int c = threadIdx.x; c < C; c += 256) {
     s1 += mom[((long)b * C + c) * 2];
@@ -248,9 +250,11 @@ __global__ __launch_bounds__(256) void gn_coef_fwd_kernel(const double* mom, con
 // the coefficients -- the cross-chunk reduce launch and the per-channel table are skipped.
 __global__ __launch_bounds__(256) void gn_coef_fwd_partial_kernel(const double* partial, long pairs, const float* gamma,
                                                                   const float* beta, float eps, long HW, int C, float* A,
-                                                                  float* D, float* S, float* mean_rstd) {
+                                                                  float* D, float* S, float* mean_rstd,
+                                                                  const float* gamma2, const float* beta2) {
   __shared__ double red[4];
   const int b = blockIdx.x;
+  if (gamma2 && 2 * b >= (int)gridDim.x) { gamma = gamma2; beta = beta2; }     // two-stream launch: second half of the samples
   const double* src = partial + (long)b * pairs * 2;
   double s1 = 0, s2 = 0, t1 = 0, t2 = 0;
   long i = threadIdx.x;
@@ -281,10 +285,12 @@ __global__ __launch_bounds__(256) void gn_coef_fwd_partial_kernel(const double* 
 __global__ __launch_bounds__(256) void gn_coef_bwd_kernel(const double* mom2, const float* mean_rstd,
                                                           const float* gamma, int B, long HW, int C, float* A,
                                                           float* E, float* D, float* S, float* dgamma, float* dbeta,
-                                                          int accumulate) {
+                                                          int accumulate, const float* gamma2, float* dgamma2,
+                                                          float* dbeta2) {
   __shared__ double red[4];
   if ((int)blockIdx.x < B) {
     const int b = blockIdx.x;
+    if (gamma2 && 2 * b >= B) gamma = gamma2;
     const double mu = mean_rstd[2 * b], r = mean_rstd[2 * b + 1];
     double t1 = 0, t2 = 0;
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -306,15 +312,20 @@ __global__ __launch_bounds__(256) void gn_coef_bwd_kernel(const double* mom2, co
   } else {
     const int c = (blockIdx.x - B) * 256 + threadIdx.x;
     if (c >= C) return;
-    double dg = 0, db = 0;
-    for (int b = 0; b < B; ++b) {
-      const double mu = mean_rstd[2 * b], r = mean_rstd[2 * b + 1];
-      const double s1 = mom2[((long)b * C + c) * 2], s2 = mom2[((long)b * C + c) * 2 + 1];
-      dg += r * (s2 - mu * s1);
-      db += s1;
+    const int nstream = gamma2 ? 2 : 1, per = B / nstream;
+    for (int z = 0; z < nstream; ++z) {       // per-channel gradients of each stream's own parameters
+      double dg = 0, db = 0;
+      for (int b = z * per; b < (z + 1) * per; ++b) {
+        const double mu = mean_rstd[2 * b], r = mean_rstd[2 * b + 1];
+        const double s1 = mom2[((long)b * C + c) * 2], s2 = mom2[((long)b * C + c) * 2 + 1];
+        dg += r * (s2 - mu * s1);
+        db += s1;
+      }
+      float* og = z ? dgamma2 : dgamma;
+      float* ob = z ? dbeta2 : dbeta;
+      og[c] = (accumulate ? og[c] : 0.f) + (float)dg;
+      ob[c] = (accumulate ? ob[c] : 0.f) + (float)db;
     }
-    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dg;
-    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)db;
   }
 }
 
@@ -426,11 +437,16 @@ __global__ __launch_bounds__(256) void eca_dwk_kernel(const double* mom2, const 
 
 // layer scale: x_new = x + ls * o.  mom2 = (sum dx, sum dx*o).  dls = sum_b S2; dbias = ls * sum_b S1.
 __global__ void ls_coef_bwd_kernel(const double* mom2, const float* ls, int B, int C, float* dls, float* dbias,
-                                   int accumulate) {
+                                   int accumulate, const float* ls2, float* dls2, float* dbias2) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  int b0 = 0, b1 = B;
+  if (gridDim.y > 1) {       // two-stream launch: blockIdx.y = stream, each over its half of the samples
+    b0 = blockIdx.y * (B / 2); b1 = b0 + B / 2;
+    if (blockIdx.y) { ls = ls2; dls = dls2; dbias = dbias2; }
+  }
   double s1 = 0, s2 = 0;
-  for (int b = 0; b < B; ++b) {
+  for (int b = b0; b < b1; ++b) {
     s1 += mom2[((long)b * C + c) * 2];
     s2 += mom2[((long)b * C + c) * 2 + 1];
   }
@@ -575,24 +591,26 @@ extern "C" int vrnet_moments_f32(const float* x, long ldx, const float* x2, long
 
 extern "C" int vrnet_gn_coef_from_pairs(const double* pairs, long pairs_per_sample, const float* gamma, const float* beta,
                                         float eps, int B, long HW, int C, float* A, float* D, float* S, float* mean_rstd,
-                                        void* stream) {
+                                        const float* gamma2, const float* beta2, void* stream) {
   VR_CHECK_ARG(pairs && pairs_per_sample > 0 && gamma && beta && A && D && S && mean_rstd, "gn_coef_from_pairs: bad arguments");
+  VR_CHECK_ARG((!gamma2 == !beta2) && (!gamma2 || B % 2 == 0), "gn_coef_from_pairs: two-stream launch needs gamma2, beta2, even batch");
   hipLaunchKernelGGL(gn_coef_fwd_partial_kernel, dim3(B), dim3(256), 0, vr_stream(stream), pairs, pairs_per_sample, gamma, beta,
-                     eps, HW, C, A, D, S, mean_rstd);
+                     eps, HW, C, A, D, S, mean_rstd, gamma2, beta2);
   VR_LAUNCH_CHECK("gn_coef_from_pairs");
   return VR_OK;
 }
 
 extern "C" int vrnet_gn_stats_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, int B,
-                                  long HW, int C, float* A, float* D, float* S, float* mean_rstd, void* workspace,
-                                  long workspace_bytes, void* stream) {
+                                  long HW, int C, float* A, float* D, float* S, float* mean_rstd, const float* gamma2,
+                                  const float* beta2, void* workspace, long workspace_bytes, void* stream) {
   VR_CHECK_ARG(gamma && beta && A && D && S && mean_rstd, "gn_stats_fwd: null tensor");
+  VR_CHECK_ARG((!gamma2 == !beta2) && (!gamma2 || B % 2 == 0), "gn_stats_fwd: two-stream launch needs gamma2, beta2, even batch");
   hipStream_t st = vr_stream(stream);
   int nchunks;
   int rc = moments_launch(x, ldx, nullptr, 0, nullptr, 0, B, HW, C, workspace, workspace_bytes, st, &nchunks, 1);
   if (rc) return rc;
   hipLaunchKernelGGL(gn_coef_fwd_partial_kernel, dim3(B), dim3(256), 0, st, reinterpret_cast<double*>(workspace),
-                     (long)nchunks, gamma, beta, eps, HW, C, A, D, S, mean_rstd);
+                     (long)nchunks, gamma, beta, eps, HW, C, A, D, S, mean_rstd, gamma2, beta2);
   VR_LAUNCH_CHECK("gn_stats_fwd");
   return VR_OK;
 }
@@ -623,17 +641,19 @@ extern "C" int vrnet_gn_coef_fwd(const double* mom, const float* gamma, const fl
                                  int C, float* A, float* D, float* S, float* mean_rstd, void* stream) {
   VR_CHECK_ARG(mom && gamma && beta && A && D && S && mean_rstd, "gn_coef_fwd: null tensor");
   hipLaunchKernelGGL(gn_coef_fwd_kernel, dim3(B), dim3(256), 0, vr_stream(stream), mom, gamma, beta, eps, HW, C, A, D, S,
-                     mean_rstd);
+                     mean_rstd, (const float*)nullptr, (const float*)nullptr);
   VR_LAUNCH_CHECK("gn_coef_fwd");
   return VR_OK;
 }
 
 extern "C" int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int B, long HW, int C,
                                  float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,
-                                 void* stream) {
+                                 const float* gamma2, float* dgamma2, float* dbeta2, void* stream) {
   VR_CHECK_ARG(mom2 && mean_rstd && gamma && A && E && D && S && dgamma && dbeta, "gn_coef_bwd: null tensor");
+  VR_CHECK_ARG((!gamma2 == !dgamma2) && (!gamma2 == !dbeta2) && (!gamma2 || B % 2 == 0),
+               "gn_coef_bwd: two-stream launch needs gamma2, dgamma2, dbeta2 and an even batch");
   hipLaunchKernelGGL(gn_coef_bwd_kernel, dim3(B + vr_cdiv(C, 256)), dim3(256), 0, vr_stream(stream), mom2, mean_rstd,
-                     gamma, B, HW, C, A, E, D, S, dgamma, dbeta, accumulate);
+                     gamma, B, HW, C, A, E, D, S, dgamma, dbeta, accumulate, gamma2, dgamma2, dbeta2);
   VR_LAUNCH_CHECK("gn_coef_bwd");
   return VR_OK;
 }
@@ -683,10 +703,12 @@ extern "C" int vrnet_eca_coef_bwd(const double* mom2, const double* mom, const f
 }
 
 extern "C" int vrnet_ls_coef_bwd(const double* mom2, const float* ls, int B, int C, float* dls, float* dbias,
-                                 int accumulate, void* stream) {
+                                 int accumulate, int pair, const float* ls2, float* dls2, float* dbias2, void* stream) {
   VR_CHECK_ARG(mom2, "ls_coef_bwd: null tensor");
-  hipLaunchKernelGGL(ls_coef_bwd_kernel, dim3(vr_cdiv(C, 128)), dim3(128), 0, vr_stream(stream), mom2, ls, B, C, dls,
-                     dbias, accumulate);
+  VR_CHECK_ARG(!pair || (B % 2 == 0 && (!ls == !ls2) && (!dls == !dls2) && (!dbias == !dbias2)),
+               "ls_coef_bwd: two-stream launch needs the second parameter set and an even batch");
+  hipLaunchKernelGGL(ls_coef_bwd_kernel, dim3(vr_cdiv(C, 128), pair ? 2 : 1), dim3(128), 0, vr_stream(stream), mom2, ls, B, C,
+                     dls, dbias, accumulate, ls2, dls2, dbias2);
   VR_LAUNCH_CHECK("ls_coef_bwd");
   return VR_OK;
 }

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvrnet_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -25,23 +25,23 @@ _SIGS = {
     "vrnet_abi_version": ([], I),
     "vrnet_last_error": ([], ctypes.c_char_p),
     "vrnet_device_arch": ([ctypes.c_char_p, I], I),
-    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, P], I),
+    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
-    "vrnet_conv2d_wgrad_workspace": ([I] * 7, L),
-    "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 14 + [P, L, P], I),
+    "vrnet_conv2d_wgrad_workspace": ([I] * 8, L),
+    "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 14 + [P, P, P, P, L, P], I),
     "vrnet_pack_weight_f32": ([P, P, I, I, I, I, P], I),
     "vrnet_moments_workspace": ([I, L, I], L),
     "vrnet_moments_f32": ([P, L, P, L, P, L, I, L, I, P, P, L, P], I),
     "vrnet_affine_f32": ([P, L, P, P, P, I, P, L, P, L, P, P, P, L, P, L, I, L, I, I, P], I),
     "vrnet_gn_coef_fwd": ([P, P, P, F, I, L, I, P, P, P, P, P], I),
-    "vrnet_gn_coef_from_pairs": ([P, L, P, P, F, I, L, I, P, P, P, P, P], I),
-    "vrnet_gn_stats_fwd": ([P, L, P, P, F, I, L, I, P, P, P, P, P, L, P], I),
-    "vrnet_gn_coef_bwd": ([P, P, P, I, L, I, P, P, P, P, P, P, I, P], I),
+    "vrnet_gn_coef_from_pairs": ([P, L, P, P, F, I, L, I, P, P, P, P, P, P, P], I),
+    "vrnet_gn_stats_fwd": ([P, L, P, P, F, I, L, I, P, P, P, P, P, P, P, L, P], I),
+    "vrnet_gn_coef_bwd": ([P, P, P, I, L, I, P, P, P, P, P, P, I, P, P, P, P], I),
     "vrnet_bn_coef_fwd": ([P, P, P, F, F, P, P, P, I, I, L, I, P, P, P, P, P], I),
     "vrnet_bn_coef_bwd": ([P, P, P, I, I, L, I, P, P, P, P, P, P, I, P], I),
     "vrnet_eca_coef_fwd": ([P, P, I, I, L, I, P, P], I),
     "vrnet_eca_coef_bwd": ([P, P, P, P, I, I, L, I, P, P, I, P], I),
-    "vrnet_ls_coef_bwd": ([P, P, I, I, P, P, I, P], I),
+    "vrnet_ls_coef_bwd": ([P, P, I, I, P, P, I, I, P, P, P, P], I),
     "vrnet_moments_to_float": ([P, P, L, D, I, P], I),
     "vrnet_copy_channels_f32": ([P, L, I, P, L, I, L, I, I, P], I),
     "vrnet_patch_gather_f32": ([P, L, P, P, I, I, I, I, I, I, P], I),
@@ -51,10 +51,10 @@ _SIGS = {
     "vrnet_nhwc_to_nchw_f32": ([P, L, P, I, I, L, I, P], I),
     "vrnet_add_f32": ([P, P, L, P], I),
     "vrnet_fill_f32": ([P, F, L, P], I),
-    "vrnet_cluster_fwd_f32": ([P, P, L, P, P, P, L, P, P, I, I, I, I, I, I, P], I),
+    "vrnet_cluster_fwd_f32": ([P, P, L, P, P, P, L, P, P, I, I, I, I, I, I, P, P, P], I),
     "vrnet_cluster_bwd_workspace": ([I, I, I], L),
     "vrnet_cluster_bwd_workspace2": ([I, I, I, I, I], L),
-    "vrnet_cluster_bwd_f32": ([P, P, L, P, P, P, P, L, P, P, L, P, P, I, I, I, I, I, I, I, P, L, P], I),
+    "vrnet_cluster_bwd_f32": ([P, P, L, P, P, P, P, L, P, P, L, P, P, I, I, I, I, I, I, I, P, P, P, P, P, L, P], I),
     "vrnet_dwconv3x3_f32": ([P, L, P, P, L, I, I, I, I, I, I, P], I),
     "vrnet_dwconv3x3_wgrad_workspace": ([I, I, I, I], L),
     "vrnet_dwconv3x3_wgrad_f32": ([P, L, P, L, P, I, I, I, I, I, P, L, P], I),
@@ -147,11 +147,14 @@ _ws = Workspace()
 # --------------------------------------------------------------------------------------- wrappers
 def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, mode=0, act=0,
            ypre=None, ldypre=0, res=None, ldres=0, res_scale=None, kscale=None, aux=None, ldaux=0,
-           out_nchw=0, out_ctot=0, out_coff=0, accumulate=0, stats=None, precision=0):
+           out_nchw=0, out_ctot=0, out_coff=0, accumulate=0, stats=None, precision=0, pair_rows=0, w2=None, bias2=None,
+           res_scale2=None, kscale2=None):
+    """pair_rows > 0: two-stream launch, GEMM rows >= pair_rows use (w2, bias2, res_scale2, kscale2)."""
     _check(_lib.vrnet_conv2d_f32(ptr(a), lda, ptr(w), ptr(bias), ptr(y), ldy, B, H, W, Cin, OH, OW, Cout, kh, kw,
                                  stride, pad, dil, mode, act, ptr(ypre), ldypre, ptr(res), ldres, ptr(res_scale),
                                  ptr(kscale), ptr(aux), ldaux, out_nchw, out_ctot, out_coff, accumulate, ptr(stats),
-                                 precision, stream()), "conv2d")
+                                 precision, pair_rows, ptr(w2), ptr(bias2), ptr(res_scale2), ptr(kscale2), stream()),
+           "conv2d")
 
 
 def bf16_conv_ok(lda, Cin, Cout, mode):
@@ -173,12 +176,13 @@ def conv_stats_buffer(B, HW, Cout, device):
 
 
 def conv2d_wgrad(x, ldx, dy, lddy, dw, dbias, row_scale, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil,
-                 accumulate=0, precision=0):
-    nbytes = _lib.vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw)
+                 accumulate=0, precision=0, dw2=None, dbias2=None, row_scale2=None):
+    """dw2 given: two-stream launch, samples [B/2, B) contribute to (dw2, dbias2, row_scale2)."""
+    nbytes = _lib.vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw, 1 if dw2 is not None else 0)
     ws = _ws.get(nbytes, x.device)
     _check(_lib.vrnet_conv2d_wgrad_f32(ptr(x), ldx, ptr(dy), lddy, ptr(dw), ptr(dbias), ptr(row_scale), B, H, W, Cin,
-                                       OH, OW, Cout, kh, kw, stride, pad, dil, accumulate, precision, ptr(ws),
-                                       ws.numel(), stream()), "conv2d_wgrad")
+                                       OH, OW, Cout, kh, kw, stride, pad, dil, accumulate, precision, ptr(dw2),
+                                       ptr(dbias2), ptr(row_scale2), ptr(ws), ws.numel(), stream()), "conv2d_wgrad")
 
 
 def bf16_wgrad_ok(ldx, lddy, Cin, Cout):
@@ -209,20 +213,22 @@ def gn_coef_fwd(mom, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd):
                                   ptr(mean_rstd), stream()), "gn_coef_fwd")
 
 
-def gn_coef_from_pairs(pairs, per_sample, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd):
+def gn_coef_from_pairs(pairs, per_sample, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd, gamma2=None, beta2=None):
     _check(_lib.vrnet_gn_coef_from_pairs(ptr(pairs), per_sample, ptr(gamma), ptr(beta), eps, B, HW, C, ptr(A), ptr(Dc),
-                                         ptr(S), ptr(mean_rstd), stream()), "gn_coef_from_pairs")
+                                         ptr(S), ptr(mean_rstd), ptr(gamma2), ptr(beta2), stream()), "gn_coef_from_pairs")
 
 
-def gn_stats_fwd(x, ldx, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd):
+def gn_stats_fwd(x, ldx, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd, gamma2=None, beta2=None):
     ws = _ws.get(_lib.vrnet_moments_workspace(B, HW, C), x.device)
     _check(_lib.vrnet_gn_stats_fwd(ptr(x), ldx, ptr(gamma), ptr(beta), eps, B, HW, C, ptr(A), ptr(Dc), ptr(S),
-                                   ptr(mean_rstd), ptr(ws), ws.numel(), stream()), "gn_stats_fwd")
+                                   ptr(mean_rstd), ptr(gamma2), ptr(beta2), ptr(ws), ws.numel(), stream()), "gn_stats_fwd")
 
 
-def gn_coef_bwd(mom2, mean_rstd, gamma, B, HW, C, A, E, Dc, S, dgamma, dbeta, accumulate):
+def gn_coef_bwd(mom2, mean_rstd, gamma, B, HW, C, A, E, Dc, S, dgamma, dbeta, accumulate, gamma2=None, dgamma2=None,
+                dbeta2=None):
     _check(_lib.vrnet_gn_coef_bwd(ptr(mom2), ptr(mean_rstd), ptr(gamma), B, HW, C, ptr(A), ptr(E), ptr(Dc), ptr(S),
-                                  ptr(dgamma), ptr(dbeta), accumulate, stream()), "gn_coef_bwd")
+                                  ptr(dgamma), ptr(dbeta), accumulate, ptr(gamma2), ptr(dgamma2), ptr(dbeta2), stream()),
+           "gn_coef_bwd")
 
 
 def bn_coef_fwd(mom, gamma, beta, eps, momentum, rm, rv, nbt, training, B, HW, C, A, Dc, S, mean_rstd):
@@ -245,8 +251,9 @@ def eca_coef_bwd(mom2, mom, gate, wk, k, B, HW, C, Fc, dwk, accumulate):
                                    stream()), "eca_coef_bwd")
 
 
-def ls_coef_bwd(mom2, ls, B, C, dls, dbias, accumulate):
-    _check(_lib.vrnet_ls_coef_bwd(ptr(mom2), ptr(ls), B, C, ptr(dls), ptr(dbias), accumulate, stream()), "ls_coef_bwd")
+def ls_coef_bwd(mom2, ls, B, C, dls, dbias, accumulate, pair=0, ls2=None, dls2=None, dbias2=None):
+    _check(_lib.vrnet_ls_coef_bwd(ptr(mom2), ptr(ls), B, C, ptr(dls), ptr(dbias), accumulate, pair, ptr(ls2), ptr(dls2),
+                                  ptr(dbias2), stream()), "ls_coef_bwd")
 
 
 def moments_to_float(mom, out, n, scale, which=0):
@@ -286,17 +293,18 @@ def fill_(dst, value):
     _check(_lib.vrnet_fill_f32(ptr(dst), float(value), dst.numel(), stream()), "fill")
 
 
-def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold):
+def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold, alpha2=None, beta2=None):
     _check(_lib.vrnet_cluster_fwd_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(out), ldo, ptr(idx), ptr(wgt), B, H,
-                                      W, E, Dh, fold, stream()), "cluster_fwd")
+                                      W, E, Dh, fold, ptr(alpha2), ptr(beta2), stream()), "cluster_fwd")
 
 
 def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, dbeta, accumulate_ab, B, H, W, E, Dh,
-                fold):
+                fold, alpha2=None, beta2=None, dalpha2=None, dbeta2=None):
     ws = _ws.get(_lib.vrnet_cluster_bwd_workspace2(B, H, W, E, fold), f.device)
     _check(_lib.vrnet_cluster_bwd_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(idx), ptr(dout), lddo, ptr(df),
                                       ptr(dv), lddf, ptr(dalpha), ptr(dbeta), accumulate_ab, B, H, W, E, Dh, fold,
-                                      ptr(ws), ws.numel(), stream()), "cluster_bwd")
+                                      ptr(alpha2), ptr(beta2), ptr(dalpha2), ptr(dbeta2), ptr(ws), ws.numel(), stream()),
+           "cluster_bwd")
 
 
 def dwconv3x3(x, ldx, w, y, ldy, B, H, W, C, flip=0, accumulate=0):

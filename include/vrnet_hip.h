@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------- */
-int vrnet_abi_version(void);                 /* == 2 */
+int vrnet_abi_version(void);                 /* == 3 */
 const char* vrnet_last_error(void);          /* host string, thread local */
 int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sramecc+:xnack-" (synchronous) */
 
@@ -45,23 +45,30 @@ int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sram
  *   vrnet_pack_weight_t_f32's [kh*kw][Cin][Cout] pack with kscale folded in (kscale itself must then be NULL).
  * stats (NULL = none; forward, NHWC, Cout > 32, OH*OW % 32 == 0): [ceil(M/32)][ceil(Cout/32)][2] fp64 (sum, sum of
  *   squares) of the STORED outputs per 32-row x 32-channel tile -- the GroupNorm statistics of the consumer
- *   (vrnet_gn_coef_from_pairs: OH*OW/32 * ceil(Cout/32) consecutive pairs per sample) without another pass over y. */
+ *   (vrnet_gn_coef_from_pairs: OH*OW/32 * ceil(Cout/32) consecutive pairs per sample) without another pass over y.
+ * Two-stream launch (pair_rows > 0): the image chain and the radar chain of a backbone stage run the same layer
+ *   shapes on their own parameters (vr_coc.py:589-600: network[idx](x), network_radar[idx](x_radar)); with both
+ *   streams stacked along the batch, GEMM rows < pair_rows use (w, bias, res_scale, kscale) and rows >= pair_rows use
+ *   (w2, bias2, res_scale2, kscale2) -- one launch with twice the tiles instead of two.  pair_rows % 128 == 0. */
 int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias, float* y, long ldy,
                      int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride, int pad,
                      int dil, int mode, int act, float* ypre, long ldypre, const float* res, long ldres,
                      const float* res_scale, const float* kscale, const float* aux, long ldaux, int out_nchw,
-                     int out_ctot, int out_coff, int accumulate, double* stats, int precision, void* stream);
+                     int out_ctot, int out_coff, int accumulate, double* stats, int precision, int pair_rows,
+                     const float* w2, const float* bias2, const float* res_scale2, const float* kscale2, void* stream);
 
 /* Weight (+ bias) gradient of the same convolutions (autograd of nn.Conv2d): dw in OIHW layout
  * [Cout][Cin][kh][kw], dbias[Cout] (NULL = none), both scaled by row_scale[Cout] when given (layer scale).
  * Deterministic split over output pixels into fp32 slabs in `workspace` (size from ..._workspace).
  * precision 1: dy and x rounded to bf16 while staged, v_mfma_f32_32x32x16_bf16 with transposing LDS reads, fp32
- * accumulate / slabs / bias sums (needs 16-byte rows, Cin, Cout multiples of 4 and > 32). */
-long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int Cout, int kh, int kw);
+ * accumulate / slabs / bias sums (needs 16-byte rows, Cin, Cout multiples of 4 and > 32).
+ * Two-stream launch (dw2 != NULL; workspace with pair = 1): samples [0, B/2) contribute to (dw, dbias, row_scale),
+ * samples [B/2, B) to (dw2, dbias2, row_scale2). */
+long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int Cout, int kh, int kw, int pair);
 int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, float* dbias,
                            const float* row_scale, int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh,
-                           int kw, int stride, int pad, int dil, int accumulate, int precision, void* workspace,
-                           long workspace_bytes, void* stream);
+                           int kw, int stride, int pad, int dil, int accumulate, int precision, float* dw2,
+                           float* dbias2, const float* row_scale2, void* workspace, long workspace_bytes, void* stream);
 int vrnet_pack_weight_f32(const float* w_oihw, float* w_tnc, int Cout, int Cin, int kh, int kw, void* stream);
 /* [kh*kw][Cin][Cout] = w_oihw[n][c][t] * kscale[n] (kscale NULL = 1): the data-gradient operand of the bf16 path. */
 int vrnet_pack_weight_t_f32(const float* w_oihw, const float* kscale, float* w_tcn, int Cout, int Cin, int kh, int kw,
@@ -92,18 +99,20 @@ int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1,
 int vrnet_gn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, int B, long HW, int C,
                       float* A, float* D, float* S, float* mean_rstd, void* stream);
 /* The same coefficients from (sum, sum of squares) pairs, pairs_per_sample consecutive pairs per sample (the `stats`
- * output of vrnet_conv2d_f32). */
+ * output of vrnet_conv2d_f32).  gamma2 / beta2 (NULL = none): two-stream launch, samples [B/2, B) use them. */
 int vrnet_gn_coef_from_pairs(const double* pairs, long pairs_per_sample, const float* gamma, const float* beta, float eps,
-                             int B, long HW, int C, float* A, float* D, float* S, float* mean_rstd, void* stream);
+                             int B, long HW, int C, float* A, float* D, float* S, float* mean_rstd,
+                             const float* gamma2, const float* beta2, void* stream);
 /* vrnet_moments_f32 + vrnet_gn_coef_fwd in two launches (the per-sample totals come straight from the chunk partials);
  * workspace as vrnet_moments_workspace. */
 int vrnet_gn_stats_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, int B, long HW, int C,
-                       float* A, float* D, float* S, float* mean_rstd, void* workspace, long workspace_bytes,
-                       void* stream);
-/* mom2 = moments(dy, x2 = x): dx = A*dy + E*(x - S) + D with A,E,D,S [B][C]; dgamma, dbeta [C]. */
+                       float* A, float* D, float* S, float* mean_rstd, const float* gamma2, const float* beta2,
+                       void* workspace, long workspace_bytes, void* stream);
+/* mom2 = moments(dy, x2 = x): dx = A*dy + E*(x - S) + D with A,E,D,S [B][C]; dgamma, dbeta [C].
+ * gamma2 / dgamma2 / dbeta2 (NULL = none): two-stream launch, samples [B/2, B) belong to the second norm. */
 int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int B, long HW, int C,
                       float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,
-                      void* stream);
+                      const float* gamma2, float* dgamma2, float* dbeta2, void* stream);
 /* nn.BatchNorm2d: batch statistics + running-stat update (unbiased var, momentum) + num_batches_tracked += 1
  * when training, running statistics otherwise.  y = A*(z - S) + D with A,D,S [C]; mean_rstd [C][2]. */
 int vrnet_bn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, float momentum,
@@ -118,9 +127,10 @@ int vrnet_eca_coef_fwd(const double* mom, const float* wk, int k, int B, long HW
 /* mom2 = moments(dy, x2 = x): dx = gate*dy + F[b][c]; dwk [k]. */
 int vrnet_eca_coef_bwd(const double* mom2, const double* mom, const float* gate, const float* wk, int k, int B,
                        long HW, int C, float* F, float* dwk, int accumulate, void* stream);
-/* Layer scale x + ls*o (vr_coc.py:266-271), mom2 = moments(dx, x2 = o): dls[c] = sum dx*o; dbias = ls * sum dx. */
+/* Layer scale x + ls*o (vr_coc.py:266-271), mom2 = moments(dx, x2 = o): dls[c] = sum dx*o; dbias = ls * sum dx.
+ * pair = 1: two-stream launch, samples [B/2, B) reduce into (dls2, dbias2) with ls2. */
 int vrnet_ls_coef_bwd(const double* mom2, const float* ls, int B, int C, float* dls, float* dbias, int accumulate,
-                      void* stream);
+                      int pair, const float* ls2, float* dls2, float* dbias2, void* stream);
 int vrnet_moments_to_float(const double* mom, float* out, long n, double scale, int which, void* stream);
 
 /* ---- non-overlapping patch embedding as gather + GEMM ---------------------------------------------------
@@ -152,17 +162,19 @@ int vrnet_fill_f32(float* dst, float value, long n, void* stream);
  * tiles of the map (fold = 1: the whole map), D % 4 == 0, D <= 32.  Regions of <= 256 points (every backbone
  * stage at 512 px) stay in registers; larger ones (neck p3 at 512 px, everything at 1024 px) use a streaming kernel.
  * idx: (B,H,W,E) u8 hard assignment (first maximum, as torch.max(dim)); wgt: (B,H,W,E) similarity of the
- * assigned centre (optional for regions of <= 256 points, required above).  alpha, beta: device scalars (sim_alpha, sim_beta, :148-149). */
+ * assigned centre (optional for regions of <= 256 points, required above).  alpha, beta: device scalars (sim_alpha, sim_beta, :148-149).
+ * alpha2 / beta2 (NULL = none): two-stream launch, samples [B/2, B) belong to a second Cluster module. */
 int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                           float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E, int D,
-                          int fold, void* stream);
+                          int fold, const float* alpha2, const float* beta2, void* stream);
 long vrnet_cluster_bwd_workspace(int B, int E, int fold);                          /* regions of <= 256 points */
 long vrnet_cluster_bwd_workspace2(int B, int H, int W, int E, int fold);            /* any region size */
 /* Recomputes the forward from f, v with the saved assignment idx; df, dv share row stride lddf. */
 int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                           const unsigned char* idx, const float* dout, long lddo, float* df, float* dv, long lddf,
                           float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W, int E, int D,
-                          int fold, void* workspace, long workspace_bytes, void* stream);
+                          int fold, const float* alpha2, const float* beta2, float* dalpha2, float* dbeta2,
+                          void* workspace, long workspace_bytes, void* stream);
 
 /* ---- depthwise 3x3, stride 1, pad 1 (DWConv.dconv, normal_conv.py:26-27; head towers decouplehead.py:23-34)
  * w: [C][3][3] (the OIHW tensor of a groups=C conv).  flip = 1 gives the input gradient. */
