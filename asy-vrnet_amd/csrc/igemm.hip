@@ -963,7 +963,11 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   p.stats = stats;
   p.stats_nb = (int)vr_cdiv(p.CN, 32);
   p.pair_rows = pair_rows; p.w2 = w2; p.bias2 = bias2; p.res_scale2 = res_scale2; p.kscale2 = kscale2;
-  VR_CHECK_ARG(!pair_rows || (pair_rows < M && !p.perm2), "conv2d: two-stream launch with an unsupported row layout");
+  VR_CHECK_ARG(!pair_rows || (pair_rows < M && 2L * pair_rows == M), "conv2d: the two streams must have equal row counts");
+  if (pair_rows && p.perm2) {
+    if ((M / 8) % 128 == 0) p.pair_rows = (int)(M / 8);      // parity-major rows: the streams split every parity class
+    else p.perm2 = 0;
+  }
   if (pair_rows) {
     p.b_vec = p.b_vec && vr_aligned16(w2);
     p.e_vec = p.e_vec && (!bias2 || vr_aligned16(bias2)) && (!res_scale2 || vr_aligned16(res_scale2));
@@ -980,6 +984,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                  "conv2d: the bf16 path needs 16-byte aligned rows, a contraction that is a multiple of 4, more than 32 "
                  "output channels and (mode 1) the transposed weight pack with kscale folded in");
     p.perm2 = 0;
+    p.pair_rows = pair_rows;
     vr_igemm_bf16_launch(&p, mode, st);
     VR_LAUNCH_CHECK("conv2d(bf16)");
     return VR_OK;

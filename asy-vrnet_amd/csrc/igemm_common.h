@@ -33,7 +33,10 @@ struct IgemmArgs {
 // The argument block a workgroup whose first row is m0 works with: the second stream's parameters behind pair_rows.
 __device__ __forceinline__ IgemmArgs igemm_select_stream(const IgemmArgs& in, int m0) {
   IgemmArgs p = in;
-  if (in.pair_rows && m0 >= in.pair_rows) {
+  // parity-major rows (perm2): each of the 4 parity classes lists all samples in order, so the second stream is the
+  // second half of every class (pair_rows is then half a class: M / 8)
+  const int r0 = in.perm2 ? m0 % (in.M >> 2) : m0;
+  if (in.pair_rows && r0 >= in.pair_rows) {
     p.w = in.w2; p.bias = in.bias2; p.res_scale = in.res_scale2; p.kscale = in.kscale2;
   }
   return p;

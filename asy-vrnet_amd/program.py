@@ -18,8 +18,12 @@ from . import modules as M
 
 
 class Act:
-    """NHWC activation: `t` is a (B,H,W,C) tensor or channel-slice view; row stride `ld` floats."""
-    __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad", "pairs")
+    """NHWC activation: `t` is a (B,H,W,C) tensor or channel-slice view; row stride `ld` floats.
+
+    Two-stream buffers: the image and the radar stream of a backbone stage live in ONE (2B,H,W,C) tensor (image
+    samples first) so that a stage's ClusterBlocks run as one launch per layer; `half(k)` is the Act of one stream --
+    a view whose gradient is the matching half of the parent's gradient buffer (`written[k]`: that half holds data)."""
+    __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad", "pairs", "parent", "slot", "written", "_halves")
 
     def __init__(self, t, need_grad=True):
         self.t = t
@@ -28,6 +32,21 @@ class Act:
         self.ld = t.stride(2)
         self.grad = None
         self.need_grad = need_grad
+        self.parent, self.slot, self.written, self._halves = None, 0, None, None
+
+    def half(self, k):
+        if self._halves is None:
+            assert self.B % 2 == 0 and self.ld == self.C
+            n = self.B // 2
+            self._halves = []
+            for i in range(2):
+                a = Act(self.t[i * n:(i + 1) * n], self.need_grad)
+                a.parent, a.slot = self, i
+                self._halves.append(a)
+        return self._halves[k]
+
+    def halves(self):
+        return self.half(0), self.half(1)
 
     @property
     def HW(self):
@@ -59,11 +78,13 @@ class RT:
         self.det_grads, self.seg_grad = (None, None, None), None
         self._depth = 0
         self._chain = "main"        # logical chain id: "main" or (depth, branch index)
-        self._aside_pending = {}
+        self._aside_open = None     # aside work of the tape closure being replayed
+        self._aside_batches = []    # closed batches not yet joined: (events, tensors kept alive, parameters reported)
         self._deferred_wgrads = []
         self.ready = None           # with a bucketer: parameters whose gradient kernels were issued, not yet handed over
         self.tape_pos = 0           # index of the top-level tape closure being replayed
         self.concurrent = True      # fork independent chains (image / radar, seg / det, head levels) onto side streams
+        self.pair_streams = True    # image + radar chain of a backbone stage as one two-stream batch (one launch per layer)
 
     # ---- fork / join of independent chains -------------------------------------------------------------
     _side_streams = {}
@@ -82,6 +103,8 @@ class RT:
     # side streams crashes hipStreamEndCapture (tools/micro/graph_fork_probe.py).  Hence: on the main chain a weight
     # gradient forks an auxiliary stream directly; inside a forked chain it is deferred and all deferred weight
     # gradients of the section run, mutually concurrent, on the section's side streams once the chains have joined.
+    # The main-chain joins LAG by one tape closure: the weight gradients of block k run beside the data gradients of
+    # block k+1 and are joined (their operands released, their parameters reported ready) after block k+1.
     def aside(self, fn, keep):
         """`fn` launches weight / parameter-gradient kernels whose results no later backward kernel reads;
         `keep`: tensors it reads (held until it has been ordered before their release)."""
@@ -92,22 +115,46 @@ class RT:
             self._deferred_wgrads.append((fn, keep))
             return
         cur = torch.cuda.current_stream(self.device)
-        key = (self.device, "aux")
-        aux = RT._aux_streams.get(key)
-        if aux is None:
-            aux = RT._aux_streams[key] = torch.cuda.Stream(self.device)
+        pool = RT._aux_streams.setdefault(self.device, [])
+        while len(pool) < WGRAD_STREAMS:
+            pool.append(torch.cuda.Stream(self.device))
+        ent = self._aside_open
+        if ent is None:
+            ent = self._aside_open = {"streams": {}, "keep": [], "n": 0}
+        aux = pool[ent["n"] % len(pool)]
+        ent["n"] += 1
         aux.wait_stream(cur)
         with torch.cuda.stream(aux):
             fn()
-        self._aside_pending.setdefault("main", (aux, []))[1].extend(keep)
+        ent["streams"][aux] = True
+        ent["keep"].extend(keep)
 
-    def join_aside(self):
+    def join_aside(self, lag=1):
+        """End of a top-level tape closure: closes the closure's batch of aside work (events on the auxiliary streams it
+        used, the parameters it reported) and joins the batches older than `lag` closures into the current stream.
+        Returns the parameters whose gradient kernels are now ordered before the current stream."""
         if self._chain != "main":
-            return
-        ent = self._aside_pending.pop("main", None)
+            return []
+        ent, self._aside_open = self._aside_open, None
+        fresh = self.ready if self.ready is not None else []
+        if self.ready is not None:
+            self.ready = []
+        evs = []
         if ent is not None:
-            torch.cuda.current_stream(self.device).wait_stream(ent[0])
-            ent[1].clear()
+            for st in ent["streams"]:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                evs.append(ev)
+        self._aside_batches.append((evs, ent["keep"] if ent is not None else [], fresh))
+        done = []
+        cur = torch.cuda.current_stream(self.device)
+        while len(self._aside_batches) > lag:
+            evs, keep, ready = self._aside_batches.pop(0)
+            for ev in evs:
+                cur.wait_event(ev)
+            keep.clear()
+            done.extend(ready)
+        return done
 
     def _launch_deferred_wgrads(self, cur, streams):
         """Issues the pending deferred weight gradients round-robin on `streams` (already forked from `cur`)."""
@@ -245,25 +292,76 @@ class RT:
 
     def grad_target(self, act):
         """(buffer, accumulate) to write d(act) into."""
+        par = act.parent
+        if par is not None:                       # one stream of a two-stream buffer: its half of the parent's gradient
+            if par.grad is None:
+                par.grad = self.buf(par.B, par.H, par.W, par.C)
+                par.written = [False, False]
+            elif par.written is None:
+                par.written = [True, True]
+            n = act.B
+            acc = 1 if par.written[act.slot] else 0
+            par.written[act.slot] = True
+            return par.grad[act.slot * n:(act.slot + 1) * n], acc
         if act.grad is None:
             act.grad = self.buf(act.B, act.H, act.W, act.C)
+            act.written = None
             return act.grad, 0
+        _complete(act)
         return act.grad, 1
 
     def give_grad(self, act, g):
         """Hands an owned, contiguous gradient buffer to `act`."""
         if not act.need_grad:
             return
+        if act.parent is not None:
+            buf, acc = self.grad_target(act)
+            if acc:
+                hip.add_(buf, g)
+            else:
+                hip.copy_channels(g, act.C, 1, buf, act.C, 1, act.rows, act.C)
+            return
         if act.grad is None:
             act.grad = g
+            act.written = None
         else:
+            _complete(act)
             hip.add_(act.grad, g)
 
 
+def _complete(act):
+    """A two-stream gradient buffer of which only one half has been written so far: zero the other half."""
+    w = act.written
+    if w is not None:
+        n = act.B // 2
+        for k in range(2):
+            if not w[k]:
+                hip.fill_(act.grad[k * n:(k + 1) * n], 0.0)
+        act.written = None
+
+
 def take_grad(act):
+    par = act.parent
+    if par is not None:
+        if par.grad is None or (par.written is not None and not par.written[act.slot]):
+            return None
+        n = act.B
+        return par.grad[act.slot * n:(act.slot + 1) * n]
     g = act.grad
+    if g is not None:
+        _complete(act)
     act.grad = None
     return g
+
+
+def _pair(m):
+    """(first, second or None) of a module / tensor or a pair of them (two-stream launch)."""
+    return (m[0], m[1]) if isinstance(m, tuple) else (m, None)
+
+
+def _attr(ms, name):
+    a, b = _pair(ms)
+    return (getattr(a, name), getattr(b, name)) if b is not None else getattr(a, name)
 
 
 # ----------------------------------------------------------------------------------------- conv helpers
@@ -275,42 +373,74 @@ def conv_geom(x, conv):
     return co, ci, kh, kw, s, p, d, OH, OW
 
 
+def _pair_kw(rt, x, convs, w_of, bias=True, res_scale=None, kscale=None):
+    """Keyword arguments of a two-stream conv2d launch (empty for a single module): rows of the first stream and
+    the second stream's parameter set."""
+    c0, c1 = _pair(convs)
+    if c1 is None:
+        return {}
+    rs0, rs1 = _pair(res_scale) if res_scale is not None else (None, None)
+    ks0, ks1 = _pair(kscale) if kscale is not None else (None, None)
+    assert x.B % 2 == 0 and (x.B // 2) * x.H * x.W % 128 == 0
+    return dict(w2=w_of(c1), bias2=c1.bias if bias else None, res_scale2=rs1, kscale2=ks1)
+
+
 def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw=None, bias=True, stats=False):
-    """out: Act (NHWC target) or, with nchw=(tensor, ctot, coff), a channel range of an NCHW tensor."""
-    co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, conv)
-    b = conv.bias if bias else None
+    """out: Act (NHWC target) or, with nchw=(tensor, ctot, coff), a channel range of an NCHW tensor.
+    conv / res_scale may be pairs (two-stream launch over a (2B,...) input: first half of the rows = first module)."""
+    c0, c1 = _pair(conv)
+    co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, c0)
+    b = c0.bias if bias else None
     if nchw is None:
         pairs, per = hip.conv_stats_buffer(x.B, OH * OW, co, x.t.device) if stats else (None, 0)
-        hip.conv2d(x.t, x.ld, rt.weight(conv), b, out.t, out.ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
+        kw2 = {}
+        if c1 is not None:
+            kw2 = _pair_kw(rt, x, conv, rt.weight, bias, res_scale)
+            kw2["pair_rows"] = (x.B // 2) * OH * OW
+        hip.conv2d(x.t, x.ld, rt.weight(c0), b, out.t, out.ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
                    mode=0, act=act, ypre=None if ypre is None else ypre.t, ldypre=0 if ypre is None else ypre.ld,
-                   res=None if res is None else res.t, ldres=0 if res is None else res.ld, res_scale=res_scale,
-                   stats=pairs, precision=rt.prec_fwd(x.ld, ci, co))
+                   res=None if res is None else res.t, ldres=0 if res is None else res.ld,
+                   res_scale=_pair(res_scale)[0] if res_scale is not None else None,
+                   stats=pairs, precision=rt.prec_fwd(x.ld, ci, co), **kw2)
         if pairs is not None:       # statistics of the stored output: the consumer's GroupNorm skips its moments pass
             out.pairs = (pairs, per)
     else:
+        assert c1 is None
         t, ctot, coff = nchw
-        hip.conv2d(x.t, x.ld, rt.weight(conv), b, t, 0, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=0, act=act,
+        hip.conv2d(x.t, x.ld, rt.weight(c0), b, t, 0, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=0, act=act,
                    out_nchw=1, out_ctot=ctot, out_coff=coff, precision=rt.prec_fwd(x.ld, ci, co))
 
 
 def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, skip_bias=False, dx_to=None,
                   defer_ok=True):
     """Gradients of y = conv(x): weight/bias into the parameter table, dx accumulated into x.grad
-    (or written to the Act `dx_to`).  dy: tensor whose data_ptr is the (0,0) element, row stride lddy."""
-    co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, conv)
-    gw, accw = rt.pgrad(conv.weight)
-    gb, accb = (None, 0) if (conv.bias is None or skip_bias) else rt.pgrad(conv.bias)
+    (or written to the Act `dx_to`).  dy: tensor whose data_ptr is the (0,0) element, row stride lddy.
+    conv / kscale / row_scale may be pairs (two-stream launch)."""
+    c0, c1 = _pair(conv)
+    co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, c0)
+    gw, accw = rt.pgrad(c0.weight)
+    gb, accb = (None, 0) if (c0.bias is None or skip_bias) else rt.pgrad(c0.bias)
+    gw2 = gb2 = None
+    if c1 is not None:
+        gw2, accw2 = rt.pgrad(c1.weight)
+        gb2, accb2 = (None, 0) if (c1.bias is None or skip_bias) else rt.pgrad(c1.bias)
+        assert (gw is None) == (gw2 is None) and (gb is None) == (gb2 is None) and (gw is None or accw == accw2), \
+            "the two streams of a stage must be frozen / trained together"
+    rs0, rs1 = _pair(row_scale) if row_scale is not None else (None, None)
     if gw is not None or gb is not None:
         assert gb is None or gw is not None
         assert gb is None or accb == accw
 
         def wgrad():
-            hip.conv2d_wgrad(x.t, x.ld, dy, lddy, gw, gb, row_scale, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
-                             accumulate=accw, precision=rt.prec_wgrad(x.ld, lddy, ci, co))
+            hip.conv2d_wgrad(x.t, x.ld, dy, lddy, gw, gb, rs0, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
+                             accumulate=accw, precision=rt.prec_wgrad(x.ld, lddy, ci, co), dw2=gw2, dbias2=gb2,
+                             row_scale2=rs1)
             if rt.on_param_grad:
-                rt.on_param_grad(conv.weight)
-                if gb is not None:
-                    rt.on_param_grad(conv.bias)
+                for cv, g in ((c0, gb), (c1, gb2)):
+                    if cv is not None:
+                        rt.on_param_grad(cv.weight)
+                        if g is not None:
+                            rt.on_param_grad(cv.bias)
         if defer_ok:
             rt.aside(wgrad, (x.t, dy))
         else:                    # dy is updated in place later in this closure: the weight gradient must read it now
@@ -322,15 +452,21 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
         else:
             buf, acc = rt.grad_target(x)
             ld = x.C
-        wd, ks, prec = rt.dgrad_operands(conv, conv.weight, rt.weight(conv), co, ci, kh, kw, kscale, lddy)
+        ks0, ks1 = _pair(kscale) if kscale is not None else (None, None)
+        wd, ks, prec = rt.dgrad_operands(c0, c0.weight, rt.weight(c0), co, ci, kh, kw, ks0, lddy)
+        kw2 = {}
+        if c1 is not None:
+            wd1, ks1, prec1 = rt.dgrad_operands(c1, c1.weight, rt.weight(c1), co, ci, kh, kw, ks1, lddy)
+            assert prec1 == prec
+            kw2 = dict(pair_rows=(x.B // 2) * x.H * x.W, w2=wd1, kscale2=ks1)
         hip.conv2d(dy, lddy, wd, None, buf, ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=1,
                    kscale=ks, aux=None if aux is None else aux.t, ldaux=0 if aux is None else aux.ld, accumulate=acc,
-                   precision=prec)
+                   precision=prec, **kw2)
 
 
 def simple_conv(rt, x, conv, out=None):
-    """Plain conv with bias (PointRecuder.proj): recorded on the tape."""
-    co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, conv)
+    """Plain conv with bias (PointRecuder.proj): recorded on the tape.  conv may be a pair (two-stream launch)."""
+    co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, _pair(conv)[0])
     y = out if out is not None else rt.new(x.B, OH, OW, co)
     conv_call(rt, x, conv, y)
 
@@ -383,32 +519,51 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
 
 
 def gn_forward(rt, x, gn):
+    """GroupNorm(1, C); gn may be a pair of modules (two-stream launch: second half of the samples = second module)."""
+    g0, g1 = _pair(gn)
     B, HW, C = x.B, x.HW, x.C
     A, D, S, ms = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C), rt.buf(B, 2)
+    kw2 = {} if g1 is None else dict(gamma2=g1.weight, beta2=g1.bias)
     if x.pairs is not None:
-        hip.gn_coef_from_pairs(x.pairs[0], x.pairs[1], gn.weight, gn.bias, gn.eps, B, HW, C, A, D, S, ms)
+        hip.gn_coef_from_pairs(x.pairs[0], x.pairs[1], g0.weight, g0.bias, g0.eps, B, HW, C, A, D, S, ms, **kw2)
     else:
-        hip.gn_stats_fwd(x.t, x.ld, gn.weight, gn.bias, gn.eps, B, HW, C, A, D, S, ms)
+        hip.gn_stats_fwd(x.t, x.ld, g0.weight, g0.bias, g0.eps, B, HW, C, A, D, S, ms, **kw2)
     y = rt.new(x.B, x.H, x.W, C)
     hip.affine(y.t, C, B, HW, C, x1=x.t, ld1=x.ld, A=A, D1=D, S1=S, bstride=C)
     return y, ms
 
 
+def _pgrads_or_scratch(rt, params, sizes):
+    """Gradient buffers for a list of parameters (scratch where a parameter needs no gradient) and ONE accumulate flag."""
+    outs, acc = [], 0
+    for prm, n in zip(params, sizes):
+        g, a = rt.pgrad(prm)
+        if g is None:
+            g, a = rt.buf(n), 0
+        else:
+            acc = a
+        outs.append(g)
+    return outs, acc
+
+
 def gn_backward(rt, gn, x, ms, dy, out, accumulate):
     """out (+)= dx of y = GN(x) given contiguous dy."""
+    g0, g1 = _pair(gn)
     B, HW, C = x.B, x.HW, x.C
     mom2 = hip.moments(dy, C, B, HW, C, x2=x.t, ldx2=x.ld)
     A, E, D, S = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C), rt.buf(B, C)
-    gw, accw = rt.pgrad(gn.weight)
-    gb, _ = rt.pgrad(gn.bias)
-    if gw is None:
-        gw, accw = rt.buf(C), 0
-    if gb is None:
-        gb = rt.buf(C)
-    hip.gn_coef_bwd(mom2, ms, gn.weight, B, HW, C, A, E, D, S, gw, gb, accw)
+    (gw, gb), accw = _pgrads_or_scratch(rt, (g0.weight, g0.bias), (C, C))
+    kw2 = {}
+    if g1 is not None:
+        (gw2, gb2), accw2 = _pgrads_or_scratch(rt, (g1.weight, g1.bias), (C, C))
+        assert accw2 == accw
+        kw2 = dict(gamma2=g1.weight, dgamma2=gw2, dbeta2=gb2)
+    hip.gn_coef_bwd(mom2, ms, g0.weight, B, HW, C, A, E, D, S, gw, gb, accw, **kw2)
     if rt.on_param_grad:
-        rt.on_param_grad(gn.weight)
-        rt.on_param_grad(gn.bias)
+        for g in (g0, g1):
+            if g is not None:
+                rt.on_param_grad(g.weight)
+                rt.on_param_grad(g.bias)
     hip.affine(out, C, B, HW, C, x1=dy, ld1=C, A=A, x2=x.t, ld2=x.ld, E=E, D2=D, S2=S, bstride=C, accumulate=accumulate)
 
 
@@ -464,128 +619,174 @@ def ds_base_conv(rt, x, m, out=None):
 
 # ----------------------------------------------------------------------------------------- ClusterBlock
 def cluster_block(rt, x, m, name=None):
-    """ClusterBlock.forward (vr_coc.py:264-271): x + ls1*Cluster(GN(x)), then + ls2*Mlp(GN(.))."""
-    tm, mlp = m.token_mixer, m.mlp
+    """ClusterBlock.forward (vr_coc.py:264-271): x + ls1*Cluster(GN(x)), then + ls2*Mlp(GN(.)).
+    m / name may be pairs: the image and the radar block of a backbone stage (vr_coc.py:589-600) as ONE launch per
+    layer over a (2B,H,W,C) two-stream buffer, each half with its own parameters."""
+    m0, m1 = _pair(m)
+    paired = m1 is not None
+    tm, mlp = _attr(m, "token_mixer"), _attr(m, "mlp")
+    tm0, tm1 = _pair(tm)
+    mlp0 = _pair(mlp)[0]
     B, H, W, C = x.B, x.H, x.W, x.C
-    E, Dh, fold = tm.heads, tm.head_dim, tm.fold
+    E, Dh, fold = tm0.heads, tm0.head_dim, tm0.fold
     ED = E * Dh
-    xn, ms1 = gn_forward(rt, x, m.norm1)
-    wcat, bcat = tm._fused_qkv                                   # [fc1 ; fc_v]: one GEMM, f | v side by side
+    rows_half = (B // 2) * H * W
+    xn, ms1 = gn_forward(rt, x, _attr(m, "norm1"))
+    wcat, bcat = tm0._fused_qkv                                  # [fc1 ; fc_v]: one GEMM, f | v side by side
+    kwq = dict(pair_rows=rows_half, w2=tm1._fused_qkv[0], bias2=tm1._fused_qkv[1]) if paired else {}
     fv = rt.new(B, H, W, 2 * ED)
     hip.conv2d(xn.t, xn.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0,
-               precision=rt.prec_fwd(xn.ld, C, 2 * ED))
+               precision=rt.prec_fwd(xn.ld, C, 2 * ED), **kwq)
     f_t, v_t = fv.t, fv.t[..., ED:]
     o = rt.new(B, H, W, ED)
     idx = rt.buf(B, H, W, E, dtype=torch.uint8)
     big = (H // max(fold, 1)) * (W // max(fold, 1)) > 256       # streaming kernel keeps the similarity map
-    hip.cluster_fwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, o.t, ED, idx, rt.buf(B, H, W, E) if big else None,
-                    B, H, W, E, Dh, fold)
+    kwc = dict(alpha2=tm1.sim_alpha, beta2=tm1.sim_beta) if paired else {}
+    hip.cluster_fwd(f_t, v_t, 2 * ED, tm0.sim_alpha, tm0.sim_beta, o.t, ED, idx, rt.buf(B, H, W, E) if big else None,
+                    B, H, W, E, Dh, fold, **kwc)
     if name is not None:
-        rt.idx_maps[name] = idx
+        n0, n1 = _pair(name)
+        if paired:
+            rt.idx_maps[n0], rt.idx_maps[n1] = idx[:B // 2], idx[B // 2:]
+        else:
+            rt.idx_maps[n0] = idx
+    ls1, ls2 = _attr(m, "layer_scale_1"), _attr(m, "layer_scale_2")
     t1 = rt.new(B, H, W, C) if rt.record else None
     x1 = rt.new(B, H, W, C)
-    conv_call(rt, o, tm.fc2, x1, ypre=t1, res=x, res_scale=m.layer_scale_1, stats=True)
-    xn2, ms2 = gn_forward(rt, x1, m.norm2)
-    hid = mlp.fc1.weight.shape[0]
+    conv_call(rt, o, _attr(tm, "fc2"), x1, ypre=t1, res=x, res_scale=ls1, stats=True)
+    xn2, ms2 = gn_forward(rt, x1, _attr(m, "norm2"))
+    hid = mlp0.fc1.weight.shape[0]
     u = rt.new(B, H, W, hid) if rt.record else None
     h = rt.new(B, H, W, hid)
-    conv_call(rt, xn2, mlp.fc1, h, act=2, ypre=u)
+    conv_call(rt, xn2, _attr(mlp, "fc1"), h, act=2, ypre=u)
     t2 = rt.new(B, H, W, C) if rt.record else None
     x2 = rt.new(B, H, W, C)
-    conv_call(rt, h, mlp.fc2, x2, ypre=t2, res=x1, res_scale=m.layer_scale_2, stats=True)
+    conv_call(rt, h, _attr(mlp, "fc2"), x2, ypre=t2, res=x1, res_scale=ls2, stats=True)
 
     def bwd():
         dx2 = take_grad(x2)                                      # owned; becomes dx1, then dx
         if dx2 is None:
             return
         # ---- MLP branch
-        ls2 = m.layer_scale_2
         mom2 = hip.moments(dx2, C, B, H * W, C, x2=t2.t, ldx2=C)
-        _ls_grads(rt, mom2, ls2, mlp.fc2.bias, B, C)
+        _ls_grads(rt, mom2, ls2, _attr(_attr(mlp, "fc2"), "bias"), B, C)
         du = rt.new(B, H, W, hid)
-        conv_backward(rt, h, mlp.fc2, dx2, C, kscale=ls2, aux=u, row_scale=ls2, skip_bias=True, dx_to=du, defer_ok=False)
+        conv_backward(rt, h, _attr(mlp, "fc2"), dx2, C, kscale=ls2, aux=u, row_scale=ls2, skip_bias=True, dx_to=du,
+                      defer_ok=False)
         dxn2 = rt.new(B, H, W, C)
-        conv_backward(rt, xn2, mlp.fc1, du.t, hid, dx_to=dxn2)
-        gn_backward(rt, m.norm2, x1, ms2, dxn2.t, dx2, accumulate=1)          # dx2 now holds dx1
+        conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2)
+        gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx2, accumulate=1)          # dx2 now holds dx1
         # ---- Cluster branch
-        ls1 = m.layer_scale_1
         mom2 = hip.moments(dx2, C, B, H * W, C, x2=t1.t, ldx2=C)
-        _ls_grads(rt, mom2, ls1, tm.fc2.bias, B, C)
+        _ls_grads(rt, mom2, ls1, _attr(_attr(tm, "fc2"), "bias"), B, C)
         do = rt.new(B, H, W, ED)
-        conv_backward(rt, o, tm.fc2, dx2, C, kscale=ls1, row_scale=ls1, skip_bias=True, dx_to=do, defer_ok=False)
+        conv_backward(rt, o, _attr(tm, "fc2"), dx2, C, kscale=ls1, row_scale=ls1, skip_bias=True, dx_to=do, defer_ok=False)
         dfv = rt.new(B, H, W, 2 * ED)
-        ga, acca = rt.pgrad(tm.sim_alpha)
-        gb, _ = rt.pgrad(tm.sim_beta)
-        if ga is None:
-            ga, acca = rt.buf(1), 0
-        if gb is None:
-            gb = rt.buf(1)
-        hip.cluster_bwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, idx, do.t, ED, dfv.t, dfv.t[..., ED:], 2 * ED, ga, gb,
-                        acca, B, H, W, E, Dh, fold)
+        (ga, gb), acca = _pgrads_or_scratch(rt, (tm0.sim_alpha, tm0.sim_beta), (1, 1))
+        kwb = {}
+        if paired:
+            (ga2, gb2), acca2 = _pgrads_or_scratch(rt, (tm1.sim_alpha, tm1.sim_beta), (1, 1))
+            assert acca2 == acca
+            kwb = dict(alpha2=tm1.sim_alpha, beta2=tm1.sim_beta, dalpha2=ga2, dbeta2=gb2)
+        hip.cluster_bwd(f_t, v_t, 2 * ED, tm0.sim_alpha, tm0.sim_beta, idx, do.t, ED, dfv.t, dfv.t[..., ED:], 2 * ED, ga, gb,
+                        acca, B, H, W, E, Dh, fold, **kwb)
         if rt.on_param_grad:
-            rt.on_param_grad(tm.sim_alpha)
-            rt.on_param_grad(tm.sim_beta)
-        _fused_qkv_wgrad(rt, tm, xn, dfv, wcat)
+            for t in (tm0, tm1):
+                if t is not None:
+                    rt.on_param_grad(t.sim_alpha)
+                    rt.on_param_grad(t.sim_beta)
+        _fused_qkv_wgrad(rt, tm, xn, dfv)
         dxn = rt.new(B, H, W, C)                                 # d xn = [df | dv] . [fc1 ; fc_v]: one data-gradient GEMM
-        wd, _, prec = rt.dgrad_operands(tm, wcat, wcat, 2 * ED, C, 1, 1, None, 2 * ED)
-        hip.conv2d(dfv.t, 2 * ED, wd, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1, precision=prec)
-        gn_backward(rt, m.norm1, x, ms1, dxn.t, dx2, accumulate=1)             # dx2 now holds dx
+        wd, _, prec = rt.dgrad_operands(tm0, wcat, wcat, 2 * ED, C, 1, 1, None, 2 * ED)
+        kwd = {}
+        if paired:
+            wd1, _, _ = rt.dgrad_operands(tm1, tm1._fused_qkv[0], tm1._fused_qkv[0], 2 * ED, C, 1, 1, None, 2 * ED)
+            kwd = dict(pair_rows=rows_half, w2=wd1)
+        hip.conv2d(dfv.t, 2 * ED, wd, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1, precision=prec, **kwd)
+        gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx2, accumulate=1)             # dx2 now holds dx
         rt.give_grad(x, dx2)
     rt.push(bwd)
     return x2
 
 
-def _fused_qkv_wgrad(rt, tm, xn, dfv, wcat):
-    """Weight / bias gradients of fc1 and fc_v as one GEMM into a scratch [2ED, C] | [2ED], then copied (or added)
-    into the four parameter gradients; deferred off the critical path like every other weight gradient."""
-    ed, c = tm.fc1.weight.shape[0], tm.fc1.weight.shape[1]
-    targets = [(tm.fc1.weight, 0, c), (tm.fc_v.weight, ed, c), (tm.fc1.bias, 0, 1), (tm.fc_v.bias, ed, 1)]
+def _fused_qkv_wgrad(rt, tm, xn, dfv):
+    """Weight / bias gradients of fc1 and fc_v as one GEMM into [2ED, C] | [2ED] (per stream), deferred off the critical
+    path like every other weight gradient.  The GEMM writes the four parameter gradients IN PLACE when their buffers are
+    adjacent -- always without a bucketer (they are handed out as views of one buffer), and with the execution-order
+    arena of parallel.GradBucketer, where the four are reported ready back to back; otherwise (the bucketer's recording
+    pass) through a scratch matrix and four strided copies."""
+    tms = [t for t in _pair(tm) if t is not None]
+    ed, c = tms[0].fc1.weight.shape[0], tms[0].fc1.weight.shape[1]
     B, H, W = xn.B, xn.H, xn.W
-    fresh = rt.bucketer is None and all(prm.requires_grad and prm not in rt.pgrads for prm, _, _ in targets)
-    if fresh:
-        # no gradient buffer exists yet for any of the four: hand out views of one [2ED, C] | [2ED] pair, so the GEMM
-        # writes the parameter gradients in place (no scatter copies)
-        gw, gbias = rt.buf(2 * ed, c), rt.buf(2 * ed)
-        rt.pgrads[tm.fc1.weight], rt.pgrads[tm.fc_v.weight] = gw[:ed].view_as(tm.fc1.weight), gw[ed:].view_as(tm.fc_v.weight)
-        rt.pgrads[tm.fc1.bias], rt.pgrads[tm.fc_v.bias] = gbias[:ed], gbias[ed:]
-
-        def wgrad_direct():
-            hip.conv2d_wgrad(xn.t, xn.ld, dfv.t, 2 * ed, gw, gbias, None, B, H, W, c, H, W, 2 * ed, 1, 1, 1, 0, 1,
-                             precision=rt.prec_wgrad(xn.ld, 2 * ed, c, 2 * ed))
-        rt.aside(wgrad_direct, (xn.t, dfv.t))
+    plans = []
+    for t in tms:
+        prms = (t.fc1.weight, t.fc_v.weight, t.fc1.bias, t.fc_v.bias)
+        if not any(p.requires_grad for p in prms):
+            plans.append(None)
+            continue
+        fresh = rt.bucketer is None and all(p.requires_grad and p not in rt.pgrads for p in prms)
+        if fresh:
+            gw, gbias = rt.buf(2 * ed, c), rt.buf(2 * ed)
+            rt.pgrads[prms[0]], rt.pgrads[prms[1]] = gw[:ed].view_as(prms[0]), gw[ed:].view_as(prms[1])
+            rt.pgrads[prms[2]], rt.pgrads[prms[3]] = gbias[:ed], gbias[ed:]
+            plans.append((gw, gbias, 0, None))
+            continue
+        got = [rt.pgrad(p) for p in prms]
+        (g0, a0), (g1, a1), (g2, a2), (g3, a3) = got
+        adjacent = all(g is not None for g, _ in got) and a0 == a1 == a2 == a3 and \
+            g1.data_ptr() == g0.data_ptr() + 4 * g0.numel() and g3.data_ptr() == g2.data_ptr() + 4 * g2.numel()
+        if adjacent:
+            gw = torch.as_strided(g0, (2 * ed, c), (c, 1))
+            gbias = torch.as_strided(g2, (2 * ed,), (1,))
+            plans.append((gw, gbias, a0, None))
+        else:
+            plans.append((rt.buf(2 * ed, c), rt.buf(2 * ed), 0, [(p, g, a) for p, (g, a) in zip(prms, got)]))
+    if all(pl is None for pl in plans):
         return
-    grads = [(prm,) + rt.pgrad(prm) + (row0, width) for prm, row0, width in targets]
-    if all(g is None for _, g, _, _, _ in grads):
-        return
+    assert all(pl is not None for pl in plans) and len({pl[2] for pl in plans}) == 1, \
+        "the two streams of a stage must be frozen / trained together"
 
     def wgrad():
-        gw, gbias = rt.buf(2 * ed, c), rt.buf(2 * ed)
-        hip.conv2d_wgrad(xn.t, xn.ld, dfv.t, 2 * ed, gw, gbias, None, B, H, W, c, H, W, 2 * ed, 1, 1, 1, 0, 1,
-                         precision=rt.prec_wgrad(xn.ld, 2 * ed, c, 2 * ed))
-        for prm, g, acc, row0, width in grads:
-            if g is None:
-                continue
-            src = gw[row0:] if width > 1 else gbias[row0:]
-            hip.copy_channels(src, width, 1, g, width, 1, ed, width, accumulate=acc)
+        kw2 = dict(dw2=plans[1][0], dbias2=plans[1][1]) if len(plans) == 2 else {}
+        hip.conv2d_wgrad(xn.t, xn.ld, dfv.t, 2 * ed, plans[0][0], plans[0][1], None, B, H, W, c, H, W, 2 * ed, 1, 1, 1, 0, 1,
+                         accumulate=plans[0][2], precision=rt.prec_wgrad(xn.ld, 2 * ed, c, 2 * ed), **kw2)
+        for t, (gw, gbias, _, scatter) in zip(tms, plans):
+            if scatter is not None:
+                for (prm, g, acc), (src, width) in zip(scatter, ((gw, c), (gw[ed:], c), (gbias, 1), (gbias[ed:], 1))):
+                    if g is not None:
+                        hip.copy_channels(src, width, 1, g, width, 1, ed, width, accumulate=acc)
             if rt.on_param_grad:
-                rt.on_param_grad(prm)
+                for prm in (t.fc1.weight, t.fc_v.weight, t.fc1.bias, t.fc_v.bias):     # back to back: adjacent in the arena
+                    rt.on_param_grad(prm)
     rt.aside(wgrad, (xn.t, dfv.t))
 
 
 def _ls_grads(rt, mom2, ls, bias, B, C):
-    gl, accl = rt.pgrad(ls)
-    gb, accb = rt.pgrad(bias)
+    """Layer-scale and fc2-bias gradients from (sum dx, sum dx * branch) moments; ls / bias may be pairs."""
+    l0, l1 = _pair(ls)
+    b0, b1 = _pair(bias)
+    gl, accl = rt.pgrad(l0)
+    gb, accb = rt.pgrad(b0)
+    kw2 = {}
+    if l1 is not None:
+        gl2, _ = rt.pgrad(l1)
+        gb2, _ = rt.pgrad(b1)
+        assert (gl is None) == (gl2 is None) and (gb is None) == (gb2 is None)
+        kw2 = dict(pair=1, ls2=l1, dls2=gl2, dbias2=gb2)
     if gl is not None or gb is not None:
         assert gl is None or gb is None or accl == accb
-        hip.ls_coef_bwd(mom2, ls, B, C, gl, gb, accl if gl is not None else accb)
+        hip.ls_coef_bwd(mom2, l0, B, C, gl, gb, accl if gl is not None else accb, **kw2)
         if rt.on_param_grad:
-            rt.on_param_grad(ls)
-            rt.on_param_grad(bias)
+            for l, b in ((l0, b0), (l1, b1)):
+                if l is not None:
+                    rt.on_param_grad(l)
+                    rt.on_param_grad(b)
 
 
 # ----------------------------------------------------------------------------------------- fusion blocks
-def image_enhance(rt, x, r, m):
-    """ImageEnhanceByRadar.forward (vr_coc.py:312-316): BN((1 + minmax(ReLU(BN(conv3x3(r))))) * x)."""
+def image_enhance(rt, x, r, m, out=None):
+    """ImageEnhanceByRadar.forward (vr_coc.py:312-316): BN((1 + minmax(ReLU(BN(conv3x3(r))))) * x).
+    out: Act to write the result into (one stream's half of the next two-stream buffer)."""
     conv, bn1 = m.radar_projection.conv, m.radar_projection.bn
     B, H, W, C = x.B, x.H, x.W, x.C
     z = rt.new(B, H, W, C)
@@ -597,7 +798,7 @@ def image_enhance(rt, x, r, m):
     t = rt.new(B, H, W, C)
     assert x.ld == C, "image map must be contiguous"
     hip.enhance_mul(p.t, x.t, mm, t.t, n)
-    y, ms2 = bn_forward(rt, t, m.norm, relu=False)
+    y, ms2 = bn_forward(rt, t, m.norm, relu=False, out=out)
 
     def bwd():
         g = take_grad(y)
@@ -710,8 +911,8 @@ def eca(rt, x, m):
     return y
 
 
-def radar_enhance(rt, x, r, m):
-    """RadarEnhanceByImage.forward (vr_coc.py:331-359)."""
+def radar_enhance(rt, x, r, m, out=None):
+    """RadarEnhanceByImage.forward (vr_coc.py:331-359).  out: as in image_enhance."""
     a = x if m.initial else shuffle_attention(rt, x, m.image_attn)
     u = eca(rt, cat2(rt, a, r, interleave=True), m.channel_attn)
     conv, bn1 = m.inverse_projection.conv, m.inverse_projection.bn
@@ -721,7 +922,7 @@ def radar_enhance(rt, x, r, m):
     q, ms1 = bn_forward(rt, z, bn1, relu=True)
     s = rt.new(B, H, W, C)
     hip.affine(s.t, C, B, H * W, C, x1=q.t, ld1=C, x2=r.t, ld2=r.ld)
-    y, ms2 = bn_forward(rt, s, m.norm, relu=False)
+    y, ms2 = bn_forward(rt, s, m.norm, relu=False, out=out)
 
     def bwd():
         g = take_grad(y)
@@ -838,7 +1039,7 @@ def backbone_forward(rt, bb, x, r):
     if tuple(bb.fea_pos.shape[:2]) != (H, W):
         raise RuntimeError(f"input {H}x{W} does not match fea_pos {tuple(bb.fea_pos.shape[:2])}: "
                            "construct EfficientVRNet(..., img_size=(H, W))")
-    def embed(act, pe):
+    def embed(act, pe, out=None):
         """cat([x, fea_pos]) -> 4x4/s4 PointRecuder (vr_coc.py:583-586, 99-102) as patch gather + one plain GEMM:
         the concat is never materialised and the projection runs on the vector path with K = 16*(C+2)."""
         conv = pe.proj
@@ -850,7 +1051,7 @@ def backbone_forward(rt, bb, x, r):
         hip.patch_gather(act.t, act.ld, bb.fea_pos, patches.t, B, H, W, C, CP, k)   # :585 uses fea_pos for both streams
         w2 = rt.buf(co, KT)                                       # OHWI: [n][(ky,kx)][c]
         hip.weight_ohwi(conv.weight, w2, co, ci, kh, kw, 0)
-        y = rt.new(B, OH, OW, co)
+        y = out if out is not None else rt.new(B, OH, OW, co)
         hip.conv2d(patches.t, KT, w2, conv.bias, y.t, y.ld, B, OH, OW, KT, OH, OW, co, 1, 1, 1, 0, 1, mode=0,
                    precision=rt.prec_fwd(KT, KT, co))
 
@@ -881,30 +1082,54 @@ def backbone_forward(rt, bb, x, r):
         rt.push(bwd)
         return y
     xe, re_ = x, r
-    x, r = rt.parallel([lambda: embed(xe, bb.patch_embed), lambda: embed(re_, bb.patch_embed_radar)])
+    dims = [bb.network[3 * i][0].norm1.weight.shape[0] for i in range(4)]
+    # Two-stream mode (default): the image and the radar chain of every stage run as ONE batch of 2B samples in one
+    # (2B,H,W,C) buffer, image samples first -- one launch per layer with twice the tiles and per-half parameters
+    # instead of two half-filled launches on two streams (vr_coc.py:589-600 calls network[idx] / network_radar[idx]
+    # back to back on equal shapes).  model.pair_streams = False keeps the two chains on two forked streams.
     outs, outs_r = [], []
 
     def chain(act, blocks, prefix):
         for j, blk in enumerate(blocks):
             act = cluster_block(rt, act, blk, f"{prefix}.{j}.token_mixer")
         return act
+
+    def can_pair(h, w):          # rows of one stream must be whole 128-row tiles (true for every stage from 256 px at bs 2)
+        return rt.pair_streams and (B * h * w) % 128 == 0
+    xr = rt.new(2 * B, H // 4, W // 4, dims[0])                  # stage-0 input: both patch embeddings
+    xh, rh = xr.halves()
+    rt.parallel([lambda: embed(xe, bb.patch_embed, out=xh), lambda: embed(re_, bb.patch_embed_radar, out=rh)])
     for i in range(4):
-        xi, ri = x, r
-        x, r = rt.parallel([
-            lambda: chain(xi, bb.network[3 * i], f"backbone.backbone.network.{3 * i}"),
-            lambda: chain(ri, bb.network_radar[3 * i], f"backbone.backbone.network_radar.{3 * i}")])
-        x = image_enhance(rt, x, r, bb.network[3 * i + 1])
-        r = radar_enhance(rt, x, r, bb.network_radar[3 * i + 1])
+        pi, pr = f"backbone.backbone.network.{3 * i}", f"backbone.backbone.network_radar.{3 * i}"
+        if can_pair(xr.H, xr.W):
+            for j, (bi, br) in enumerate(zip(bb.network[3 * i], bb.network_radar[3 * i])):
+                xr = cluster_block(rt, xr, (bi, br), (f"{pi}.{j}.token_mixer", f"{pr}.{j}.token_mixer"))
+            xs, rs = xr.halves()
+        else:                                                    # tiny maps (test sizes): two chains on two forked streams
+            xi, ri = xr.halves()
+            xs, rs = rt.parallel([lambda: chain(xi, bb.network[3 * i], pi), lambda: chain(ri, bb.network_radar[3 * i], pr)])
+        if i < 3:                                                # fused maps go into the reducer's two-stream input
+            fused = rt.new(2 * B, xs.H, xs.W, xs.C)
+            fx, fr = fused.halves()
+        else:
+            fx = fr = None
+        x = image_enhance(rt, xs, rs, bb.network[3 * i + 1], out=fx)
+        r = radar_enhance(rt, x, rs, bb.network_radar[3 * i + 1], out=fr)
         if i in (0, 3):
             outs.append(x)
             outs_r.append(r)
         if i < 3:
-            xf, rf = x, r
-            x, r = rt.parallel([lambda: simple_conv(rt, xf, bb.network[3 * i + 2].proj),
-                                lambda: simple_conv(rt, rf, bb.network_radar[3 * i + 2].proj)])
+            ci, cr = bb.network[3 * i + 2].proj, bb.network_radar[3 * i + 2].proj
+            if can_pair(fused.H // 2, fused.W // 2):
+                xr = simple_conv(rt, fused, (ci, cr))
+            else:
+                xr = rt.new(2 * B, fused.H // 2, fused.W // 2, dims[i + 1])
+                ox, orr = xr.halves()
+                rt.parallel([lambda: simple_conv(rt, fx, ci, out=ox), lambda: simple_conv(rt, fr, cr, out=orr)])
             if i < 2:
-                outs.append(x)
-                outs_r.append(r)
+                xs, rs = xr.halves()
+                outs.append(xs)
+                outs_r.append(rs)
     return outs, outs_r
 
 
@@ -1023,6 +1248,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
     with torch.cuda.device(x.device):          # kernels launch on the inputs' device, whatever the caller's current one
         rt = RT(x.device, model.training, record)
         rt.concurrent = bool(getattr(model, "concurrent", True))
+        rt.pair_streams = bool(getattr(model, "pair_streams", True))
         rt.bf16 = str(getattr(model, "compute_dtype", "f32")).lower() in ("bf16", "bfloat16", "torch.bfloat16")
         rt.bucketer = getattr(model, "_grad_bucketer", None)
         rt.ready = [] if rt.bucketer is not None else None
@@ -1049,13 +1275,19 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
     return rt, (xa, ra), dets, seg
 
 
-def _drain_ready(rt):
-    """Hands the parameters whose gradient kernels have been issued AND joined into the current stream to the
-    bucketer (which may start a bucket's all-reduce: it must be ordered behind those kernels)."""
-    if rt.ready:
-        done, rt.ready[:] = list(rt.ready), []
-        for prm in done:
-            rt.bucketer.mark_ready(prm, rt.tape_pos)
+def _mark_ready(rt, params, pos):
+    """Hands parameters whose gradient kernels are ordered before the current stream to the bucketer (which may start
+    a bucket's all-reduce behind them)."""
+    if rt.bucketer is not None:
+        for prm in params:
+            rt.bucketer.mark_ready(prm, pos)
+
+
+def _take_ready(rt):
+    if not rt.ready:
+        return []
+    done, rt.ready = rt.ready, []
+    return done
 
 
 def backward_begin(rt, gdets, gseg):
@@ -1066,25 +1298,28 @@ def backward_begin(rt, gdets, gseg):
 
 
 def backward_range(rt, lo, hi, flush_each=False):
-    """Replays tape closures hi-1 ... lo (the backward of forward sections lo ... hi-1).  flush_each: the deferred
-    weight gradients are issued after every closure (the bucketer's recording pass: a parameter is then attributed
+    """Replays tape closures hi-1 ... lo (the backward of forward sections lo ... hi-1).  flush_each: every weight
+    gradient is issued and joined after each closure (the bucketer's recording pass: a parameter is then attributed
     to the closure a cut could be placed behind)."""
     with torch.cuda.device(rt.device):
         for i in range(hi - 1, lo - 1, -1):
             rt.tape_pos = i
             rt.tape[i]()
-            rt.join_aside()
+            done = rt.join_aside(0 if flush_each else 1)
             if flush_each:
                 rt.flush_deferred_wgrads()
-            _drain_ready(rt)
+                done += _take_ready(rt)
+            _mark_ready(rt, done, i)
 
 
 def backward_cut(rt):
     """Every gradient kernel issued so far is ordered before whatever the current stream runs next (joins the
     side streams): the point where a captured segment ends / a bucket's collective may start."""
     with torch.cuda.device(rt.device):
+        done = rt.join_aside(0)
         rt.flush_deferred_wgrads()
-        _drain_ready(rt)
+        done += _take_ready(rt)
+        _mark_ready(rt, done, rt.tape_pos)
 
 
 def backward_end(rt, model, inputs, needs, params=None, needs_params=None):

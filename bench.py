@@ -219,6 +219,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 (headline metric, BASELINE configs[1]) or bf16-operand dense convs (configs[2..4])")
     ap.add_argument("--serial", action="store_true", help="one stream: no concurrent chains (diagnostic)")
+    ap.add_argument("--no-pair", action="store_true",
+                    help="image and radar chain of a stage as two launches on two streams instead of one two-stream launch (diagnostic)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     args = ap.parse_args()
 
@@ -257,6 +259,8 @@ def main():
     model.compute_dtype = args.dtype
     if args.serial:
         model.concurrent = False
+    if args.no_pair:
+        model.pair_streams = False
     net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 

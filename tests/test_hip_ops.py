@@ -576,3 +576,173 @@ def test_wgrad_bf16_operands(hip, case):
     close(db, bias.grad, tol=1e-5, what="bf16 wgrad db")
     hip.conv2d_wgrad(nhwc(x), Ci, nhwc(g), Co, dw, db, None, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, accumulate=1, precision=1)
     close(dw, 2 * dw_ref, tol=3e-5, what="bf16 wgrad accumulate")
+
+
+# ---- two-stream launches (image + radar chain of a backbone stage as one batch, vr_coc.py:589-600): every entry point
+# ---- with a second parameter set must equal two single launches on the two halves of the batch
+PAIR_CONV_CASES = [
+    # B (both streams), H, W, Cin, Cout, k, s, p
+    (4, 8, 8, 64, 128, 1, 1, 0),      # 128 rows per stream: LDS-DMA kernel
+    (4, 16, 16, 48, 96, 1, 1, 0),
+    (8, 32, 32, 64, 64, 1, 1, 0),     # 4096 rows per stream
+    (16, 32, 32, 32, 48, 1, 1, 0),    # M = 16384, short K: register-staged kernel
+    (4, 16, 16, 32, 64, 3, 2, 1),     # the stage reducers (3x3 / s2): parity-major data gradient
+    (8, 32, 32, 64, 96, 3, 2, 1),
+    (4, 16, 16, 40, 24, 1, 1, 0),     # <= 32 output channels
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CONV_CASES)
+@pytest.mark.parametrize("precision", [0, 1])
+def test_two_stream_conv(hip, case, precision):
+    B, H, W, Ci, Co, k, s, p = case
+    if precision == 1 and not (hip.bf16_conv_ok(Ci, Ci, Co, 0) and hip.bf16_conv_ok(Co, Ci, Co, 1) and hip.bf16_wgrad_ok(Ci, Co, Ci, Co)):
+        pytest.skip("shape not on the bf16 path")
+    Bh = B // 2
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = nhwc(rnd(B, Ci, H, W, seed=1))
+    ws = [rnd(Co, Ci, k, k, seed=2 + i) / np.sqrt(Ci * k * k) for i in range(2)]
+    wp = [pack(hip, w) for w in ws]
+    bs = [rnd(Co, seed=4 + i).cuda() for i in range(2)]
+    ls = [rnd(Co, seed=6 + i).cuda() for i in range(2)]
+    res = nhwc(rnd(B, Co, OH, OW, seed=8))
+    y, ypre = torch.empty(B, OH, OW, Co, device="cuda"), torch.empty(B, OH, OW, Co, device="cuda")
+    stats_ok = precision == 0 and (OH * OW) % 32 == 0 and Co > 32 and Co % 4 == 0
+    st, per = hip.conv_stats_buffer(B, OH * OW, Co, x.device) if stats_ok else (None, 0)
+    hip.conv2d(x, Ci, wp[0], bs[0], y, Co, B, H, W, Ci, OH, OW, Co, k, k, s, p, 1, act=2, ypre=ypre, ldypre=Co, res=res,
+               ldres=Co, res_scale=ls[0], stats=st, precision=precision, pair_rows=Bh * OH * OW, w2=wp[1], bias2=bs[1],
+               res_scale2=ls[1])
+    for i in range(2):
+        sl = slice(i * Bh, (i + 1) * Bh)
+        yr, pr = torch.empty(Bh, OH, OW, Co, device="cuda"), torch.empty(Bh, OH, OW, Co, device="cuda")
+        hip.conv2d(x[sl], Ci, wp[i], bs[i], yr, Co, Bh, H, W, Ci, OH, OW, Co, k, k, s, p, 1, act=2, ypre=pr, ldypre=Co,
+                   res=res[sl], ldres=Co, res_scale=ls[i], precision=precision)
+        close(y[sl], yr, 1e-5, what=f"pair fwd stream {i}")
+        close(ypre[sl], pr, 1e-5, what=f"pair ypre stream {i}")
+    if st is not None:
+        tot = st.view(B, -1, 2).sum(1).cpu()
+        ref = torch.stack([y.double().sum((1, 2, 3)), (y.double() ** 2).sum((1, 2, 3))], 1).cpu()
+        close(tot, ref, 1e-6, what="pair stats")
+    # data gradient with contraction scale
+    g = nhwc(rnd(B, Co, OH, OW, seed=9))
+    wt = wp
+    ks = ls
+    if precision == 1:
+        wt = []
+        for i in range(2):
+            t = torch.empty(k * k, Ci, Co, device="cuda")
+            hip.pack_weight_t(ws[i].cuda(), ls[i], t, Co, Ci, k, k)
+            wt.append(t)
+        ks = [None, None]
+    dx = torch.empty(B, H, W, Ci, device="cuda")
+    hip.conv2d(g, Co, wt[0], None, dx, Ci, B, H, W, Ci, OH, OW, Co, k, k, s, p, 1, mode=1, kscale=ks[0], precision=precision,
+               pair_rows=Bh * H * W, w2=wt[1], kscale2=ks[1])
+    for i in range(2):
+        sl = slice(i * Bh, (i + 1) * Bh)
+        dr = torch.empty(Bh, H, W, Ci, device="cuda")
+        hip.conv2d(g[sl], Co, wt[i], None, dr, Ci, Bh, H, W, Ci, OH, OW, Co, k, k, s, p, 1, mode=1, kscale=ks[i],
+                   precision=precision)
+        close(dx[sl], dr, 1e-5, what=f"pair dgrad stream {i}")
+    # weight / bias gradient with row scale, then accumulate
+    dws = [torch.empty(Co, Ci, k, k, device="cuda") for _ in range(2)]
+    dbs = [torch.empty(Co, device="cuda") for _ in range(2)]
+    hip.conv2d_wgrad(x, Ci, g, Co, dws[0], dbs[0], ls[0], B, H, W, Ci, OH, OW, Co, k, k, s, p, 1, precision=precision,
+                     dw2=dws[1], dbias2=dbs[1], row_scale2=ls[1])
+    for i in range(2):
+        sl = slice(i * Bh, (i + 1) * Bh)
+        dwr, dbr = torch.empty(Co, Ci, k, k, device="cuda"), torch.empty(Co, device="cuda")
+        hip.conv2d_wgrad(x[sl], Ci, g[sl], Co, dwr, dbr, ls[i], Bh, H, W, Ci, OH, OW, Co, k, k, s, p, 1, precision=precision)
+        close(dws[i], dwr, 1e-5, what=f"pair wgrad stream {i}")
+        close(dbs[i], dbr, 1e-5, what=f"pair bgrad stream {i}")
+    keep = [d.clone() for d in dws]
+    hip.conv2d_wgrad(x, Ci, g, Co, dws[0], dbs[0], ls[0], B, H, W, Ci, OH, OW, Co, k, k, s, p, 1, accumulate=1,
+                     precision=precision, dw2=dws[1], dbias2=dbs[1], row_scale2=ls[1])
+    for i in range(2):
+        close(dws[i], 2 * keep[i], 1e-5, what=f"pair wgrad accumulate stream {i}")
+
+
+def test_two_stream_conv_rejects_bad_arguments(hip):
+    x = torch.zeros(4, 8, 8, 64, device="cuda")
+    w = torch.zeros(64, 64, device="cuda")
+    y = torch.empty(4, 8, 8, 64, device="cuda")
+    with pytest.raises(RuntimeError, match="two-stream"):
+        hip.conv2d(x, 64, w, None, y, 64, 4, 8, 8, 64, 8, 8, 64, 1, 1, 1, 0, 1, pair_rows=128)          # no second set
+    with pytest.raises(RuntimeError, match="two-stream"):
+        hip.conv2d(x, 64, w, None, y, 64, 4, 8, 8, 64, 8, 8, 64, 1, 1, 1, 0, 1, pair_rows=100, w2=w)    # not whole tiles
+    with pytest.raises(RuntimeError, match="equal row counts"):
+        hip.conv2d(x, 64, w, None, y, 64, 4, 8, 8, 64, 8, 8, 64, 1, 1, 1, 0, 1, pair_rows=256, w2=w)    # M = 256: nothing left
+
+
+@pytest.mark.parametrize("case", [(4, 4, 32, 32, 32, 2), (2, 8, 32, 16, 16, 1), (2, 4, 24, 64, 64, 2), (4, 4, 24, 16, 16, 2)])
+def test_two_stream_cluster(hip, case):
+    B, E, D, H, W, fold = case
+    Bh = B // 2
+    f, v, g = nhwc(rnd(B, E * D, H, W, seed=1)), nhwc(rnd(B, E * D, H, W, seed=2)), nhwc(rnd(B, E * D, H, W, seed=3))
+    al = [torch.tensor([1.3], device="cuda"), torch.tensor([0.7], device="cuda")]
+    be = [torch.tensor([-0.2], device="cuda"), torch.tensor([0.3], device="cuda")]
+    out = torch.empty(B, H, W, E * D, device="cuda")
+    idx = torch.empty(B, H, W, E, dtype=torch.uint8, device="cuda")
+    wgt = torch.empty(B, H, W, E, device="cuda")
+    hip.cluster_fwd(f, v, E * D, al[0], be[0], out, E * D, idx, wgt, B, H, W, E, D, fold, alpha2=al[1], beta2=be[1])
+    df, dv = torch.empty_like(f), torch.empty_like(v)
+    dab = torch.zeros(4, device="cuda")
+    hip.cluster_bwd(f, v, E * D, al[0], be[0], idx, g, E * D, df, dv, E * D, dab[0:1], dab[1:2], 0, B, H, W, E, D, fold,
+                    alpha2=al[1], beta2=be[1], dalpha2=dab[2:3], dbeta2=dab[3:4])
+    for i in range(2):
+        sl = slice(i * Bh, (i + 1) * Bh)
+        o1 = torch.empty(Bh, H, W, E * D, device="cuda")
+        i1 = torch.empty(Bh, H, W, E, dtype=torch.uint8, device="cuda")
+        w1 = torch.empty(Bh, H, W, E, device="cuda")
+        hip.cluster_fwd(f[sl], v[sl], E * D, al[i], be[i], o1, E * D, i1, w1, Bh, H, W, E, D, fold)
+        assert torch.equal(out[sl], o1) and torch.equal(idx[sl], i1)
+        df1, dv1 = torch.empty_like(o1), torch.empty_like(o1)
+        d1 = torch.zeros(2, device="cuda")
+        hip.cluster_bwd(f[sl], v[sl], E * D, al[i], be[i], i1, g[sl], E * D, df1, dv1, E * D, d1[0:1], d1[1:2], 0, Bh, H, W,
+                        E, D, fold)
+        assert torch.equal(df[sl], df1) and torch.equal(dv[sl], dv1)
+        close(dab[2 * i:2 * i + 2], d1, 1e-6, what=f"pair dalpha/dbeta stream {i}")
+
+
+def test_two_stream_group_norm_and_layer_scale(hip):
+    B, H, W, C = 4, 16, 16, 64
+    Bh, HW = B // 2, H * W
+    x, dy = nhwc(rnd(B, C, H, W, seed=1) * 2 + 0.5), nhwc(rnd(B, C, H, W, seed=2))
+    gam = [rnd(C, seed=3 + i).cuda() for i in range(2)]
+    bet = [rnd(C, seed=5 + i).cuda() for i in range(2)]
+
+    def bufs(b):
+        return [torch.empty(b, C, device="cuda") for _ in range(3)] + [torch.empty(b, 2, device="cuda")]
+    A, D, S, ms = bufs(B)
+    hip.gn_stats_fwd(x, C, gam[0], bet[0], 1e-5, B, HW, C, A, D, S, ms, gamma2=gam[1], beta2=bet[1])
+    mom2 = hip.moments(dy, C, B, HW, C, x2=x, ldx2=C)
+    A2, E2, D2, S2 = [torch.empty(B, C, device="cuda") for _ in range(4)]
+    dg = [torch.empty(C, device="cuda") for _ in range(4)]
+    hip.gn_coef_bwd(mom2, ms, gam[0], B, HW, C, A2, E2, D2, S2, dg[0], dg[1], 0, gamma2=gam[1], dgamma2=dg[2], dbeta2=dg[3])
+    dl = [torch.empty(C, device="cuda") for _ in range(4)]
+    hip.ls_coef_bwd(mom2, gam[0], B, C, dl[0], dl[1], 0, pair=1, ls2=gam[1], dls2=dl[2], dbias2=dl[3])
+    for i in range(2):
+        sl = slice(i * Bh, (i + 1) * Bh)
+        A1, D1, S1, ms1 = bufs(Bh)
+        hip.gn_stats_fwd(x[sl], C, gam[i], bet[i], 1e-5, Bh, HW, C, A1, D1, S1, ms1)
+        assert torch.equal(A[sl], A1) and torch.equal(D[sl], D1) and torch.equal(S[sl], S1) and torch.equal(ms[sl], ms1)
+        m1 = hip.moments(dy[sl], C, Bh, HW, C, x2=x[sl], ldx2=C)
+        a, e, d, s_ = [torch.empty(Bh, C, device="cuda") for _ in range(4)]
+        g1, b1 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        hip.gn_coef_bwd(m1, ms1, gam[i], Bh, HW, C, a, e, d, s_, g1, b1, 0)
+        assert torch.equal(A2[sl], a) and torch.equal(E2[sl], e) and torch.equal(D2[sl], d)
+        assert torch.equal(dg[2 * i], g1) and torch.equal(dg[2 * i + 1], b1)
+        l1, lb1 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        hip.ls_coef_bwd(m1, gam[i], Bh, C, l1, lb1, 0)
+        assert torch.equal(dl[2 * i], l1) and torch.equal(dl[2 * i + 1], lb1)
+
+
+def test_wrappers_reject_host_and_strided_tensors(hip):
+    """The per-op wrappers validate every tensor argument: no CPU tensor, wrong dtype or
+    element-strided view reaches a kernel as a raw pointer."""
+    g = torch.zeros(2, 4, 4, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="HIP device"):
+        hip.add_(g, torch.zeros(2, 4, 4, 8))
+    with pytest.raises(RuntimeError, match="unsupported dtype"):
+        hip.add_(g, g.half())
+    with pytest.raises(RuntimeError, match="innermost dimension"):
+        hip.add_(g[..., ::2], g[..., ::2])
