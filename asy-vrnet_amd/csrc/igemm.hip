@@ -309,6 +309,17 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
   if (mt >= MT) return;
   const int m0 = mt * BM, n0 = nt * BN;
   const IgemmArgs p = igemm_select_stream(p_in, m0);
+#ifdef VR_IGEMM_STAMP2
+  // diagnostic build: per-workgroup timeline [start, first stage landed, main loop done, epilogue done, HW id]
+  unsigned long long* wg_stamp = reinterpret_cast<unsigned long long*>(p_in.stats) + 8 * (long)blockIdx.x;
+  if (tid == 0) {
+    wg_stamp[0] = __builtin_amdgcn_s_memtime();
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    wg_stamp[4] = hw;
+    wg_stamp[5] = __builtin_readcyclecounter();
+  }
+#endif
   const int nkb = (p.CK + BK - 1) / BK;
   const int TAPS = p.kh * p.kw;
 
@@ -488,6 +499,9 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef VR_IGEMM_STAMP2
+    if (tid == 0 && s == 0) wg_stamp[1] = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef VR_IGEMM_STAMP
     if (blockIdx.x == 8 && tid == 0 && s < 64) stamp[4 * s + 0] = __builtin_amdgcn_s_memtime();
 #endif
@@ -550,6 +564,17 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     if (++kb == nkb) kb = 0;
   }
   __syncthreads();
+#ifdef VR_IGEMM_STAMP2
+  if (tid == 0) wg_stamp[2] = __builtin_amdgcn_s_memtime();
+  {
+    IgemmArgs q = p;
+    q.stats = nullptr;
+    igemm_epilogue<T, T, 2, 2>(q, acc, smem, m0, n0);
+  }
+  __syncthreads();
+  if (tid == 0) wg_stamp[3] = __builtin_amdgcn_s_memtime();
+  return;
+#endif
 #ifdef VR_IGEMM_STAMP
   IgemmArgs q = p;            // the stats pointer carries the stamps in this build
   q.stats = nullptr;
@@ -880,6 +905,43 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, co
   }
 }
 
+// Layer-scale gradient from the weight-gradient slabs of the branch's last 1x1 conv (vr_coc.py:266-271: x + ls * t,
+// t = W h + b):  dls[n] = sum_m dy[m,n] t[m,n] = sum_c W[n,c] * (sum_m dy[m,n] h[m,c]) + b[n] * sum_m dy[m,n]
+//                       = rowdot(W[n,:], dW_raw[n,:]) + b[n] * db_raw[n]
+// -- the branch output t never has to be stored for the backward pass and no pass over (dy, t) is needed.
+// One workgroup per output channel; fixed reduction order.
+__global__ __launch_bounds__(256) void wgrad_rowdot_kernel(const float* slab, const float* bslab, const float* w,
+                                                           const float* bias, float* dls, int S, int Cout, int Cin,
+                                                           int accumulate, const float* w2, const float* bias2, float* dls2) {
+  __shared__ double red[4];
+  const long per = (long)Cout * Cin;
+  if (blockIdx.y) {
+    slab += (long)S * per;
+    if (bslab) bslab += (long)S * Cout;
+    w = w2; bias = bias2; dls = dls2;
+  }
+  const int n = blockIdx.x;
+  double acc = 0.0;
+  for (int c = threadIdx.x; c < Cin; c += 256) {
+    const float wv = w[(long)n * Cin + c];
+    float sum = 0.f;
+    for (int k = 0; k < S; ++k) sum += slab[(long)k * per + (long)n * Cin + c];
+    acc += (double)sum * (double)wv;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = red[0] + red[1] + red[2] + red[3];
+    if (bias && bslab) {
+      float sb = 0.f;
+      for (int k = 0; k < S; ++k) sb += bslab[(long)k * Cout + n];
+      tot += (double)bias[n] * (double)sb;
+    }
+    dls[n] = (accumulate ? dls[n] : 0.f) + (float)tot;
+  }
+}
+
 __global__ void pack_weight_kernel(const float* w, float* out, int Cout, int Cin, int T) {
   const long total = (long)T * Cout * Cin;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -972,9 +1034,11 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
     p.b_vec = p.b_vec && vr_aligned16(w2);
     p.e_vec = p.e_vec && (!bias2 || vr_aligned16(bias2)) && (!res_scale2 || vr_aligned16(res_scale2));
   }
+#ifndef VR_IGEMM_STAMP2
   VR_CHECK_ARG(!stats || (p.e_vec && !p.perm2 && mode == 0 && ((long)p.MH * p.MW) % 32 == 0 && p.CN > 32),
                "conv2d: output statistics need the vector epilogue, a forward conv, > 32 output channels and a map of a "
                "multiple of 32 pixels");
+#endif
   dim3 block(256);
   hipStream_t st = vr_stream(stream);
   if (precision == 1) {
@@ -1127,7 +1191,9 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
                                       const float* row_scale, int B, int H, int W, int Cin, int OH, int OW,
                                       int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
                                       int precision, float* dw2, float* dbias2, const float* row_scale2,
-                                      void* workspace, long workspace_bytes, void* stream) {
+                                      const float* w, const float* bias, float* dls, const float* w2,
+                                      const float* bias2, float* dls2, void* workspace, long workspace_bytes,
+                                      void* stream) {
   VR_CHECK_ARG(x && dy && dw && workspace, "conv2d_wgrad: null tensor");
   const long M = (long)B * OH * OW;
   VR_CHECK_ARG(M < (1L << 31) && (long)B * H * W < (1L << 31), "conv2d_wgrad: too many pixels");
@@ -1135,6 +1201,9 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   VR_CHECK_ARG(streams == 1 || (B % 2 == 0 && (!dbias == !dbias2) && (!row_scale == !row_scale2)),
                "conv2d_wgrad: a two-stream launch needs an even batch and the second set of outputs");
   const int T = kh * kw;
+  VR_CHECK_ARG(!dls || (w && T == 1 && (!bias || dbias) && (streams == 1 || (w2 && dls2 && (!bias == !bias2)))),
+               "conv2d_wgrad: the layer-scale gradient needs a 1x1 conv, its weights, (with a bias) the bias gradient, "
+               "and in a two-stream launch the second set");
   int cfg, bn, nt, ct, S, rows;
   wgrad_plan(M / streams, Cin, Cout, T, &cfg, &bn, &nt, &ct, &S, &rows, precision == 1);
   const long need = vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw, streams == 2);
@@ -1204,6 +1273,11 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   }
 #undef VR_WREDUCE
   VR_LAUNCH_CHECK("conv2d_wgrad_reduce");
+  if (dls) {
+    hipLaunchKernelGGL(wgrad_rowdot_kernel, dim3(Cout, streams), dim3(256), 0, st, p.slab, p.bslab, w, bias, dls, S, Cout,
+                       Cin, accumulate, w2, bias2, dls2);
+    VR_LAUNCH_CHECK("conv2d_wgrad_rowdot");
+  }
   return VR_OK;
 }
 

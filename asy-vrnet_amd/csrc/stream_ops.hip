@@ -139,6 +139,7 @@ struct AffineArgs {
   const float* x2; long ld2; const float* E; const float* D2; const float* S2;
   float* out; long ldo;
   long HW; int C; long bstride; int pre; int accumulate;
+  const float* add; long ldadd;      // plain addend (out-of-place accumulate); accumulate = 1 is add == out
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -156,7 +157,7 @@ __device__ __forceinline__ void affine_one(const AffineArgs& p, long row, long c
     if (p.x2) x2 = ld4(p.x2 + row * p.ld2 + c);
     if (p.pre == 2) mk = ld4(p.masky + row * p.ldm + c);
     float* o = p.out + row * p.ldo + c;
-    if (p.accumulate) acc = ld4(o);
+    if (p.add) acc = ld4(p.add + row * p.ldadd + c);
     if (p.x1) v += (p.A ? ld4(p.A + cb + c) : one) * (a - (p.S1 ? ld4(p.S1 + cb + c) : zero));
     if (p.pre == 1) {
 #pragma unroll
@@ -168,7 +169,7 @@ __device__ __forceinline__ void affine_one(const AffineArgs& p, long row, long c
     }
     if (p.x2) v += (p.E ? ld4(p.E + cb + c) : one) * (x2 - (p.S2 ? ld4(p.S2 + cb + c) : zero));
     if (p.D2) v += ld4(p.D2 + cb + c);
-    if (p.accumulate) v += acc;
+    if (p.add) v += acc;
     *reinterpret_cast<f32x4*>(o) = v;
   } else {
     float v = p.D1 ? p.D1[cb + c] : 0.f;
@@ -178,7 +179,7 @@ __device__ __forceinline__ void affine_one(const AffineArgs& p, long row, long c
     if (p.x2) v += (p.E ? p.E[cb + c] : 1.f) * (p.x2[row * p.ld2 + c] - (p.S2 ? p.S2[cb + c] : 0.f));
     if (p.D2) v += p.D2[cb + c];
     float* o = p.out + row * p.ldo + c;
-    if (p.accumulate) v += o[0];
+    if (p.add) v += p.add[row * p.ldadd + c];
     o[0] = v;
   }
 }
@@ -618,14 +619,17 @@ extern "C" int vrnet_gn_stats_fwd(const float* x, long ldx, const float* gamma, 
 extern "C" int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1, const float* S1, int pre,
                                 const float* masky, long ldm, const float* x2, long ld2, const float* E,
                                 const float* D2, const float* S2, long coef_bstride, float* out, long ldo, int B,
-                                long HW, int C, int accumulate, void* stream) {
+                                long HW, int C, int accumulate, const float* add, long ldadd, void* stream) {
   VR_CHECK_ARG(out && B > 0 && HW > 0 && C > 0, "affine: bad arguments");
   VR_CHECK_ARG(pre != 2 || masky, "affine: mask mode without mask tensor");
-  AffineArgs p{x1, ld1, A, D1, S1, masky, ldm, x2, ld2, E, D2, S2, out, ldo, HW, C, coef_bstride, pre, accumulate};
+  VR_CHECK_ARG(!(accumulate && add), "affine: accumulate (in place) and add (out of place) are exclusive");
+  if (accumulate) { add = out; ldadd = ldo; }
+  AffineArgs p{x1, ld1, A, D1, S1, masky, ldm, x2, ld2, E, D2, S2, out, ldo, HW, C, coef_bstride, pre, accumulate, add, ldadd};
   bool vec = (C % 4 == 0) && (ldo % 4 == 0) && vr_aligned16(out) && (coef_bstride % 4 == 0);
   if (x1) vec = vec && (ld1 % 4 == 0) && vr_aligned16(x1);
   if (x2) vec = vec && (ld2 % 4 == 0) && vr_aligned16(x2);
   if (pre == 2) vec = vec && (ldm % 4 == 0) && vr_aligned16(masky);
+  if (add) vec = vec && (ldadd % 4 == 0) && vr_aligned16(add);
   for (const float* c : {A, D1, S1, E, D2, S2}) vec = vec && (!c || vr_aligned16(c));
   long blocks = vr_cdiv(HW * (C / (vec ? 4 : 1)), 256 * 4);
   if (blocks < 1) blocks = 1;

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvrnet_hip.so")
+LIB_PATH = os.environ.get("VRNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libvrnet_hip.so")   # override: diagnostic builds only
 ABI_VERSION = 3
 
 if not os.path.exists(LIB_PATH):
@@ -28,11 +28,11 @@ _SIGS = {
     "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
     "vrnet_conv2d_wgrad_workspace": ([I] * 8, L),
-    "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 14 + [P, P, P, P, L, P], I),
+    "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 14 + [P, P, P, P, P, P, P, P, P, P, L, P], I),
     "vrnet_pack_weight_f32": ([P, P, I, I, I, I, P], I),
     "vrnet_moments_workspace": ([I, L, I], L),
     "vrnet_moments_f32": ([P, L, P, L, P, L, I, L, I, P, P, L, P], I),
-    "vrnet_affine_f32": ([P, L, P, P, P, I, P, L, P, L, P, P, P, L, P, L, I, L, I, I, P], I),
+    "vrnet_affine_f32": ([P, L, P, P, P, I, P, L, P, L, P, P, P, L, P, L, I, L, I, I, P, L, P], I),
     "vrnet_gn_coef_fwd": ([P, P, P, F, I, L, I, P, P, P, P, P], I),
     "vrnet_gn_coef_from_pairs": ([P, L, P, P, F, I, L, I, P, P, P, P, P, P, P], I),
     "vrnet_gn_stats_fwd": ([P, L, P, P, F, I, L, I, P, P, P, P, P, P, P, L, P], I),
@@ -176,13 +176,16 @@ def conv_stats_buffer(B, HW, Cout, device):
 
 
 def conv2d_wgrad(x, ldx, dy, lddy, dw, dbias, row_scale, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil,
-                 accumulate=0, precision=0, dw2=None, dbias2=None, row_scale2=None):
-    """dw2 given: two-stream launch, samples [B/2, B) contribute to (dw2, dbias2, row_scale2)."""
+                 accumulate=0, precision=0, dw2=None, dbias2=None, row_scale2=None, w=None, bias=None, dls=None,
+                 w2=None, bias2=None, dls2=None):
+    """dw2 given: two-stream launch, samples [B/2, B) contribute to (dw2, dbias2, row_scale2).
+    dls given (1x1 convs): layer-scale gradient rowdot(w, dw_raw) + bias * db_raw."""
     nbytes = _lib.vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw, 1 if dw2 is not None else 0)
     ws = _ws.get(nbytes, x.device)
     _check(_lib.vrnet_conv2d_wgrad_f32(ptr(x), ldx, ptr(dy), lddy, ptr(dw), ptr(dbias), ptr(row_scale), B, H, W, Cin,
                                        OH, OW, Cout, kh, kw, stride, pad, dil, accumulate, precision, ptr(dw2),
-                                       ptr(dbias2), ptr(row_scale2), ptr(ws), ws.numel(), stream()), "conv2d_wgrad")
+                                       ptr(dbias2), ptr(row_scale2), ptr(w), ptr(bias), ptr(dls), ptr(w2), ptr(bias2),
+                                       ptr(dls2), ptr(ws), ws.numel(), stream()), "conv2d_wgrad")
 
 
 def bf16_wgrad_ok(ldx, lddy, Cin, Cout):
@@ -203,9 +206,11 @@ def moments(x, ldx, B, HW, C, x2=None, ldx2=0, mask=None, ldm=0, out=None):
 
 
 def affine(out, ldo, B, HW, C, x1=None, ld1=0, A=None, D1=None, pre=0, masky=None, ldm=0, x2=None, ld2=0, E=None,
-           D2=None, bstride=0, accumulate=0, S1=None, S2=None):
+           D2=None, bstride=0, accumulate=0, S1=None, S2=None, add=None, ldadd=0):
+    """out = pre(A*(x1-S1)+D1) + E*(x2-S2) + D2 [+ out (accumulate=1) | + add (out of place)]."""
     _check(_lib.vrnet_affine_f32(ptr(x1), ld1, ptr(A), ptr(D1), ptr(S1), pre, ptr(masky), ldm, ptr(x2), ld2, ptr(E),
-                                 ptr(D2), ptr(S2), bstride, ptr(out), ldo, B, HW, C, accumulate, stream()), "affine")
+                                 ptr(D2), ptr(S2), bstride, ptr(out), ldo, B, HW, C, accumulate, ptr(add), ldadd, stream()),
+           "affine")
 
 
 def gn_coef_fwd(mom, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd):

@@ -57,7 +57,7 @@ class Act:
         return self.B * self.H * self.W
 
 
-WGRAD_STREAMS = int(os.environ.get("VRNET_WGRAD_STREAMS", "4"))   # side streams for deferred weight gradients
+WGRAD_STREAMS = int(os.environ.get("VRNET_WGRAD_STREAMS", "2"))   # side streams for weight gradients (measured: 2 < 1 < 4 ms/step)
 
 
 class RT:
@@ -412,10 +412,11 @@ def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw
 
 
 def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, skip_bias=False, dx_to=None,
-                  defer_ok=True):
+                  defer_ok=True, ls_grad=None):
     """Gradients of y = conv(x): weight/bias into the parameter table, dx accumulated into x.grad
     (or written to the Act `dx_to`).  dy: tensor whose data_ptr is the (0,0) element, row stride lddy.
-    conv / kscale / row_scale may be pairs (two-stream launch)."""
+    conv / kscale / row_scale / ls_grad may be pairs (two-stream launch).  ls_grad: the layer-scale parameter(s) behind
+    this (1x1) conv: their gradient comes out of the weight-gradient slabs (hip.conv2d_wgrad, dls)."""
     c0, c1 = _pair(conv)
     co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, c0)
     gw, accw = rt.pgrad(c0.weight)
@@ -427,6 +428,18 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
         assert (gw is None) == (gw2 is None) and (gb is None) == (gb2 is None) and (gw is None or accw == accw2), \
             "the two streams of a stage must be frozen / trained together"
     rs0, rs1 = _pair(row_scale) if row_scale is not None else (None, None)
+    kwl = {}
+    l0 = l1 = None
+    if ls_grad is not None:
+        l0, l1 = _pair(ls_grad)
+        gl, accl = rt.pgrad(l0)
+        if gl is not None:
+            assert gw is not None and accl == accw and (c0.bias is None or gb is not None), \
+                "a layer scale is trained together with the conv in front of it"
+            kwl = dict(w=c0.weight, bias=c0.bias, dls=gl)
+            if l1 is not None:
+                gl2, _ = rt.pgrad(l1)
+                kwl.update(w2=c1.weight, bias2=c1.bias, dls2=gl2)
     if gw is not None or gb is not None:
         assert gb is None or gw is not None
         assert gb is None or accb == accw
@@ -434,13 +447,15 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
         def wgrad():
             hip.conv2d_wgrad(x.t, x.ld, dy, lddy, gw, gb, rs0, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
                              accumulate=accw, precision=rt.prec_wgrad(x.ld, lddy, ci, co), dw2=gw2, dbias2=gb2,
-                             row_scale2=rs1)
+                             row_scale2=rs1, **kwl)
             if rt.on_param_grad:
-                for cv, g in ((c0, gb), (c1, gb2)):
+                for cv, g, l in ((c0, gb, l0), (c1, gb2, l1)):
                     if cv is not None:
                         rt.on_param_grad(cv.weight)
                         if g is not None:
                             rt.on_param_grad(cv.bias)
+                        if l is not None and kwl:
+                            rt.on_param_grad(l)
         if defer_ok:
             rt.aside(wgrad, (x.t, dy))
         else:                    # dy is updated in place later in this closure: the weight gradient must read it now
@@ -546,8 +561,8 @@ def _pgrads_or_scratch(rt, params, sizes):
     return outs, acc
 
 
-def gn_backward(rt, gn, x, ms, dy, out, accumulate):
-    """out (+)= dx of y = GN(x) given contiguous dy."""
+def gn_backward(rt, gn, x, ms, dy, out, accumulate=0, add=None):
+    """out = dx of y = GN(x) given contiguous dy [+ out (accumulate) | + add (another contiguous tensor)]."""
     g0, g1 = _pair(gn)
     B, HW, C = x.B, x.HW, x.C
     mom2 = hip.moments(dy, C, B, HW, C, x2=x.t, ldx2=x.ld)
@@ -564,7 +579,8 @@ def gn_backward(rt, gn, x, ms, dy, out, accumulate):
             if g is not None:
                 rt.on_param_grad(g.weight)
                 rt.on_param_grad(g.bias)
-    hip.affine(out, C, B, HW, C, x1=dy, ld1=C, A=A, x2=x.t, ld2=x.ld, E=E, D2=D, S2=S, bstride=C, accumulate=accumulate)
+    hip.affine(out, C, B, HW, C, x1=dy, ld1=C, A=A, x2=x.t, ld2=x.ld, E=E, D2=D, S2=S, bstride=C, accumulate=accumulate,
+               add=add, ldadd=0 if add is None else C)
 
 
 # ----------------------------------------------------------------------------------------- BaseConv
@@ -651,36 +667,33 @@ def cluster_block(rt, x, m, name=None):
         else:
             rt.idx_maps[n0] = idx
     ls1, ls2 = _attr(m, "layer_scale_1"), _attr(m, "layer_scale_2")
-    t1 = rt.new(B, H, W, C) if rt.record else None
     x1 = rt.new(B, H, W, C)
-    conv_call(rt, o, _attr(tm, "fc2"), x1, ypre=t1, res=x, res_scale=ls1, stats=True)
+    conv_call(rt, o, _attr(tm, "fc2"), x1, res=x, res_scale=ls1, stats=True)
     xn2, ms2 = gn_forward(rt, x1, _attr(m, "norm2"))
     hid = mlp0.fc1.weight.shape[0]
     u = rt.new(B, H, W, hid) if rt.record else None
     h = rt.new(B, H, W, hid)
     conv_call(rt, xn2, _attr(mlp, "fc1"), h, act=2, ypre=u)
-    t2 = rt.new(B, H, W, C) if rt.record else None
     x2 = rt.new(B, H, W, C)
-    conv_call(rt, h, _attr(mlp, "fc2"), x2, ypre=t2, res=x1, res_scale=ls2, stats=True)
+    conv_call(rt, h, _attr(mlp, "fc2"), x2, res=x1, res_scale=ls2, stats=True)
 
     def bwd():
-        dx2 = take_grad(x2)                                      # owned; becomes dx1, then dx
+        dx2 = take_grad(x2)
         if dx2 is None:
             return
+        # Nothing below updates a gradient map in place, so EVERY weight gradient of the block runs beside the data
+        # gradients on the auxiliary streams.  The layer-scale gradients come out of the fc2 weight-gradient slabs
+        # (conv_backward, ls_grad): the branch outputs are not stored and no (dx, branch) moments pass exists.
         # ---- MLP branch
-        mom2 = hip.moments(dx2, C, B, H * W, C, x2=t2.t, ldx2=C)
-        _ls_grads(rt, mom2, ls2, _attr(_attr(mlp, "fc2"), "bias"), B, C)
         du = rt.new(B, H, W, hid)
-        conv_backward(rt, h, _attr(mlp, "fc2"), dx2, C, kscale=ls2, aux=u, row_scale=ls2, skip_bias=True, dx_to=du,
-                      defer_ok=False)
+        conv_backward(rt, h, _attr(mlp, "fc2"), dx2, C, kscale=ls2, aux=u, row_scale=ls2, dx_to=du, ls_grad=ls2)
         dxn2 = rt.new(B, H, W, C)
         conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2)
-        gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx2, accumulate=1)          # dx2 now holds dx1
+        dx1 = rt.buf(B, H, W, C)
+        gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx1, add=dx2)               # dx1 = dx2 + d(GN -> Mlp branch)
         # ---- Cluster branch
-        mom2 = hip.moments(dx2, C, B, H * W, C, x2=t1.t, ldx2=C)
-        _ls_grads(rt, mom2, ls1, _attr(_attr(tm, "fc2"), "bias"), B, C)
         do = rt.new(B, H, W, ED)
-        conv_backward(rt, o, _attr(tm, "fc2"), dx2, C, kscale=ls1, row_scale=ls1, skip_bias=True, dx_to=do, defer_ok=False)
+        conv_backward(rt, o, _attr(tm, "fc2"), dx1, C, kscale=ls1, row_scale=ls1, dx_to=do, ls_grad=ls1)
         dfv = rt.new(B, H, W, 2 * ED)
         (ga, gb), acca = _pgrads_or_scratch(rt, (tm0.sim_alpha, tm0.sim_beta), (1, 1))
         kwb = {}
@@ -703,8 +716,9 @@ def cluster_block(rt, x, m, name=None):
             wd1, _, _ = rt.dgrad_operands(tm1, tm1._fused_qkv[0], tm1._fused_qkv[0], 2 * ED, C, 1, 1, None, 2 * ED)
             kwd = dict(pair_rows=rows_half, w2=wd1)
         hip.conv2d(dfv.t, 2 * ED, wd, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1, precision=prec, **kwd)
-        gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx2, accumulate=1)             # dx2 now holds dx
-        rt.give_grad(x, dx2)
+        dx = rt.buf(B, H, W, C)
+        gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx, add=dx1)                   # dx = dx1 + d(GN -> Cluster branch)
+        rt.give_grad(x, dx)
     rt.push(bwd)
     return x2
 
@@ -759,28 +773,6 @@ def _fused_qkv_wgrad(rt, tm, xn, dfv):
                 for prm in (t.fc1.weight, t.fc_v.weight, t.fc1.bias, t.fc_v.bias):     # back to back: adjacent in the arena
                     rt.on_param_grad(prm)
     rt.aside(wgrad, (xn.t, dfv.t))
-
-
-def _ls_grads(rt, mom2, ls, bias, B, C):
-    """Layer-scale and fc2-bias gradients from (sum dx, sum dx * branch) moments; ls / bias may be pairs."""
-    l0, l1 = _pair(ls)
-    b0, b1 = _pair(bias)
-    gl, accl = rt.pgrad(l0)
-    gb, accb = rt.pgrad(b0)
-    kw2 = {}
-    if l1 is not None:
-        gl2, _ = rt.pgrad(l1)
-        gb2, _ = rt.pgrad(b1)
-        assert (gl is None) == (gl2 is None) and (gb is None) == (gb2 is None)
-        kw2 = dict(pair=1, ls2=l1, dls2=gl2, dbias2=gb2)
-    if gl is not None or gb is not None:
-        assert gl is None or gb is None or accl == accb
-        hip.ls_coef_bwd(mom2, l0, B, C, gl, gb, accl if gl is not None else accb, **kw2)
-        if rt.on_param_grad:
-            for l, b in ((l0, b0), (l1, b1)):
-                if l is not None:
-                    rt.on_param_grad(l)
-                    rt.on_param_grad(b)
 
 
 # ----------------------------------------------------------------------------------------- fusion blocks

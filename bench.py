@@ -105,17 +105,17 @@ class ConvTimer:
             e1.record()
             rec["wgrad"].append((conv_flops(B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil), e0, e1,
                                  f"M{B*OH*OW} N{Cout} K{Cin}x{kh}x{kw}" + (f"d{dil}" if dil > 1 else "")))
-        def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold):
+        def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold, **kw_):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            o_cf(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold)
+            o_cf(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold, **kw_)
             e1.record()
             rec["cluster_fwd"].append((3.0 * B * H * W * E * Dh * 4, e0, e1, f"{H}x{W} E{E} D{Dh} fold{fold}"))      # read f, v; write out
 
-        def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, da, db, acc, B, H, W, E, Dh, fold):
+        def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, da, db, acc, B, H, W, E, Dh, fold, **kw_):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            o_cb(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, da, db, acc, B, H, W, E, Dh, fold)
+            o_cb(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, da, db, acc, B, H, W, E, Dh, fold, **kw_)
             e1.record()
             rec["cluster_bwd"].append((5.0 * B * H * W * E * Dh * 4, e0, e1, f"{H}x{W} E{E} D{Dh} fold{fold}"))      # read f, v, g; write df, dv
         hip.conv2d, hip.conv2d_wgrad, hip.cluster_fwd, hip.cluster_bwd = conv2d, conv2d_wgrad, cluster_fwd, cluster_bwd

@@ -63,12 +63,17 @@ int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias
  * precision 1: dy and x rounded to bf16 while staged, v_mfma_f32_32x32x16_bf16 with transposing LDS reads, fp32
  * accumulate / slabs / bias sums (needs 16-byte rows, Cin, Cout multiples of 4 and > 32).
  * Two-stream launch (dw2 != NULL; workspace with pair = 1): samples [0, B/2) contribute to (dw, dbias, row_scale),
- * samples [B/2, B) to (dw2, dbias2, row_scale2). */
+ * samples [B/2, B) to (dw2, dbias2, row_scale2).
+ * dls (NULL = none; 1x1 convs): gradient of the layer scale behind this conv (vr_coc.py:266-271, x + ls * conv(h)):
+ *   dls[n] (+)= sum_c w[n][c] * dw_raw[n][c] + bias[n] * db_raw[n]  (raw = before row_scale), which equals
+ *   sum_m dy[m,n] * conv(h)[m,n] -- so the branch output is neither stored in the forward pass nor re-read. */
 long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int Cout, int kh, int kw, int pair);
 int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, float* dbias,
                            const float* row_scale, int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh,
                            int kw, int stride, int pad, int dil, int accumulate, int precision, float* dw2,
-                           float* dbias2, const float* row_scale2, void* workspace, long workspace_bytes, void* stream);
+                           float* dbias2, const float* row_scale2, const float* w, const float* bias, float* dls,
+                           const float* w2, const float* bias2, float* dls2, void* workspace, long workspace_bytes,
+                           void* stream);
 int vrnet_pack_weight_f32(const float* w_oihw, float* w_tnc, int Cout, int Cin, int kh, int kw, void* stream);
 /* [kh*kw][Cin][Cout] = w_oihw[n][c][t] * kscale[n] (kscale NULL = 1): the data-gradient operand of the bf16 path. */
 int vrnet_pack_weight_t_f32(const float* w_oihw, const float* kscale, float* w_tcn, int Cout, int Cin, int kh, int kw,
@@ -92,7 +97,7 @@ int vrnet_moments_f32(const float* x, long ldx, const float* x2, long ldx2, cons
 int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1, const float* S1, int pre,
                      const float* masky, long ldm, const float* x2, long ld2, const float* E, const float* D2,
                      const float* S2, long coef_bstride, float* out, long ldo, int B, long HW, int C, int accumulate,
-                     void* stream);
+                     const float* add, long ldadd, void* stream);   /* add: out-of-place addend (out = ... + add) */
 
 /* Coefficient kernels: moments -> affine coefficients, saved statistics, parameter gradients. */
 /* GroupNorm(1,C), eps 1e-5 (vr_coc.py:105-111): y = A*(x - S) + D with A,D,S [B][C]; mean_rstd [B][2]. */

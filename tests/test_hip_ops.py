@@ -746,3 +746,44 @@ def test_wrappers_reject_host_and_strided_tensors(hip):
         hip.add_(g, g.half())
     with pytest.raises(RuntimeError, match="innermost dimension"):
         hip.add_(g[..., ::2], g[..., ::2])
+
+
+@pytest.mark.parametrize("pair", [False, True])
+@pytest.mark.parametrize("precision", [0, 1])
+def test_layer_scale_gradient_from_weight_gradient_slabs(hip, pair, precision):
+    """d ls of x + ls * (W h + b) (vr_coc.py:266-271) out of the fc2 weight-gradient launch: equals autograd's sum over
+    pixels of dy * branch without the branch output ever being stored."""
+    B, H, W, Ci, Co = (4, 16, 16, 128, 64)
+    S = 2 if pair else 1
+    Bh = B // S
+    h = rnd(B, Ci, H, W, seed=1)
+    g = rnd(B, Co, H, W, seed=2)
+    ws = [(rnd(Co, Ci, 1, 1, seed=3 + i) / np.sqrt(Ci)).requires_grad_(True) for i in range(S)]
+    bs = [rnd(Co, seed=5 + i).requires_grad_(True) for i in range(S)]
+    ls = [rnd(Co, seed=7 + i).requires_grad_(True) for i in range(S)]
+    rb = (lambda t: t.bfloat16().float()) if precision else (lambda t: t)
+    for i in range(S):
+        sl = slice(i * Bh, (i + 1) * Bh)
+        t = F.conv2d(rb(h[sl]), ws[i] + (rb(ws[i].detach()) - ws[i].detach()), bs[i])
+        (ls[i][None, :, None, None] * t * (g[sl] + ((rb(g[sl]) - g[sl]) if precision else 0))).sum().backward()
+    hg, gg = nhwc(h), nhwc(g)
+    dw = [torch.empty(Co, Ci, 1, 1, device="cuda") for _ in range(S)]
+    db = [torch.empty(Co, device="cuda") for _ in range(S)]
+    dl = [torch.empty(Co, device="cuda") for _ in range(S)]
+    wc, bc, lc = [w.detach().cuda() for w in ws], [b.detach().cuda() for b in bs], [l.detach().cuda() for l in ls]
+    kw = dict(dw2=dw[1], dbias2=db[1], row_scale2=lc[1], w2=wc[1], bias2=bc[1], dls2=dl[1]) if pair else {}
+    hip.conv2d_wgrad(hg, Ci, gg, Co, dw[0], db[0], lc[0], B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=precision,
+                     w=wc[0], bias=bc[0], dls=dl[0], **kw)
+    tol = 2e-2 if precision else TOL
+    for i in range(S):
+        close(dl[i], ls[i].grad, tol, what=f"dls stream {i}")
+        close(dw[i], ws[i].grad, tol, what=f"dw stream {i}")
+        close(db[i], bs[i].grad, tol, what=f"db stream {i}")
+    with pytest.raises(RuntimeError, match="layer-scale gradient"):
+        hip.conv2d_wgrad(hg, Ci, gg, Co, dw[0], None, lc[0], B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, w=wc[0], bias=bc[0], dls=dl[0])
+    # out-of-place addend of the affine kernel (the block backward never updates a gradient map in place)
+    x = nhwc(rnd(B, Co, H, W, seed=9))
+    out = torch.empty_like(x)
+    A = rnd(B, Co, seed=10).cuda()
+    hip.affine(out, Co, B, H * W, Co, x1=gg, ld1=Co, A=A, bstride=Co, add=x, ldadd=Co)
+    close(out, gg * A[:, None, None, :] + x, 1e-6, what="affine add")
