@@ -847,14 +847,19 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradArgs p) {
 template <int VEC, int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, const float* bslab, const float* row_scale,
                                                            float* dw, float* db, int S, int T, int Cout, int Cin,
-                                                           int accumulate, const float* row_scale2, float* dw2, float* db2) {
+                                                           int accumulate, const float* row_scale2, float* dw2, float* db2,
+                                                           const float* w_ls, const float* w_ls2, float* ls_part) {
   constexpr int OUTS = 256 / SL;
   __shared__ float red[SL][OUTS][VEC];
   const long per = (long)T * Cout * Cin;
+  // ls_part (layer-scale gradient, T == 1): [stream][per / VEC + Cout] -- per output quad the dot of the RAW weight
+  // gradient with the weights, per output channel the raw bias gradient; summed per row by wgrad_rowdot_kernel
   if (blockIdx.y) {      // second stream of a two-stream launch: its own S slabs, outputs and row scale
     slab += (long)S * per;
     if (bslab) bslab += (long)S * Cout;
     row_scale = row_scale2; dw = dw2; db = db2;
+    w_ls = w_ls2;
+    if (ls_part) ls_part += per / VEC + Cout;
   }
   const long nq = per / VEC;
   const int o = threadIdx.x % OUTS, sl = threadIdx.x / OUTS;
@@ -891,6 +896,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, co
     const int n = q % Cout;
     const int t = q / Cout;
     const float rs = row_scale ? row_scale[n] : 1.f;
+    if (ls_part) {
+      float dsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dsum += s[j] * w_ls[idx + j];
+      ls_part[e] = dsum;
+    }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float* d = dw + ((long)n * Cin + c + j) * T + t;
@@ -900,45 +911,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, co
   } else if (db && e < nq + Cout) {
     const int n = e - nq;
     float v = s[0];
+    if (ls_part) ls_part[e] = v;
     if (row_scale) v *= row_scale[n];
     db[n] = accumulate ? db[n] + v : v;
   }
 }
 
-// Layer-scale gradient from the weight-gradient slabs of the branch's last 1x1 conv (vr_coc.py:266-271: x + ls * t,
+// Layer-scale gradient from the weight gradient of the branch's last 1x1 conv (vr_coc.py:266-271: x + ls * t,
 // t = W h + b):  dls[n] = sum_m dy[m,n] t[m,n] = sum_c W[n,c] * (sum_m dy[m,n] h[m,c]) + b[n] * sum_m dy[m,n]
 //                       = rowdot(W[n,:], dW_raw[n,:]) + b[n] * db_raw[n]
 // -- the branch output t never has to be stored for the backward pass and no pass over (dy, t) is needed.
-// One workgroup per output channel; fixed reduction order.
-__global__ __launch_bounds__(256) void wgrad_rowdot_kernel(const float* slab, const float* bslab, const float* w,
-                                                           const float* bias, float* dls, int S, int Cout, int Cin,
-                                                           int accumulate, const float* w2, const float* bias2, float* dls2) {
-  __shared__ double red[4];
-  const long per = (long)Cout * Cin;
+// wgrad_reduce_kernel leaves per-quad dot partials and the raw bias gradient in ls_part; one wave per output
+// channel adds them in a fixed order.
+__global__ __launch_bounds__(64) void wgrad_rowdot_kernel(const float* ls_part, const float* bias, float* dls, int Cout,
+                                                          int quads_per_row, long stream_stride, int accumulate,
+                                                          const float* bias2, float* dls2) {
   if (blockIdx.y) {
-    slab += (long)S * per;
-    if (bslab) bslab += (long)S * Cout;
-    w = w2; bias = bias2; dls = dls2;
+    ls_part += stream_stride;
+    bias = bias2; dls = dls2;
   }
   const int n = blockIdx.x;
+  const float* row = ls_part + (long)n * quads_per_row;
   double acc = 0.0;
-  for (int c = threadIdx.x; c < Cin; c += 256) {
-    const float wv = w[(long)n * Cin + c];
-    float sum = 0.f;
-    for (int k = 0; k < S; ++k) sum += slab[(long)k * per + (long)n * Cin + c];
-    acc += (double)sum * (double)wv;
-  }
+  for (int q = threadIdx.x; q < quads_per_row; q += 64) acc += (double)row[q];
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
   if (threadIdx.x == 0) {
-    double tot = red[0] + red[1] + red[2] + red[3];
-    if (bias && bslab) {
-      float sb = 0.f;
-      for (int k = 0; k < S; ++k) sb += bslab[(long)k * Cout + n];
-      tot += (double)bias[n] * (double)sb;
-    }
-    dls[n] = (accumulate ? dls[n] : 0.f) + (float)tot;
+    if (bias) acc += (double)bias[n] * (double)ls_part[(long)Cout * quads_per_row + n];
+    dls[n] = (accumulate ? dls[n] : 0.f) + (float)acc;
   }
 }
 
@@ -1180,6 +1179,7 @@ extern "C" long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int
   wgrad_plan(Ms, Cin, Cout, kh * kw, &cfg, &bn, &nt, &ct, &S, &rows, 1);      // the bf16 plan may split more
   const long need16 = streams * ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
   if (need16 > need) need = need16;
+  need += streams * ((long)Cout * Cin + Cout) * 4;      // layer-scale dot partials (1x1 convs, conv2d_wgrad dls)
   if (Cin <= 8 && Cout <= 8) {
     const long t = vr_tiny_wgrad_workspace((long)B * OH * OW, Cin, Cout, kh * kw);
     if (t > need) need = t;
@@ -1221,6 +1221,9 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   p.slab = reinterpret_cast<float*>(workspace);
   p.bslab = dbias ? p.slab + (long)streams * S * T * Cout * Cin : nullptr;
   p.M_half = (int)(M / streams);
+  const bool rvec_ls = (Cin % 4 == 0);
+  const long ls_stride = (long)T * Cout * Cin / (rvec_ls ? 4 : 1) + Cout;
+  float* ls_part = dls ? p.slab + (long)streams * S * ((long)T * Cout * Cin + Cout) : nullptr;
   p.M = (int)M; p.OH = OH; p.OW = OW; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
   p.rows_per_split = rows; p.n_tiles = nt; p.c_tiles = ct;
@@ -1258,7 +1261,7 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   const long total = (long)T * Cout * Cin / (rvec ? 4 : 1) + (dbias ? Cout : 0);
 #define VR_WREDUCE(VEC_, SL_)                                                                                        \
   hipLaunchKernelGGL((wgrad_reduce_kernel<VEC_, SL_>), dim3(vr_cdiv(total, 256 / SL_), streams), dim3(256), 0, st, p.slab, \
-                     p.bslab, row_scale, dw, dbias, S, T, Cout, Cin, accumulate, row_scale2, dw2, dbias2)
+                     p.bslab, row_scale, dw, dbias, S, T, Cout, Cin, accumulate, row_scale2, dw2, dbias2, w, w2, ls_part)
   // lanes per output: enough of them to cover the serial slab loop of the small matrices, one thread per output
   // once the matrix alone yields >= 64K threads (a 16-lane block there is 6 K workgroups of 256 B of output each)
   const int sl = (total >= 65536 || S <= 2) ? 1 : ((total >= 16384 || S <= 8) ? 4 : 16);
@@ -1274,8 +1277,8 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
 #undef VR_WREDUCE
   VR_LAUNCH_CHECK("conv2d_wgrad_reduce");
   if (dls) {
-    hipLaunchKernelGGL(wgrad_rowdot_kernel, dim3(Cout, streams), dim3(256), 0, st, p.slab, p.bslab, w, bias, dls, S, Cout,
-                       Cin, accumulate, w2, bias2, dls2);
+    hipLaunchKernelGGL(wgrad_rowdot_kernel, dim3(Cout, streams), dim3(64), 0, st, ls_part, bias, dls, Cout,
+                       (int)((ls_stride - Cout) / Cout), ls_stride, accumulate, bias2, dls2);
     VR_LAUNCH_CHECK("conv2d_wgrad_rowdot");
   }
   return VR_OK;
