@@ -274,21 +274,67 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && BK == 16) ? 8 : 1) vo
 //     share an XCD), so the A rows are fetched into a single L2 once.
 __device__ __attribute__((aligned(128))) float vr_zero_page[64];
 
+// ---- fp32 products on the bf16 matrix pipe ("x6"): every fp32 operand is split EXACTLY into three bf16 values
+// a = a0 + a1 + a2 (truncation: a0 = top 16 bits of a, a1 = top 16 bits of a - a0, a2 = a - a0 - a1, which has at most
+// 8 significant bits left), and a*b is accumulated in fp32 as the six bf16 x bf16 products (exact in fp32) with
+// i + j <= 2: a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1.  The three dropped products are <= 2^-24 |ab| each, i.e. the
+// result carries fp32 rounding-level error like the fp32 MFMA, at 6 x 32 instead of 8 x 64 matrix-pipe cycles per
+// 32 x 32 x 16 block (v_mfma_f32_32x32x16_bf16 vs eight v_mfma_f32_32x32x2_f32).
+typedef __bf16 vr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned vr_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void vr_split3(const f32x4 lo4, const f32x4 hi4, vr_bf16x8 (&out)[3]) {
+  float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+  unsigned p0[8], p1[8], p2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned b0 = __builtin_bit_cast(unsigned, x[e]);
+    const float r1 = x[e] - __builtin_bit_cast(float, b0 & 0xffff0000u);
+    const unsigned b1 = __builtin_bit_cast(unsigned, r1);
+    const float r2 = r1 - __builtin_bit_cast(float, b1 & 0xffff0000u);
+    p0[e] = b0; p1[e] = b1; p2[e] = __builtin_bit_cast(unsigned, r2);
+  }
+  vr_u32x4 q0, q1, q2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {      // v_perm_b32: {hi16(x[2e+1]), hi16(x[2e])}
+    q0[e] = __builtin_amdgcn_perm(p0[2 * e + 1], p0[2 * e], 0x07060302u);
+    q1[e] = __builtin_amdgcn_perm(p1[2 * e + 1], p1[2 * e], 0x07060302u);
+    q2[e] = __builtin_amdgcn_perm(p2[2 * e + 1], p2[2 * e], 0x07060302u);
+  }
+  out[0] = __builtin_bit_cast(vr_bf16x8, q0);
+  out[1] = __builtin_bit_cast(vr_bf16x8, q1);
+  out[2] = __builtin_bit_cast(vr_bf16x8, q2);
+}
+
+__device__ __forceinline__ f32x16 vr_mfma_x6(const vr_bf16x8 (&a)[3], const vr_bf16x8 (&b)[3], f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);      // small terms first
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+
 // T = 1: 64 x 64 x 32 tile, one 32x32 accumulator per wave (16 MFMAs per stage); T = 2: 128 x 128 x 16 tile, 2 x 2
 // accumulators per wave (32 MFMAs per stage, half the LDS-fill bytes and fragment reads per MFMA) for the layers
 // whose grid still fills the chip with 128-row tiles.  Both stage 16 KB per K step.
-template <int MODE, int NST, int T>
+// Asymmetric tiles (TM != TN, e.g. 128 x 64 x 16) serve outputs of 64 / 192 / 320 channels and grids that 128 x 128
+// tiles would leave half empty.
+template <int MODE, int NST, int TM, int TN, bool X6 = false>
 __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_dma_kernel(const IgemmArgs p_in, int MT, int NT) {
-  constexpr int BM = 64 * T, BN = 64 * T, BK = 32 / T;
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = (TM == 1 && TN == 1) ? 32 : 16;
   constexpr int QPR = BK / 4;                       // 16-byte quads per K-contiguous row of a stage
   constexpr int KQ = QPR / 2;                       // quads each lane owns per stage (k = h*BK/2 .. +BK/2)
   constexpr int RSH = QPR == 8 ? 1 : 2;             // swizzle: quad' = quad ^ ((row >> RSH) & (QPR - 1))
   constexpr int A_FLOATS = BM * BK, ST_FLOATS = A_FLOATS + BN * BK;
+  constexpr int NA = A_FLOATS / 1024, NB = BN * BK / 1024, NP = NA + NB;      // 1 KB DMA pieces per wave and stage
   constexpr int RING = NST * ST_FLOATS;
   constexpr int KS_MAX = 1024;                      // kscale copy (mode 1)
   static_assert(RING >= 4 * 32 * STAGE_LD, "epilogue staging must fit the ring");
   static_assert(NST >= 3 && NST <= 6, "counted waits cover up to 4 younger stages");
-  static_assert(ST_FLOATS == 4096, "two 1 KB DMA pieces per wave and operand");
+  static_assert(NA >= 1 && NB >= 1 && NA * 1024 == A_FLOATS && NB * 1024 == BN * BK, "whole 1 KB DMA pieces per wave");
+  static_assert(NP == 4 || NST == 3, "the counted waits of deeper rings assume 4 pieces per stage");
   // one LDS object only: a second __shared__ beside a DMA staging array makes hipcc drain vmcnt before ds_reads
   __shared__ __attribute__((aligned(16))) float smem[RING + 16 + (MODE == 1 ? KS_MAX : 0)];
   unsigned* tapmask_s = reinterpret_cast<unsigned*>(smem + RING);
@@ -324,11 +370,11 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
   const int TAPS = p.kh * p.kw;
 
   // ---- loader roles: two 16-B slots of the A image and two of the B image per thread and stage
-  int a_q[2], a_b[2], a_y[2], a_x[2];
-  bool a_ok[2];
+  int a_q[NA], a_b[NA], a_y[NA], a_x[NA];
+  bool a_ok[NA];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int sl = (wave * 2 + i) * 64 + lane, r = sl / QPR;
+  for (int i = 0; i < NA; ++i) {
+    const int sl = (wave * NA + i) * 64 + lane, r = sl / QPR;
     a_q[i] = (sl % QPR) ^ ((r >> RSH) & (QPR - 1));
     const int m = m0 + r;
     a_ok[i] = m < p.M;
@@ -357,7 +403,7 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     for (int t = 0; t < TAPS; ++t) {
       const int ky = t / p.kw, kx = t - ky * p.kw;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NA; ++i) {
         int sy, sx;
         if (src_of(i, ky, kx, sy, sx)) mine |= 1u << t;
       }
@@ -385,14 +431,14 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
   // are masked for the whole tap (row outside the tile / image, padded tap, channel quad beyond CK or CN) point at
   // the zero page and do not advance, so a stage issues with two 64-bit adds per slot and no compares; only the
   // last K block of a tap whose contraction is not a multiple of BK re-checks the quad against CK.
-  const float* a_run[2];
-  const float* b_run[2];
-  int a_inc[2], b_inc[2], a_k[2], b_k[2];
+  const float* a_run[NA];
+  const float* b_run[NB];
+  int a_inc[NA], b_inc[NB], a_k[NA], b_k[NB];
   const bool k_tail = (p.CK % BK) != 0;
   auto setup_tap = [&](int t) {
     const int ky = t / p.kw, kx = t - ky * p.kw;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
       int sy, sx;
       const bool ok = src_of(i, ky, kx, sy, sx) && 4 * a_q[i] < p.CK;
       a_run[i] = ok ? p.a + ((long)(a_b[i] * p.SH + sy) * p.SW + sx) * p.lda + 4 * a_q[i] : zero_page;
@@ -401,8 +447,8 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     }
     const float* wt = p.w + (long)t * p.wtap;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int sl = (wave * 2 + i) * 64 + lane;
+    for (int i = 0; i < NB; ++i) {
+      const int sl = (wave * NB + i) * 64 + lane;
       if (MODE == 0) {           // rows n, contiguous contraction: same image as A
         const int r = sl / QPR, q = (sl % QPR) ^ ((r >> RSH) & (QPR - 1));
         const bool ok = n0 + r < p.CN && 4 * q < p.CK;
@@ -430,16 +476,16 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     float* stage = smem + ld_buf * ST_FLOATS;
     const bool last = k_tail && ld_kb == nkb - 1;          // block-uniform
     const int c0 = ld_kb * BK;
-    if (i < 2) {
+    if (i < NA) {
       const float* src = (last && c0 + a_k[i] >= p.CK) ? zero_page : a_run[i];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(stage + (wave * 2 + i) * 256), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(stage + (wave * NA + i) * 256), 16, 0, 0);
       a_run[i] += a_inc[i];
     } else {
-      const int j = i - 2;
+      const int j = i - NA;
       const float* src = (last && c0 + b_k[j] >= p.CK) ? zero_page : b_run[j];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(stage + A_FLOATS + (wave * 2 + j) * 256),
+                                       (__attribute__((address_space(3))) void*)(stage + A_FLOATS + (wave * NB + j) * 256),
                                        16, 0, 0);
       b_run[j] += b_inc[j];
     }
@@ -454,26 +500,30 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
   auto issue = [&]() {
     issue_begin();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_piece(i);
+    for (int i = 0; i < NP; ++i) issue_piece(i);
     issue_end();
   };
 
   // (one accumulator chain per tile: a second, independent set was measured with in-kernel stamps and changes
   // nothing -- with one wave per SIMD the 16 MFMAs of a stage take 1540 cycles because the wave's four DMA issues
   // cost ~130 cycles each in its own instruction stream, not because of the accumulator dependency)
-  f32x16 acc[T][T];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < T; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < T; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int h = lane >> 5;
-  int a_off[T], a_swz[T], b_off[T], b_swz[T];
+  int a_off[TM], a_swz[TM], b_off[TN], b_swz[TN];
 #pragma unroll
-  for (int i = 0; i < T; ++i) {
-    const int ra = wm * 32 * T + 32 * i + (lane & 31), rb = wn * 32 * T + 32 * i + (lane & 31);
+  for (int i = 0; i < TM; ++i) {
+    const int ra = wm * 32 * TM + 32 * i + (lane & 31);
     a_off[i] = ra * BK; a_swz[i] = (ra >> RSH) & (QPR - 1);
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int rb = wn * 32 * TN + 32 * i + (lane & 31);
     b_off[i] = MODE == 0 ? rb * BK : rb; b_swz[i] = (rb >> RSH) & (QPR - 1);
   }
 
@@ -491,10 +541,13 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     // stage s has landed once at most the min(NST - 2, stages left) younger stages (4 DMAs each) are still outstanding
     {
       const int younger = nsteps - 1 - s < NST - 2 ? nsteps - 1 - s : NST - 2;      // block-uniform
-      if (younger >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (younger == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (NP == 4 && younger >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (NP == 4 && younger == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (NP == 4 && younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (NP == 4 && younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (NP == 3 && younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (NP == 5 && younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (NP == 6 && younger == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
@@ -509,19 +562,19 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     if (more) issue_begin();
     const float* As = smem + cur * ST_FLOATS;
     const float* Bs = As + A_FLOATS;
-    f32x4 af[T][KQ], bq[T][KQ];
+    f32x4 af[TM][KQ], bq[TN][KQ];
 #pragma unroll
-    for (int i = 0; i < T; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < KQ; ++j) af[i][j] = *reinterpret_cast<const f32x4*>(As + a_off[i] + 4 * ((KQ * h + j) ^ a_swz[i]));
     if (MODE == 0) {
 #pragma unroll
-      for (int i = 0; i < T; ++i)
+      for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < KQ; ++j) bq[i][j] = *reinterpret_cast<const f32x4*>(Bs + b_off[i] + 4 * ((KQ * h + j) ^ b_swz[i]));
     } else {
 #pragma unroll
-      for (int i = 0; i < T; ++i)
+      for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < KQ; ++j)
 #pragma unroll
@@ -533,26 +586,51 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
 #pragma unroll
         for (int j = 0; j < KQ; ++j)
 #pragma unroll
-          for (int i = 0; i < T; ++i) bq[i][j] *= ks[j];
+          for (int i = 0; i < TN; ++i) bq[i][j] *= ks[j];
       }
     }
 #ifdef VR_IGEMM_STAMP
     if (blockIdx.x == 8 && tid == 0 && s < 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp[4 * s + 1] = __builtin_amdgcn_s_memtime(); }
 #endif
     constexpr int GROUPS = KQ >= 4 ? 4 : KQ;          // MFMA groups that each carry DMA pieces behind them
+    if constexpr (X6) {
+      // lane h owns k = (BK/2) h .. + BK/2 - 1 of the stage: 8 consecutive values per k16 step of the bf16 MFMA
+      constexpr int NK16 = KQ / 2;
+      static_assert(KQ % 2 == 0, "x6 needs whole k16 steps");
+#pragma unroll
+      for (int ks = 0; ks < NK16; ++ks) {
+        vr_bf16x8 a3[TM][3], b3[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) vr_split3(af[i][2 * ks], af[i][2 * ks + 1], a3[i]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) vr_split3(bq[i][2 * ks], bq[i][2 * ks + 1], b3[i]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) acc[i][jn] = vr_mfma_x6(a3[i], b3[jn], acc[i][jn]);
+        if (more) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < NP; ++q)
+            if (q % NK16 == ks) issue_piece(q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < KQ; ++j) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int i = 0; i < T; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int jn = 0; jn < T; ++jn)
+          for (int jn = 0; jn < TN; ++jn)
             acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j][e], bq[jn][j][e], acc[i][jn], 0, 0, 0);
       if (more && j < GROUPS) {
         __builtin_amdgcn_sched_barrier(0);          // keep the DMA behind this MFMA group, not hoisted to the top
 #pragma unroll
-        for (int q = j * (4 / GROUPS); q < (j + 1) * (4 / GROUPS); ++q) issue_piece(q);
+        for (int q = 0; q < NP; ++q)
+          if (q % GROUPS == j) issue_piece(q);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -569,7 +647,7 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
   {
     IgemmArgs q = p;
     q.stats = nullptr;
-    igemm_epilogue<T, T, 2, 2>(q, acc, smem, m0, n0);
+    igemm_epilogue<TM, TN, 2, 2>(q, acc, smem, m0, n0);
   }
   __syncthreads();
   if (tid == 0) wg_stamp[3] = __builtin_amdgcn_s_memtime();
@@ -578,9 +656,9 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
 #ifdef VR_IGEMM_STAMP
   IgemmArgs q = p;            // the stats pointer carries the stamps in this build
   q.stats = nullptr;
-  igemm_epilogue<T, T, 2, 2>(q, acc, smem, m0, n0);
+  igemm_epilogue<TM, TN, 2, 2>(q, acc, smem, m0, n0);
 #else
-  igemm_epilogue<T, T, 2, 2>(p, acc, smem, m0, n0);
+  igemm_epilogue<TM, TN, 2, 2>(p, acc, smem, m0, n0);
 #endif
 }
 
@@ -840,6 +918,154 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradArgs p) {
   if (do_bias && tid < 64 && n0 + tid < p.Cout) p.bslab[(long)split * p.Cout + n0 + tid] = bsum;
 }
 
+// Weight gradient with fp32 products as six bf16 x bf16 products (see vr_split3): (64 TN) x (64 TC) tile of dW, 2 x 2
+// waves with TN x TC accumulators each, 16 contraction rows (one k16 step) per stage, operand tiles [16 rows m][channels]
+// by LDS-DMA into a 3-stage ring; the fragments (8 consecutive rows of one channel) are columns of the staged tiles, read
+// with conflict-free ds_read_b32 (lanes = consecutive channels) and split in registers.  Same slabs / reduce pass as the
+// other weight-gradient kernels.
+template <int TN, int TC, bool IDENT>
+__global__ __launch_bounds__(256, 3) void wgrad_x6_kernel(const WgradArgs p) {
+  constexpr int BKD = 16, NST = 3, BN = 64 * TN, BC = 64 * TC;
+  constexpr int Y_FLOATS = BKD * BN, X_FLOATS = BKD * BC, ST_FLOATS = Y_FLOATS + X_FLOATS;
+  constexpr int NY = Y_FLOATS / 1024, NX = X_FLOATS / 1024, NP = NY + NX;
+  static_assert(NY >= 1 && NX >= 1 && NP <= 4, "1 KB DMA pieces per wave");
+  __shared__ __attribute__((aligned(16))) float smem[NST * ST_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bid = blockIdx.x;
+  const int ct = bid % p.c_tiles; bid /= p.c_tiles;
+  const int nt = bid % p.n_tiles; bid /= p.n_tiles;
+  const int t = bid;
+  const int ky = t / p.kw, kx = t - ky * p.kw;
+  const int n0 = nt * BN, c0 = ct * BC;
+  int m_begin, m_end, split;
+  wgrad_rows(p, m_begin, m_end, split);
+  const bool do_bias = p.bslab != nullptr && ct == 0 && t == 0;
+  float bsum = 0.f;
+  int y_kr[NY], y_cq[NY], x_kr[NX], x_cq[NX];
+#pragma unroll
+  for (int i = 0; i < NY; ++i) {
+    const int sl = (wave * NY + i) * 64 + lane;
+    y_kr[i] = sl / (BN / 4);
+    y_cq[i] = 4 * (sl % (BN / 4));
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int sl = (wave * NX + i) * 64 + lane;
+    x_kr[i] = sl / (BC / 4);
+    x_cq[i] = 4 * (sl % (BC / 4));
+  }
+  const float* zero_page = vr_zero_page;          // taken once and opaque: see igemm_dma_kernel
+  asm volatile("" : "+s"(zero_page));
+  int ld_m = m_begin, ld_buf = 0;
+  auto issue = [&]() {
+    float* stage = smem + ld_buf * ST_FLOATS;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int m = ld_m + y_kr[i];
+      const float* src = (m < m_end && n0 + y_cq[i] < p.Cout) ? p.dy + (long)m * p.lddy + n0 + y_cq[i] : zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + (wave * NY + i) * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int m = ld_m + x_kr[i];
+      const float* src = zero_page;
+      if (m < m_end && c0 + x_cq[i] < p.Cin) {
+        if (IDENT) {
+          src = p.x + (long)m * p.ldx + c0 + x_cq[i];
+        } else {
+          const int ox = m % p.OW;
+          const int q = m / p.OW;
+          const int oy = q % p.OH, b = q / p.OH;
+          const int sy = oy * p.stride - p.pad + ky * p.dil, sx = ox * p.stride - p.pad + kx * p.dil;
+          if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
+            src = p.x + ((long)(b * p.H + sy) * p.W + sx) * p.ldx + c0 + x_cq[i];
+        }
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + Y_FLOATS + (wave * NX + i) * 256),
+                                       16, 0, 0);
+    }
+    ld_m += BKD;
+    if (++ld_buf == NST) ld_buf = 0;
+  };
+
+  f32x16 acc[TN][TC];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int h = lane >> 5;
+  const int arow = wm * 32 * TN + (lane & 31), bcol = wn * 32 * TC + (lane & 31);
+  const int nsteps = (m_end - m_begin + BKD - 1) / BKD;
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < nsteps) issue();
+  int cur = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) {
+      if (NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (NP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + NST - 1 < nsteps) issue();
+    const float* Ys = smem + cur * ST_FLOATS;
+    const float* Xs = Ys + Y_FLOATS;
+    if (do_bias && tid < BN) {
+#pragma unroll
+      for (int k = 0; k < BKD; ++k) bsum += Ys[k * BN + tid];
+    }
+    vr_bf16x8 a3[TN][3], b3[TC][3];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      f32x4 lo, hi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo[e] = Ys[(8 * h + e) * BN + arow + 32 * i];
+        hi[e] = Ys[(8 * h + 4 + e) * BN + arow + 32 * i];
+      }
+      vr_split3(lo, hi, a3[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+      f32x4 lo, hi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo[e] = Xs[(8 * h + e) * BC + bcol + 32 * j];
+        hi[e] = Xs[(8 * h + 4 + e) * BC + bcol + 32 * j];
+      }
+      vr_split3(lo, hi, b3[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j) acc[i][j] = vr_mfma_x6(a3[i], b3[j], acc[i][j]);
+    if (++cur == NST) cur = 0;
+  }
+  const long T = (long)p.kh * p.kw;
+  float* slab = p.slab + ((long)split * T + t) * p.Cout * p.Cin;
+#pragma unroll
+  for (int j = 0; j < TC; ++j) {
+    const int c = c0 + bcol + 32 * j;
+    if (c >= p.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 32 * TN + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (n < p.Cout) slab[(long)n * p.Cin + c] = acc[i][j][r];
+      }
+  }
+  if (do_bias && tid < BN && n0 + tid < p.Cout) p.bslab[(long)split * p.Cout + n0 + tid] = bsum;
+}
+
 // dw (OIHW) = row_scale[n] * sum_s slab[s][t][n][c] (+ dw);  db[n] = row_scale[n] * sum_s bslab[s][n] (+ db)
 // SL lanes share one output (quad): lane sl sums slabs sl, sl + SL, ...; the SL partials are then added in lane
 // order through LDS (fixed order: deterministic).  Small weight matrices are split over up to 256 row ranges, and
@@ -984,14 +1210,15 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                                                      (!res_scale == !res_scale2) && (!kscale == !kscale2))),
                "conv2d: a two-stream launch needs the second parameter set and a first-stream row count that is a "
                "multiple of 128");
-  VR_CHECK_ARG(precision == 0 || precision == 1, "conv2d: precision 0 (fp32 MFMA) or 1 (bf16 operands, fp32 accumulate)");
+  VR_CHECK_ARG(precision >= 0 && precision <= 2, "conv2d: precision 0 (fp32 MFMA), 1 (bf16 operands, fp32 accumulate) or 2 "
+                                                 "(fp32 products as six bf16 x bf16 products, fp32 accumulate)");
   VR_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0, "conv2d: bad shape");
   VR_CHECK_ARG(kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d: bad geometry");
   VR_CHECK_ARG((H + 2 * pad - dil * (kh - 1) - 1) / stride + 1 == OH &&
                    (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1 == OW,
                "conv2d: output size %dx%d inconsistent with input %dx%d k%d s%d p%d d%d", OH, OW, H, W, kh,
                stride, pad, dil);
-  const bool plain = !ypre && !res && !kscale && !aux && !out_nchw && act == 0 && !stats && precision == 0 && !pair_rows;
+  const bool plain = !ypre && !res && !kscale && !aux && !out_nchw && act == 0 && !stats && precision != 1 && !pair_rows;
   if (plain && tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride))
     return vr_tiny_conv(mode, a, lda, w, mode == 0 ? bias : nullptr, y, ldy, B, H, W, Cin, Cout, kh, pad, dil, accumulate,
                         vr_stream(stream));
@@ -1092,13 +1319,41 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   // large-M layers with >= 768 such tiles: 4-11 % slower than either (K <= 256 there: prologue / epilogue bound), so
   // they are not dispatched.  All measured with bench.py --detail.
   const bool dma_shape = use_dma == 2 || M <= 8192 || (M <= 32768 && ktot >= 1024);
+  // precision 2 (x6): 128 x 128 x 16 ring tiles with 2 x 2 accumulators per wave -- each split fragment feeds two
+  // MFMA groups, which is what pays for the split (on 64 x 64 tiles the conversions cost what the faster MFMA saves)
+  static const int x6_min_n = getenv("VRNET_X6_MIN_N") ? atoi(getenv("VRNET_X6_MIN_N")) : 96;
+  static const int x6_min_tiles = getenv("VRNET_X6_MIN_TILES") ? atoi(getenv("VRNET_X6_MIN_TILES")) : 256;
+  static const int x6_tile = getenv("VRNET_X6_TILE") ? atoi(getenv("VRNET_X6_TILE")) : 0;     // tuning aid: 22 / 21
+  if (precision == 2 && dma_ok && (!pair_rows || p.pair_rows % 128 == 0)) {
+    const long mt = vr_cdiv(M, 128), nt22 = vr_cdiv(p.CN, 128), nt21 = vr_cdiv(p.CN, 64);
+    const bool waste22 = nt22 * 128 - p.CN > 16 * nt22;          // more than 12 % of the column tiles is padding
+    int tile = 0;
+    if (p.CN >= x6_min_n && mt * nt22 >= 2 * x6_min_tiles && !waste22) tile = 22;
+    else if (p.CN > 32 && mt * nt21 >= x6_min_tiles) tile = 21;
+    else if (p.CN >= x6_min_n && mt * nt22 >= x6_min_tiles) tile = 22;
+    if (x6_tile && tile) tile = x6_tile;
+    if (tile == 22) {
+      dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt22));
+      if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 2, 2, true>), grid, block, 0, st, p, (int)mt, (int)nt22);
+      else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 2, 2, true>), grid, block, 0, st, p, (int)mt, (int)nt22);
+      VR_LAUNCH_CHECK("conv2d(x6)");
+      return VR_OK;
+    }
+    if (tile == 21) {
+      dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt21));
+      if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 2, 1, true>), grid, block, 0, st, p, (int)mt, (int)nt21);
+      else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 2, 1, true>), grid, block, 0, st, p, (int)mt, (int)nt21);
+      VR_LAUNCH_CHECK("conv2d(x6)");
+      return VR_OK;
+    }
+  }
   if (dma_ok && dma_shape) {
     const int MT = (int)vr_cdiv(M, 64), NT = (int)vr_cdiv(p.CN, 64);
     dim3 grid((unsigned)(8 * vr_cdiv(MT, 8) * NT));
     // (rings of 4 / 6 stages for launches with <= 2 / 1 workgroups per CU were measured: 3-10 % slower -- the stage
     // time there is not DMA latency but per-stage issue overhead, see the interleaved issue in the kernel)
-    if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 1>), grid, block, 0, st, p, MT, NT);
-    else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 1>), grid, block, 0, st, p, MT, NT);
+    if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 1, 1>), grid, block, 0, st, p, MT, NT);
+    else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 1, 1>), grid, block, 0, st, p, MT, NT);
     VR_LAUNCH_CHECK("conv2d");
     return VR_OK;
   }
@@ -1134,6 +1389,25 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
 static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int* n_tiles, int* c_tiles, int* S,
                        int* rows, int bf16 = 0) {
   const long wsz = (long)T * Cout * Cin;
+  if (bf16 == 2) {      // x6 kernels: cfg = 10 TN + TC, tiles of (64 TN) x (64 TC); 0 = no x6 kernel for this shape
+    static const int x6_wgrad = getenv("VRNET_X6_WGRAD") ? atoi(getenv("VRNET_X6_WGRAD")) : 1;   // tuning aid
+    *cfg = 0;
+    if (!x6_wgrad || Cout <= 32 || Cin <= 32) return;
+    const int tn = Cout > 64 ? 2 : 1, tc = Cin > 64 ? 2 : 1;
+    if (tn == 1 && tc == 1) return;
+    *cfg = 10 * tn + tc; *bn = 64 * tc;
+    *n_tiles = (int)vr_cdiv(Cout, 64 * tn); *c_tiles = (int)vr_cdiv(Cin, 64 * tc);
+    const long tiles = (long)*n_tiles * *c_tiles * T;
+    long s = vr_cdiv(768, tiles);
+    long smax = vr_cdiv(M, 256);
+    if (s > smax) s = smax;
+    const long sbytes = (48L << 20) / (wsz * 4);
+    if (s > sbytes) s = sbytes;
+    if (s < 1) s = 1;
+    const long r = vr_cdiv(vr_cdiv(M, s), 16) * 16;
+    *rows = (int)r; *S = (int)vr_cdiv(M, r);
+    return;
+  }
   auto splits = [&](long tiles) {
     long s = vr_cdiv(1024, tiles);
     // >= 512 rows per split on the big maps (the reduce pass is serial in S); down to 128 rows, at most 64
@@ -1179,6 +1453,11 @@ extern "C" long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int
   wgrad_plan(Ms, Cin, Cout, kh * kw, &cfg, &bn, &nt, &ct, &S, &rows, 1);      // the bf16 plan may split more
   const long need16 = streams * ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
   if (need16 > need) need = need16;
+  wgrad_plan(Ms, Cin, Cout, kh * kw, &cfg, &bn, &nt, &ct, &S, &rows, 2);      // so may the x6 plan
+  if (cfg) {
+    const long need6 = streams * ((long)S * kh * kw * Cout * Cin + (long)S * Cout) * 4 + 256;
+    if (need6 > need) need = need6;
+  }
   need += streams * ((long)Cout * Cin + Cout) * 4;      // layer-scale dot partials (1x1 convs, conv2d_wgrad dls)
   if (Cin <= 8 && Cout <= 8) {
     const long t = vr_tiny_wgrad_workspace((long)B * OH * OW, Cin, Cout, kh * kw);
@@ -1205,7 +1484,14 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
                "conv2d_wgrad: the layer-scale gradient needs a 1x1 conv, its weights, (with a bias) the bias gradient, "
                "and in a two-stream launch the second set");
   int cfg, bn, nt, ct, S, rows;
-  wgrad_plan(M / streams, Cin, Cout, T, &cfg, &bn, &nt, &ct, &S, &rows, precision == 1);
+  const bool vec_all = (Cin % 4 == 0) && (ldx % 4 == 0) && vr_aligned16(x) && (Cout % 4 == 0) && (lddy % 4 == 0) &&
+                       vr_aligned16(dy);
+  int x6cfg = 0;
+  if (precision == 2) {
+    if (vec_all) wgrad_plan(M / streams, Cin, Cout, T, &x6cfg, &bn, &nt, &ct, &S, &rows, 2);
+    if (!x6cfg) precision = 0;       // no x6 kernel for this shape: the fp32 MFMA path
+  }
+  if (!x6cfg) wgrad_plan(M / streams, Cin, Cout, T, &cfg, &bn, &nt, &ct, &S, &rows, precision == 1);
   const long need = vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw, streams == 2);
   if (workspace_bytes < need) {
     vr_set_error("conv2d_wgrad: workspace %ld < %ld bytes", workspace_bytes, need);
@@ -1238,8 +1524,18 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
     else if (vec) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, TM_, TN_, WM_, WN_, false, true>), grid, block, 0, st, p);     \
     else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, TM_, TN_, WM_, WN_, false, false>), grid, block, 0, st, p);             \
   } while (0)
-  VR_CHECK_ARG(precision == 0 || precision == 1, "conv2d_wgrad: precision 0 (fp32 MFMA) or 1 (bf16 operands)");
-  if (precision == 1) {
+  VR_CHECK_ARG(precision >= 0 && precision <= 2, "conv2d_wgrad: precision 0 (fp32 MFMA), 1 (bf16 operands) or 2 (x6)");
+  if (x6cfg) {
+#define VR_WX6(TN_, TC_)                                                                                    \
+  do {                                                                                                      \
+    if (ident) hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, true>), grid, block, 0, st, p);                \
+    else hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, false>), grid, block, 0, st, p);                     \
+  } while (0)
+    if (x6cfg == 22) VR_WX6(2, 2);
+    else if (x6cfg == 21) VR_WX6(2, 1);
+    else VR_WX6(1, 2);
+#undef VR_WX6
+  } else if (precision == 1) {
     VR_CHECK_ARG(vec && cfg == 1 && rows % 64 == 0, "conv2d_wgrad: the bf16 path needs 16-byte aligned rows, channel counts that "
                                                     "are multiples of 4 and more than 32 channels on both sides");
     vr_wgrad_bf16_launch(&p, ident ? 1 : 0, nt * ct * T, S, streams, st);

@@ -70,6 +70,7 @@ class RT:
         self.packed = {}
         self.packed_t = {}
         self.bf16 = False           # dense convs with bf16-rounded operands on the bf16 MFMA (model.compute_dtype)
+        self.fp32_precision = 2     # fp32 layers: 2 = six-bf16-product kernels where available, 0 = fp32 MFMA only
         self.consts = {}
         self.idx_maps = {}
         self.relu_masks = None      # {BatchNorm module: ReLU output Act} when model.record_relu_masks (parity tests)
@@ -254,11 +255,17 @@ class RT:
         return p
 
     def prec_fwd(self, lda, ci, co):
-        """precision flag of a forward conv launch."""
-        return 1 if self.bf16 and hip.bf16_conv_ok(lda, ci, co, 0) else 0
+        """precision flag of a forward conv launch: 1 = bf16-rounded operands (compute_dtype "bf16"); 2 = fp32 products
+        as six exact bf16 x bf16 products where the library has a kernel for the shape, the fp32 MFMA otherwise
+        (compute_dtype "f32", the default); 0 = fp32 MFMA only (compute_dtype "f32-mfma")."""
+        if self.bf16:
+            return 1 if hip.bf16_conv_ok(lda, ci, co, 0) else self.fp32_precision
+        return self.fp32_precision
 
     def prec_wgrad(self, ldx, lddy, ci, co):
-        return 1 if self.bf16 and hip.bf16_wgrad_ok(ldx, lddy, ci, co) else 0
+        if self.bf16 and hip.bf16_wgrad_ok(ldx, lddy, ci, co):
+            return 1
+        return self.fp32_precision
 
     def dgrad_operands(self, key, w_oihw, w_packed, co, ci, kh, kw, kscale, lddy):
         """(weights, kscale, precision) of a data-gradient launch: the bf16 path contracts over Cout with the
@@ -271,7 +278,7 @@ class RT:
                 hip.pack_weight_t(w_oihw, kscale, wt, co, ci, kh, kw)
                 self.packed_t[ck] = wt
             return wt, None, 1
-        return w_packed, kscale, 0
+        return w_packed, kscale, self.fp32_precision
 
     def pgrad(self, param):
         """(gradient buffer, accumulate flag) for a parameter; None if it needs no gradient."""
@@ -1241,7 +1248,11 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         rt = RT(x.device, model.training, record)
         rt.concurrent = bool(getattr(model, "concurrent", True))
         rt.pair_streams = bool(getattr(model, "pair_streams", True))
-        rt.bf16 = str(getattr(model, "compute_dtype", "f32")).lower() in ("bf16", "bfloat16", "torch.bfloat16")
+        cd = str(getattr(model, "compute_dtype", "f32")).lower()
+        if cd not in ("f32", "fp32", "float32", "torch.float32", "f32-mfma", "bf16", "bfloat16", "torch.bfloat16"):
+            raise RuntimeError(f"compute_dtype {cd!r}: expected 'f32', 'f32-mfma' or 'bf16'")
+        rt.bf16 = cd in ("bf16", "bfloat16", "torch.bfloat16")
+        rt.fp32_precision = 0 if cd == "f32-mfma" else 2
         rt.bucketer = getattr(model, "_grad_bucketer", None)
         rt.ready = [] if rt.bucketer is not None else None
         rt.on_param_grad = rt.ready.append if rt.bucketer is not None else None

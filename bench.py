@@ -216,8 +216,10 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the CPU baseline (default: --batch)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape kernel breakdown on stderr (tuning aid)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32 (headline metric, BASELINE configs[1]) or bf16-operand dense convs (configs[2..4])")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f32-mfma", "bf16"],
+                    help="f32 (headline metric, BASELINE configs[1]: fp32 tensors, fp32-accurate products -- six exact "
+                         "bf16 x bf16 products per fp32 product on the bf16 MFMA where a kernel exists, fp32 MFMA elsewhere), "
+                         "f32-mfma (fp32 MFMA only) or bf16-operand dense convs (configs[2..4])")
     ap.add_argument("--serial", action="store_true", help="one stream: no concurrent chains (diagnostic)")
     ap.add_argument("--no-pair", action="store_true",
                     help="image and radar chain of a stage as two launches on two streams instead of one two-stream launch (diagnostic)")
