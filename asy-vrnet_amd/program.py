@@ -57,6 +57,7 @@ class Act:
         return self.B * self.H * self.W
 
 
+ASIDE_LAG = int(os.environ.get("VRNET_ASIDE_LAG", "1"))           # tape closures a main-chain weight gradient may trail by
 WGRAD_STREAMS = int(os.environ.get("VRNET_WGRAD_STREAMS", "2"))   # side streams for weight gradients (measured: 2 < 1 < 4 ms/step)
 
 
@@ -129,6 +130,7 @@ class RT:
             fn()
         ent["streams"][aux] = True
         ent["keep"].extend(keep)
+        ent["keep"].append(fn)      # the closure too: it may own scratch buffers its kernels are still using
 
     def join_aside(self, lag=1):
         """End of a top-level tape closure: closes the closure's batch of aside work (events on the auxiliary streams it
@@ -137,9 +139,9 @@ class RT:
         if self._chain != "main":
             return []
         ent, self._aside_open = self._aside_open, None
-        fresh = self.ready if self.ready is not None else []
+        fresh = list(self.ready) if self.ready is not None else []
         if self.ready is not None:
-            self.ready = []
+            self.ready.clear()          # in place: rt.on_param_grad is this list's bound append
         evs = []
         if ent is not None:
             for st in ent["streams"]:
@@ -229,6 +231,17 @@ class RT:
     def new(self, B, H, W, C, need_grad=True):
         return Act(torch.empty((B, H, W, C), dtype=torch.float32, device=self.device), need_grad)
 
+    def new_pair(self, B2, H, W, C):
+        """Two-stream buffer (2B samples, image stream first).  Its gradient buffer is allocated HERE, on the main stream:
+        the two halves are written by different chains on different side streams (seg / det branch of the neck), and a
+        buffer allocated lazily inside one chain would come from that stream's allocator pool -- where it may alias a
+        tensor the OTHER chain is not ordered against."""
+        a = self.new(B2, H, W, C)
+        if self.record:
+            a.grad = self.buf(B2, H, W, C)
+            a.written = [False, False]
+        return a
+
     def buf(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
@@ -314,6 +327,9 @@ class RT:
             act.grad = self.buf(act.B, act.H, act.W, act.C)
             act.written = None
             return act.grad, 0
+        if act.written == [False, False]:     # pre-allocated two-stream buffer, nothing in it yet
+            act.written = None
+            return act.grad, 0
         _complete(act)
         return act.grad, 1
 
@@ -328,8 +344,8 @@ class RT:
             else:
                 hip.copy_channels(g, act.C, 1, buf, act.C, 1, act.rows, act.C)
             return
-        if act.grad is None:
-            act.grad = g
+        if act.grad is None or act.written == [False, False]:
+            act.grad = g                      # (a pre-allocated two-stream gradient buffer nobody has written: replace it)
             act.written = None
         else:
             _complete(act)
@@ -356,6 +372,9 @@ def take_grad(act):
         return par.grad[act.slot * n:(act.slot + 1) * n]
     g = act.grad
     if g is not None:
+        if act.written == [False, False]:     # pre-allocated two-stream buffer that received no gradient
+            act.grad = None
+            return None
         _complete(act)
     act.grad = None
     return g
@@ -489,7 +508,10 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
 def simple_conv(rt, x, conv, out=None):
     """Plain conv with bias (PointRecuder.proj): recorded on the tape.  conv may be a pair (two-stream launch)."""
     co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, _pair(conv)[0])
-    y = out if out is not None else rt.new(x.B, OH, OW, co)
+    if out is not None:
+        y = out
+    else:
+        y = rt.new_pair(x.B, OH, OW, co) if isinstance(conv, tuple) else rt.new(x.B, OH, OW, co)
     conv_call(rt, x, conv, y)
 
     def bwd():
@@ -1095,7 +1117,7 @@ def backbone_forward(rt, bb, x, r):
 
     def can_pair(h, w):          # rows of one stream must be whole 128-row tiles (true for every stage from 256 px at bs 2)
         return rt.pair_streams and (B * h * w) % 128 == 0
-    xr = rt.new(2 * B, H // 4, W // 4, dims[0])                  # stage-0 input: both patch embeddings
+    xr = rt.new_pair(2 * B, H // 4, W // 4, dims[0])             # stage-0 input: both patch embeddings
     xh, rh = xr.halves()
     rt.parallel([lambda: embed(xe, bb.patch_embed, out=xh), lambda: embed(re_, bb.patch_embed_radar, out=rh)])
     for i in range(4):
@@ -1108,7 +1130,7 @@ def backbone_forward(rt, bb, x, r):
             xi, ri = xr.halves()
             xs, rs = rt.parallel([lambda: chain(xi, bb.network[3 * i], pi), lambda: chain(ri, bb.network_radar[3 * i], pr)])
         if i < 3:                                                # fused maps go into the reducer's two-stream input
-            fused = rt.new(2 * B, xs.H, xs.W, xs.C)
+            fused = rt.new_pair(2 * B, xs.H, xs.W, xs.C)
             fx, fr = fused.halves()
         else:
             fx = fr = None
@@ -1122,7 +1144,7 @@ def backbone_forward(rt, bb, x, r):
             if can_pair(fused.H // 2, fused.W // 2):
                 xr = simple_conv(rt, fused, (ci, cr))
             else:
-                xr = rt.new(2 * B, fused.H // 2, fused.W // 2, dims[i + 1])
+                xr = rt.new_pair(2 * B, fused.H // 2, fused.W // 2, dims[i + 1])
                 ox, orr = xr.halves()
                 rt.parallel([lambda: simple_conv(rt, fx, ci, out=ox), lambda: simple_conv(rt, fr, cr, out=orr)])
             if i < 2:
@@ -1289,7 +1311,8 @@ def _mark_ready(rt, params, pos):
 def _take_ready(rt):
     if not rt.ready:
         return []
-    done, rt.ready = rt.ready, []
+    done = list(rt.ready)
+    rt.ready.clear()                    # in place: rt.on_param_grad is this list's bound append
     return done
 
 
@@ -1308,7 +1331,7 @@ def backward_range(rt, lo, hi, flush_each=False):
         for i in range(hi - 1, lo - 1, -1):
             rt.tape_pos = i
             rt.tape[i]()
-            done = rt.join_aside(0 if flush_each else 1)
+            done = rt.join_aside(0 if flush_each else ASIDE_LAG)
             if flush_each:
                 rt.flush_deferred_wgrads()
                 done += _take_ready(rt)
