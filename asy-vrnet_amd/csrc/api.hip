@@ -4,6 +4,13 @@
 #include <cstring>
 
 static thread_local char g_err[512] = "";
+static thread_local int g_last_kernel = 0;
+void vr_note_kernel(int id) { g_last_kernel = id; }
+// Which kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to (bench.py
+// prices each launch against the roofline of the kernel that actually ran):
+//   1 fp32 MFMA register-staged   2 fp32 MFMA LDS-DMA ring   3 bf16-rounded operands   4 direct (tiny channel counts)
+//   6 six exact bf16 x bf16 products per fp32 product (x6), LDS-DMA ring
+extern "C" int vrnet_last_kernel(void) { return g_last_kernel; }
 
 void vr_set_error(const char* fmt, ...) {
   va_list ap;

@@ -11,6 +11,7 @@
 #define VR_ERR_WORKSPACE 3
 
 void vr_set_error(const char* fmt, ...);
+void vr_note_kernel(int id);
 
 #define VR_CHECK_ARG(cond, ...)                 \
   do {                                          \

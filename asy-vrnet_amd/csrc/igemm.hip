@@ -1219,6 +1219,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                "conv2d: output size %dx%d inconsistent with input %dx%d k%d s%d p%d d%d", OH, OW, H, W, kh,
                stride, pad, dil);
   const bool plain = !ypre && !res && !kscale && !aux && !out_nchw && act == 0 && !stats && precision != 1 && !pair_rows;
+  vr_note_kernel(4);
   if (plain && tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride))
     return vr_tiny_conv(mode, a, lda, w, mode == 0 ? bias : nullptr, y, ldy, B, H, W, Cin, Cout, kh, pad, dil, accumulate,
                         vr_stream(stream));
@@ -1276,6 +1277,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
     p.perm2 = 0;
     p.pair_rows = pair_rows;
     vr_igemm_bf16_launch(&p, mode, st);
+    vr_note_kernel(3);
     VR_LAUNCH_CHECK("conv2d(bf16)");
     return VR_OK;
   }
@@ -1336,6 +1338,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
       dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt22));
       if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 2, 2, true>), grid, block, 0, st, p, (int)mt, (int)nt22);
       else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 2, 2, true>), grid, block, 0, st, p, (int)mt, (int)nt22);
+      vr_note_kernel(6);
       VR_LAUNCH_CHECK("conv2d(x6)");
       return VR_OK;
     }
@@ -1343,6 +1346,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
       dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt21));
       if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 2, 1, true>), grid, block, 0, st, p, (int)mt, (int)nt21);
       else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 2, 1, true>), grid, block, 0, st, p, (int)mt, (int)nt21);
+      vr_note_kernel(6);
       VR_LAUNCH_CHECK("conv2d(x6)");
       return VR_OK;
     }
@@ -1354,6 +1358,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
     // time there is not DMA latency but per-stage issue overhead, see the interleaved issue in the kernel)
     if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 1, 1>), grid, block, 0, st, p, MT, NT);
     else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 1, 1>), grid, block, 0, st, p, MT, NT);
+    vr_note_kernel(2);
     VR_LAUNCH_CHECK("conv2d");
     return VR_OK;
   }
@@ -1379,6 +1384,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   }
 #undef VR_IGEMM
 #undef VR_IGEMM_
+  vr_note_kernel(1);
   VR_LAUNCH_CHECK("conv2d");
   return VR_OK;
 }
@@ -1499,6 +1505,7 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   }
   VR_CHECK_ARG(streams == 1 || !tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride),
                "conv2d_wgrad: two-stream launch of a tiny-channel layer");
+  vr_note_kernel(4);
   if (tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride))
     return vr_tiny_wgrad(x, ldx, dy, lddy, dw, dbias, row_scale, B, H, W, Cin, Cout, kh, pad, dil, accumulate, workspace,
                          vr_stream(stream));
@@ -1552,6 +1559,7 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   else VR_WGRAD(128, 32, 1, 1, 4, 1);
   }
 #undef VR_WGRAD
+  vr_note_kernel(x6cfg ? 6 : (precision == 1 ? 3 : 1));
   VR_LAUNCH_CHECK("conv2d_wgrad");
   const bool rvec = (Cin % 4 == 0);                 // slabs are 16-byte aligned (workspace arena), rows of Cin floats
   const long total = (long)T * Cout * Cin / (rvec ? 4 : 1) + (dbias ? Cout : 0);

@@ -24,6 +24,7 @@ P, L, I, F, D = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float, ct
 _SIGS = {
     "vrnet_abi_version": ([], I),
     "vrnet_last_error": ([], ctypes.c_char_p),
+    "vrnet_last_kernel": ([], I),
     "vrnet_device_arch": ([ctypes.c_char_p, I], I),
     "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
@@ -95,6 +96,11 @@ def _check(rc, name):
 
 
 _DTYPES = frozenset((torch.float32, torch.float64, torch.uint8, torch.int64, torch.int32))
+
+
+def last_kernel():
+    """Kernel family of this thread's last conv2d / conv2d_wgrad call (include/vrnet_hip.h)."""
+    return _lib.vrnet_last_kernel()
 
 
 def ptr(t):

@@ -31,17 +31,42 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense bf16 MFMA (no sparsity)
+X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # fp32-equivalent FLOP/s of the x6 kernels: six bf16 MFMAs per fp32 product block
+# matrix-pipe ceiling per kernel family (hip.last_kernel()): fp32-equivalent TFLOP/s
+FAMILY_PEAK = {1: FP32_MFMA_PEAK_TFLOPS, 2: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS, 4: None, 6: X6_PEAK_TFLOPS}
+FAMILY_NAME = {1: "fp32 MFMA, register-staged", 2: "fp32 MFMA, LDS-DMA ring", 3: "bf16-rounded operands",
+               4: "direct (tiny channel counts, no MFMA)", 6: "x6: six exact bf16 x bf16 products per fp32 product"}
+
+
+def kernel_source_hash():
+    """Hash of the kernel sources: ties a committed PMC table to the build it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "asy-vrnet_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "asy-vrnet_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic_bytes(phi):
     """Average HBM bytes per igemm launch from the committed rocprofv3 PMC passes (profiles/; FETCH_SIZE doubled
-    for gfx950 as the MI355X guide prescribes, separate --pmc passes).  None when no profile matches this run."""
+    for gfx950 as the MI355X guide prescribes, separate --pmc passes).  The table carries the hash of the kernel
+    sources it was measured on (<csv>.meta.json, written by tools/pmc_traffic.sh): None when no table exists or when
+    the kernels have changed since -- a stale table is never reported."""
     import csv
     import glob
     if phi != "l":
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc_phi-l_bs8_512.csv")))
     if not files:
+        return None
+    try:
+        meta = json.load(open(files[-1] + ".meta.json"))
+    except (OSError, ValueError):
+        return None
+    if meta.get("kernel_source_hash") != kernel_source_hash():
         return None
     n, tot = 0, 0.0
     for row in csv.DictReader(open(files[-1])):
@@ -96,7 +121,8 @@ class ConvTimer:
             o_conv(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, *rest, **kw_)
             e1.record()
             rec["igemm"].append((conv_flops(B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil), e0, e1,
-                                 f"M{B*OH*OW} N{Cout} K{Cin}x{kh}x{kw}" + (f"d{dil}" if dil > 1 else "")))
+                                 f"M{B*OH*OW} N{Cout} K{Cin}x{kh}x{kw}" + (f"d{dil}" if dil > 1 else "") + f" k{hip.last_kernel()}",
+                                 hip.last_kernel()))
 
         def conv2d_wgrad(x, ldx, dy, lddy, dw, db, rs, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, *rest, **kw_):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -104,7 +130,8 @@ class ConvTimer:
             o_wgrad(x, ldx, dy, lddy, dw, db, rs, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, *rest, **kw_)
             e1.record()
             rec["wgrad"].append((conv_flops(B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil), e0, e1,
-                                 f"M{B*OH*OW} N{Cout} K{Cin}x{kh}x{kw}" + (f"d{dil}" if dil > 1 else "")))
+                                 f"M{B*OH*OW} N{Cout} K{Cin}x{kh}x{kw}" + (f"d{dil}" if dil > 1 else "") + f" k{hip.last_kernel()}",
+                                 hip.last_kernel()))
         def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold, **kw_):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -131,11 +158,25 @@ class ConvTimer:
         ms = sum(x[1].elapsed_time(x[2]) for x in r)
         return len(r), flops, ms
 
+    def by_family(self, key):
+        """{kernel family: [launches, flops, ms]} and the matrix-pipe-ideal time of the mix (ms)."""
+        torch.cuda.synchronize()
+        fam, ideal = {}, 0.0
+        for x in self.rec[key]:
+            a = fam.setdefault(x[4], [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += x[0]
+            a[2] += x[1].elapsed_time(x[2])
+            pk = FAMILY_PEAK.get(x[4])
+            if pk:
+                ideal += x[0] / (pk * 1e12) * 1e3
+        return fam, ideal
+
     def detail(self, key, unit_scale, unit):
         """Per-shape breakdown (stderr aid for tuning): launches, total ms, achieved rate."""
         torch.cuda.synchronize()
         agg = {}
-        for work, e0, e1, tag in self.rec[key]:
+        for work, e0, e1, tag, *_ in self.rec[key]:
             a = agg.setdefault(tag, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += work
@@ -318,6 +359,8 @@ def main():
                 eager_step(args.warmup + i)
             n, flops, ms = ct.summary("igemm")
             nw, fw, msw = ct.summary("wgrad")
+            fam, ideal_ms = ct.by_family("igemm")
+            _, ideal_w = ct.by_family("wgrad")
             ncf, bcf, mscf = ct.summary("cluster_fwd")
             ncb, bcb, mscb = ct.summary("cluster_bwd")
             if args.detail:
@@ -328,20 +371,30 @@ def main():
         model.concurrent = True
         ach = flops / (ms * 1e-3) / 1e12
         bf16 = args.dtype == "bf16"
-        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
-        kern = ("igemm_bf16_kernel (implicit-GEMM conv forward + data-gradient, operands rounded to bf16 when staged, "
-                "v_mfma_f32_32x32x16_bf16, fp32 accumulate)") if bf16 else (
-            "igemm_dma_kernel + igemm_kernel (implicit-GEMM conv forward + data-gradient, v_mfma_f32_32x32x2_f32; "
-            "LDS-DMA ring / register-staged variants)")
+        # Matrix-pipe ceiling of the dominant kernel class = FLOP-weighted over the kernel families that actually ran
+        # (hip.last_kernel() per launch): x6 launches are priced against bf16 peak / 6 products = 416.7 TFLOP/s of
+        # fp32-equivalent work, fp32-MFMA launches against 157.3, bf16-operand launches against 2500.
+        peak = flops / (ideal_ms * 1e-3) / 1e12 if ideal_ms > 0 else FP32_MFMA_PEAK_TFLOPS
+        fam_rep = {FAMILY_NAME.get(k, str(k)): {"launches_per_step": v[0] // args.steps, "share_of_flops": round(v[1] / flops, 4),
+                                               "achieved": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None,
+                                               "peak": FAMILY_PEAK.get(k)} for k, v in sorted(fam.items())}
+        kern = ("implicit-GEMM conv forward + data-gradient (igemm_dma_kernel / igemm_kernel / igemm_bf16_kernel): per launch "
+                "the library picks x6 (fp32 products as six exact bf16 x bf16 products on v_mfma_f32_32x32x16_bf16, fp32 "
+                "accumulate), the fp32 MFMA (v_mfma_f32_32x32x2_f32) or, with --dtype bf16, bf16-rounded operands; "
+                "`families` lists what ran")
         roof = {"bound": "mfma", "kernel": kern,
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
                 "frac": round(ach / peak, 4),
+                "peak_note": "FLOP-weighted matrix-pipe ceiling of the kernel mix that ran (x6 416.7 = bf16 2500 / 6; fp32 MFMA 157.3)",
+                "achieved_over_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                "families": fam_rep,
                 "traffic": pmc_traffic_bytes(args.phi) if (args.batch == 8 and args.size == 512 and not bf16) else None,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/; null unless measured on this exact kernel source)",
                 "launches_per_step": n // args.steps, "avg_launch_us": round(1e3 * ms / n, 2),
                 "avg_launch_gflop": round(flops / n / 1e9, 3),
                 "share_of_step": round(ms / args.steps / ms_per_step, 3),
                 "wgrad": {"achieved": round(fw / (msw * 1e-3) / 1e12, 2), "launches_per_step": nw // args.steps,
+                          "peak": round(fw / (ideal_w * 1e-3) / 1e12, 1) if ideal_w > 0 else None,
                           "share_of_step": round(msw / args.steps / ms_per_step, 3)},
                 # the HBM-bound Context-Cluster kernels: algorithmic bytes (3 resp. 5 tensors of B*P*E*D fp32) / time
                 "cluster_hbm": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s",

@@ -23,6 +23,10 @@ extern "C" {
 
 /* ---- library ------------------------------------------------------------------------------------- */
 int vrnet_abi_version(void);                 /* == 3 */
+/* Kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to: 1 fp32 MFMA
+ * (register-staged), 2 fp32 MFMA (LDS-DMA ring), 3 bf16-rounded operands, 4 direct kernels for tiny channel counts,
+ * 6 "x6": every fp32 product as six exact bf16 x bf16 products on the bf16 MFMA, fp32 accumulate. */
+int vrnet_last_kernel(void);
 const char* vrnet_last_error(void);          /* host string, thread local */
 int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sramecc+:xnack-" (synchronous) */
 

@@ -39,3 +39,5 @@ with open(dst, "w") as fo:
         fo.write(f"\"{k}\",{n},{f:.0f},{w:.0f},{(f + w) / 1024:.2f}\n")
 print(open(dst).read()[:1500])
 PY
+# the hash of the kernel sources this table was measured on: bench.py reports roofline.traffic only while it matches
+python3 -c "import json, sys; sys.path.insert(0, '.'); import bench; json.dump({'kernel_source_hash': bench.kernel_source_hash()}, open('$1.meta.json', 'w'))"
