@@ -306,6 +306,13 @@ __device__ __forceinline__ void vr_split3(const f32x4 lo4, const f32x4 hi4, vr_b
   out[2] = __builtin_bit_cast(vr_bf16x8, q2);
 }
 
+// one bf16 value per operand, round-to-nearest-even (v_cvt_pk_bf16_f32): the "bf16 with MFMA conv path" of BASELINE configs[2..4]
+__device__ __forceinline__ vr_bf16x8 vr_round8(const f32x4 lo4, const f32x4 hi4) {
+  const vr_bf16x8 r = {(__bf16)lo4[0], (__bf16)lo4[1], (__bf16)lo4[2], (__bf16)lo4[3],
+                       (__bf16)hi4[0], (__bf16)hi4[1], (__bf16)hi4[2], (__bf16)hi4[3]};
+  return r;
+}
+
 __device__ __forceinline__ f32x16 vr_mfma_x6(const vr_bf16x8 (&a)[3], const vr_bf16x8 (&b)[3], f32x16 c) {
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);      // small terms first
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
@@ -321,7 +328,7 @@ __device__ __forceinline__ f32x16 vr_mfma_x6(const vr_bf16x8 (&a)[3], const vr_b
 // whose grid still fills the chip with 128-row tiles.  Both stage 16 KB per K step.
 // Asymmetric tiles (TM != TN, e.g. 128 x 64 x 16) serve outputs of 64 / 192 / 320 channels and grids that 128 x 128
 // tiles would leave half empty.
-template <int MODE, int NST, int TM, int TN, bool X6 = false>
+template <int MODE, int NST, int TM, int TN, int PROD = 0>      // PROD: 0 fp32 MFMA, 6 x6, 1 bf16-rounded operands
 __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_dma_kernel(const IgemmArgs p_in, int MT, int NT) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = (TM == 1 && TN == 1) ? 32 : 16;
   constexpr int QPR = BK / 4;                       // 16-byte quads per K-contiguous row of a stage
@@ -593,7 +600,30 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     if (blockIdx.x == 8 && tid == 0 && s < 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp[4 * s + 1] = __builtin_amdgcn_s_memtime(); }
 #endif
     constexpr int GROUPS = KQ >= 4 ? 4 : KQ;          // MFMA groups that each carry DMA pieces behind them
-    if constexpr (X6) {
+    if constexpr (PROD == 1) {
+      constexpr int NK16 = KQ / 2;
+      static_assert(KQ % 2 == 0, "bf16 MFMA needs whole k16 steps");
+#pragma unroll
+      for (int ks = 0; ks < NK16; ++ks) {
+        vr_bf16x8 a1[TM], b1[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a1[i] = vr_round8(af[i][2 * ks], af[i][2 * ks + 1]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) b1[i] = vr_round8(bq[i][2 * ks], bq[i][2 * ks + 1]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[jn], acc[i][jn], 0, 0, 0);
+        if (more) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < NP; ++q)
+            if (q % NK16 == ks) issue_piece(q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else if constexpr (PROD == 6) {
       // lane h owns k = (BK/2) h .. + BK/2 - 1 of the stage: 8 consecutive values per k16 step of the bf16 MFMA
       constexpr int NK16 = KQ / 2;
       static_assert(KQ % 2 == 0, "x6 needs whole k16 steps");
@@ -923,7 +953,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradArgs p) {
 // by LDS-DMA into a 3-stage ring; the fragments (8 consecutive rows of one channel) are columns of the staged tiles, read
 // with conflict-free ds_read_b32 (lanes = consecutive channels) and split in registers.  Same slabs / reduce pass as the
 // other weight-gradient kernels.
-template <int TN, int TC, bool IDENT>
+template <int TN, int TC, bool IDENT, int PROD>      // PROD: 6 = x6, 1 = bf16-rounded operands (one product)
 __global__ __launch_bounds__(256, 3) void wgrad_x6_kernel(const WgradArgs p) {
   constexpr int BKD = 16, NST = 3, BN = 64 * TN, BC = 64 * TC;
   constexpr int Y_FLOATS = BKD * BN, X_FLOATS = BKD * BC, ST_FLOATS = Y_FLOATS + X_FLOATS;
@@ -1022,7 +1052,8 @@ __global__ __launch_bounds__(256, 3) void wgrad_x6_kernel(const WgradArgs p) {
 #pragma unroll
       for (int k = 0; k < BKD; ++k) bsum += Ys[k * BN + tid];
     }
-    vr_bf16x8 a3[TN][3], b3[TC][3];
+    constexpr int NPL = PROD == 6 ? 3 : 1;
+    vr_bf16x8 a3[TN][NPL], b3[TC][NPL];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       f32x4 lo, hi;
@@ -1031,7 +1062,8 @@ __global__ __launch_bounds__(256, 3) void wgrad_x6_kernel(const WgradArgs p) {
         lo[e] = Ys[(8 * h + e) * BN + arow + 32 * i];
         hi[e] = Ys[(8 * h + 4 + e) * BN + arow + 32 * i];
       }
-      vr_split3(lo, hi, a3[i]);
+      if constexpr (PROD == 6) vr_split3(lo, hi, a3[i]);
+      else a3[i][0] = vr_round8(lo, hi);
     }
 #pragma unroll
     for (int j = 0; j < TC; ++j) {
@@ -1041,12 +1073,16 @@ __global__ __launch_bounds__(256, 3) void wgrad_x6_kernel(const WgradArgs p) {
         lo[e] = Xs[(8 * h + e) * BC + bcol + 32 * j];
         hi[e] = Xs[(8 * h + 4 + e) * BC + bcol + 32 * j];
       }
-      vr_split3(lo, hi, b3[j]);
+      if constexpr (PROD == 6) vr_split3(lo, hi, b3[j]);
+      else b3[j][0] = vr_round8(lo, hi);
     }
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
-      for (int j = 0; j < TC; ++j) acc[i][j] = vr_mfma_x6(a3[i], b3[j], acc[i][j]);
+      for (int j = 0; j < TC; ++j) {
+        if constexpr (PROD == 6) acc[i][j] = vr_mfma_x6(a3[i], b3[j], acc[i][j]);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][0], b3[j][0], acc[i][j], 0, 0, 0);
+      }
     if (++cur == NST) cur = 0;
   }
   const long T = (long)p.kh * p.kw;
@@ -1198,6 +1234,27 @@ static bool tiny_shape(int H, int W, int Cin, int OH, int OW, int Cout, int kh, 
   return Cin <= 8 && Cout <= 8 && stride == 1 && kh == kw && (kh == 1 || kh == 3) && OH == H && OW == W;
 }
 
+// Tile of the LDS-DMA x6 / bf16 kernels for a GEMM of M rows and CN columns: 22 = 128 x 128, 21 = 128 x 64, 0 = none
+// (too few tiles to fill the chip, or <= 32 columns).
+static int vr_dma_tile(long M, int CN) {
+  static const int min_n = getenv("VRNET_X6_MIN_N") ? atoi(getenv("VRNET_X6_MIN_N")) : 96;
+  static const int min_tiles = getenv("VRNET_X6_MIN_TILES") ? atoi(getenv("VRNET_X6_MIN_TILES")) : 256;
+  static const int force = getenv("VRNET_X6_TILE") ? atoi(getenv("VRNET_X6_TILE")) : 0;     // tuning aid: 22 / 21
+  const long mt = vr_cdiv(M, 128), nt22 = vr_cdiv(CN, 128), nt21 = vr_cdiv(CN, 64);
+  const bool waste22 = nt22 * 128 - CN > 16 * nt22;          // more than 12 % of the column tiles is padding
+  int tile = 0;
+  if (CN >= min_n && mt * nt22 >= 2 * min_tiles && !waste22) tile = 22;
+  else if (CN > 32 && mt * nt21 >= min_tiles) tile = 21;
+  else if (CN >= min_n && mt * nt22 >= min_tiles) tile = 22;
+  if (force && tile) tile = force;
+  return tile;
+}
+
+/* Which LDS-DMA tile vrnet_conv2d_f32 would use at precision 2 / 3 for B*MH*MW GEMM rows and CN GEMM columns (mode 0:
+ * output pixels x Cout; mode 1: input pixels x Cin): 22, 21 or 0 = none (precision 3 is then rejected, precision 2 falls
+ * back to the fp32 MFMA).  Alignment requirements (16-byte rows, channel counts % 4) are the caller's, as for precision 1. */
+extern "C" int vrnet_conv2d_dma_tile(long rows, int cols) { return vr_dma_tile(rows, cols); }
+
 extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias, float* y, long ldy,
                                 int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride,
                                 int pad, int dil, int mode, int act, float* ypre, long ldypre, const float* res,
@@ -1210,8 +1267,8 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                                                      (!res_scale == !res_scale2) && (!kscale == !kscale2))),
                "conv2d: a two-stream launch needs the second parameter set and a first-stream row count that is a "
                "multiple of 128");
-  VR_CHECK_ARG(precision >= 0 && precision <= 2, "conv2d: precision 0 (fp32 MFMA), 1 (bf16 operands, fp32 accumulate) or 2 "
-                                                 "(fp32 products as six bf16 x bf16 products, fp32 accumulate)");
+  VR_CHECK_ARG(precision >= 0 && precision <= 3, "conv2d: precision 0 (fp32 MFMA), 1 / 3 (bf16 operands, fp32 accumulate) "
+                                                 "or 2 (fp32 products as six bf16 x bf16 products, fp32 accumulate)");
   VR_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0, "conv2d: bad shape");
   VR_CHECK_ARG(kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d: bad geometry");
   VR_CHECK_ARG((H + 2 * pad - dil * (kh - 1) - 1) / stride + 1 == OH &&
@@ -1268,7 +1325,11 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
 #endif
   dim3 block(256);
   hipStream_t st = vr_stream(stream);
-  if (precision == 1) {
+  // bf16-rounded operands: the forward launches whose grid fills the chip run on the LDS-DMA tile kernels below (as do
+  // data gradients at precision 3, standard weight layout); everything else on the register-staged bf16 kernel
+  const bool bf16_tile_fwd = precision == 1 && mode == 0 && p.a_vec && p.b_vec && p.CN > 32 && vr_dma_tile(M, p.CN) != 0 &&
+                             (!pair_rows || pair_rows % 128 == 0);
+  if (precision == 1 && !bf16_tile_fwd) {
     // bf16 operands: both operands must be contraction-contiguous 16-byte rows; in mode 1 `w` is the TRANSPOSED pack
     // (vrnet_pack_weight_t_f32, which also folds kscale in), so kscale must not be passed again
     VR_CHECK_ARG(p.a_vec && p.CK % 4 == 0 && vr_aligned16(w) && p.CN > 32 && !kscale,
@@ -1323,34 +1384,33 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   const bool dma_shape = use_dma == 2 || M <= 8192 || (M <= 32768 && ktot >= 1024);
   // precision 2 (x6): 128 x 128 x 16 ring tiles with 2 x 2 accumulators per wave -- each split fragment feeds two
   // MFMA groups, which is what pays for the split (on 64 x 64 tiles the conversions cost what the faster MFMA saves)
-  static const int x6_min_n = getenv("VRNET_X6_MIN_N") ? atoi(getenv("VRNET_X6_MIN_N")) : 96;
-  static const int x6_min_tiles = getenv("VRNET_X6_MIN_TILES") ? atoi(getenv("VRNET_X6_MIN_TILES")) : 256;
-  static const int x6_tile = getenv("VRNET_X6_TILE") ? atoi(getenv("VRNET_X6_TILE")) : 0;     // tuning aid: 22 / 21
-  if (precision == 2 && dma_ok && (!pair_rows || p.pair_rows % 128 == 0)) {
+  const bool bf16_tiles = precision == 3 || (precision == 1 && mode == 0);   // (mode 1 at precision 1 brings the transposed pack)
+  if ((precision == 2 || bf16_tiles) && dma_ok && (!pair_rows || p.pair_rows % 128 == 0)) {
     const long mt = vr_cdiv(M, 128), nt22 = vr_cdiv(p.CN, 128), nt21 = vr_cdiv(p.CN, 64);
-    const bool waste22 = nt22 * 128 - p.CN > 16 * nt22;          // more than 12 % of the column tiles is padding
-    int tile = 0;
-    if (p.CN >= x6_min_n && mt * nt22 >= 2 * x6_min_tiles && !waste22) tile = 22;
-    else if (p.CN > 32 && mt * nt21 >= x6_min_tiles) tile = 21;
-    else if (p.CN >= x6_min_n && mt * nt22 >= x6_min_tiles) tile = 22;
-    if (x6_tile && tile) tile = x6_tile;
-    if (tile == 22) {
-      dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt22));
-      if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 2, 2, true>), grid, block, 0, st, p, (int)mt, (int)nt22);
-      else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 2, 2, true>), grid, block, 0, st, p, (int)mt, (int)nt22);
-      vr_note_kernel(6);
-      VR_LAUNCH_CHECK("conv2d(x6)");
+    const int tile = vr_dma_tile(M, p.CN);
+#define VR_TILE_LAUNCH(PR)                                                                                              \
+  do {                                                                                                                  \
+    if (tile == 22) {                                                                                                   \
+      dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt22));                                                                 \
+      if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 2, 2, PR>), grid, block, 0, st, p, (int)mt, (int)nt22); \
+      else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 2, 2, PR>), grid, block, 0, st, p, (int)mt, (int)nt22);           \
+    } else {                                                                                                            \
+      dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt21));                                                                 \
+      if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 2, 1, PR>), grid, block, 0, st, p, (int)mt, (int)nt21); \
+      else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 2, 1, PR>), grid, block, 0, st, p, (int)mt, (int)nt21);           \
+    }                                                                                                                   \
+  } while (0)
+    if (tile) {
+      if (precision == 2) VR_TILE_LAUNCH(6);
+      else VR_TILE_LAUNCH(1);
+      vr_note_kernel(precision == 2 ? 6 : 3);
+      VR_LAUNCH_CHECK("conv2d(dma tiles)");
       return VR_OK;
     }
-    if (tile == 21) {
-      dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt21));
-      if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 2, 1, true>), grid, block, 0, st, p, (int)mt, (int)nt21);
-      else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 2, 1, true>), grid, block, 0, st, p, (int)mt, (int)nt21);
-      vr_note_kernel(6);
-      VR_LAUNCH_CHECK("conv2d(x6)");
-      return VR_OK;
-    }
+#undef VR_TILE_LAUNCH
   }
+  VR_CHECK_ARG(precision != 3, "conv2d: precision 3 (bf16-rounded operands on the LDS-DMA tiles, standard weight layout) has "
+                               "no kernel for this shape / alignment: ask vrnet_conv2d_dma_tile first");
   if (dma_ok && dma_shape) {
     const int MT = (int)vr_cdiv(M, 64), NT = (int)vr_cdiv(p.CN, 64);
     dim3 grid((unsigned)(8 * vr_cdiv(MT, 8) * NT));
@@ -1493,9 +1553,9 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   const bool vec_all = (Cin % 4 == 0) && (ldx % 4 == 0) && vr_aligned16(x) && (Cout % 4 == 0) && (lddy % 4 == 0) &&
                        vr_aligned16(dy);
   int x6cfg = 0;
-  if (precision == 2) {
+  if (precision == 2 || precision == 1) {      // the tile kernels: x6, or (precision 1) bf16-rounded operands
     if (vec_all) wgrad_plan(M / streams, Cin, Cout, T, &x6cfg, &bn, &nt, &ct, &S, &rows, 2);
-    if (!x6cfg) precision = 0;       // no x6 kernel for this shape: the fp32 MFMA path
+    if (!x6cfg && precision == 2) precision = 0;       // no tile kernel for this shape: the fp32 MFMA path
   }
   if (!x6cfg) wgrad_plan(M / streams, Cin, Cout, T, &cfg, &bn, &nt, &ct, &S, &rows, precision == 1);
   const long need = vrnet_conv2d_wgrad_workspace(B, OH, OW, Cin, Cout, kh, kw, streams == 2);
@@ -1533,10 +1593,15 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   } while (0)
   VR_CHECK_ARG(precision >= 0 && precision <= 2, "conv2d_wgrad: precision 0 (fp32 MFMA), 1 (bf16 operands) or 2 (x6)");
   if (x6cfg) {
-#define VR_WX6(TN_, TC_)                                                                                    \
-  do {                                                                                                      \
-    if (ident) hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, true>), grid, block, 0, st, p);                \
-    else hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, false>), grid, block, 0, st, p);                     \
+#define VR_WX6(TN_, TC_)                                                                                            \
+  do {                                                                                                              \
+    if (precision == 2) {                                                                                           \
+      if (ident) hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, true, 6>), grid, block, 0, st, p);                   \
+      else hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, false, 6>), grid, block, 0, st, p);                        \
+    } else {                                                                                                        \
+      if (ident) hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, true, 1>), grid, block, 0, st, p);                   \
+      else hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, false, 1>), grid, block, 0, st, p);                        \
+    }                                                                                                               \
   } while (0)
     if (x6cfg == 22) VR_WX6(2, 2);
     else if (x6cfg == 21) VR_WX6(2, 1);
@@ -1559,7 +1624,7 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   else VR_WGRAD(128, 32, 1, 1, 4, 1);
   }
 #undef VR_WGRAD
-  vr_note_kernel(x6cfg ? 6 : (precision == 1 ? 3 : 1));
+  vr_note_kernel(x6cfg ? (precision == 2 ? 6 : 3) : (precision == 1 ? 3 : 1));
   VR_LAUNCH_CHECK("conv2d_wgrad");
   const bool rvec = (Cin % 4 == 0);                 // slabs are 16-byte aligned (workspace arena), rows of Cin floats
   const long total = (long)T * Cout * Cin / (rvec ? 4 : 1) + (dbias ? Cout : 0);

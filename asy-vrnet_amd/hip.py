@@ -28,6 +28,7 @@ _SIGS = {
     "vrnet_device_arch": ([ctypes.c_char_p, I], I),
     "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
+    "vrnet_conv2d_dma_tile": ([L, I], I),
     "vrnet_conv2d_wgrad_workspace": ([I] * 8, L),
     "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 14 + [P, P, P, P, P, P, P, P, P, P, L, P], I),
     "vrnet_pack_weight_f32": ([P, P, I, I, I, I, P], I),
@@ -167,6 +168,11 @@ def bf16_conv_ok(lda, Cin, Cout, mode):
     """Shapes the bf16-operand path of conv2d accepts (mirrors the check in vrnet_conv2d_f32)."""
     ck, cn = (Cin, Cout) if mode == 0 else (Cout, Cin)
     return ck % 4 == 0 and lda % 4 == 0 and cn > 32 and cn % 4 == 0
+
+
+def conv2d_dma_tile(rows, cols):
+    """22 / 21 / 0: tile of the LDS-DMA x6 / bf16 kernels for a GEMM of rows x cols (0 = no such kernel)."""
+    return _lib.vrnet_conv2d_dma_tile(rows, cols)
 
 
 def pack_weight_t(w_oihw, kscale, out, Cout, Cin, kh, kw):

@@ -280,10 +280,12 @@ class RT:
             return 1
         return self.fp32_precision
 
-    def dgrad_operands(self, key, w_oihw, w_packed, co, ci, kh, kw, kscale, lddy):
+    def dgrad_operands(self, key, w_oihw, w_packed, co, ci, kh, kw, kscale, lddy, rows=None):
         """(weights, kscale, precision) of a data-gradient launch: the bf16 path contracts over Cout with the
         TRANSPOSED pack [t][Cin][Cout], into which kscale is folded."""
         if self.bf16 and hip.bf16_conv_ok(lddy, ci, co, 1):
+            if rows is not None and (kscale is None or co <= 1024) and hip.conv2d_dma_tile(rows, ci):
+                return w_packed, kscale, 3        # LDS-DMA tile kernel: standard weight layout, kscale applied in the kernel
             ck = (key, None if kscale is None else kscale.data_ptr())
             wt = self.packed_t.get(ck)
             if wt is None:
@@ -494,10 +496,11 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
             buf, acc = rt.grad_target(x)
             ld = x.C
         ks0, ks1 = _pair(kscale) if kscale is not None else (None, None)
-        wd, ks, prec = rt.dgrad_operands(c0, c0.weight, rt.weight(c0), co, ci, kh, kw, ks0, lddy)
+        rows = x.B * x.H * x.W if not isinstance(conv, tuple) or (x.B // 2) * x.H * x.W % 128 == 0 else None
+        wd, ks, prec = rt.dgrad_operands(c0, c0.weight, rt.weight(c0), co, ci, kh, kw, ks0, lddy, rows)
         kw2 = {}
         if c1 is not None:
-            wd1, ks1, prec1 = rt.dgrad_operands(c1, c1.weight, rt.weight(c1), co, ci, kh, kw, ks1, lddy)
+            wd1, ks1, prec1 = rt.dgrad_operands(c1, c1.weight, rt.weight(c1), co, ci, kh, kw, ks1, lddy, rows)
             assert prec1 == prec
             kw2 = dict(pair_rows=(x.B // 2) * x.H * x.W, w2=wd1, kscale2=ks1)
         hip.conv2d(dy, lddy, wd, None, buf, ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=1,
@@ -739,10 +742,10 @@ def cluster_block(rt, x, m, name=None):
                     rt.on_param_grad(t.sim_beta)
         _fused_qkv_wgrad(rt, tm, xn, dfv)
         dxn = rt.new(B, H, W, C)                                 # d xn = [df | dv] . [fc1 ; fc_v]: one data-gradient GEMM
-        wd, _, prec = rt.dgrad_operands(tm0, wcat, wcat, 2 * ED, C, 1, 1, None, 2 * ED)
+        wd, _, prec = rt.dgrad_operands(tm0, wcat, wcat, 2 * ED, C, 1, 1, None, 2 * ED, B * H * W)
         kwd = {}
         if paired:
-            wd1, _, _ = rt.dgrad_operands(tm1, tm1._fused_qkv[0], tm1._fused_qkv[0], 2 * ED, C, 1, 1, None, 2 * ED)
+            wd1, _, _ = rt.dgrad_operands(tm1, tm1._fused_qkv[0], tm1._fused_qkv[0], 2 * ED, C, 1, 1, None, 2 * ED, B * H * W)
             kwd = dict(pair_rows=rows_half, w2=wd1)
         hip.conv2d(dfv.t, 2 * ED, wd, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1, precision=prec, **kwd)
         dx = rt.buf(B, H, W, C)

@@ -43,7 +43,11 @@ int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sram
  *   act: 1 ReLU, 2 exact-erf GELU;  v = res[m,n] + res_scale[n] * v (layer-scale residual, vr_coc.py:266-271);
  *   store NHWC y[m*ldy+n] or NCHW y[b][out_coff+n][pix] of a (B,out_ctot,OH,OW) tensor (head cat, decouplehead.py:86).
  * kscale[k]: multiplies the contraction channels of `a` (layer scale folded into the data gradient).
- * precision: 0 = fp32 operands on v_mfma_f32_32x32x2_f32 (the parity path); 1 = operands rounded to bf16 while staged,
+ * precision: 2 = every fp32 product as six exact bf16 x bf16 products (operands split into three bf16 values each,
+ *   a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1 on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32 rounding-level error,
+ *   2.7x the matrix rate of the fp32 MFMA) on the LDS-DMA tile kernels where vrnet_conv2d_dma_tile() != 0, the fp32 MFMA
+ *   elsewhere -- the default of the fp32 path; 3 = bf16-rounded operands on those tile kernels, standard weight layout;
+ *   0 = fp32 operands on v_mfma_f32_32x32x2_f32 only; 1 = operands rounded to bf16 while staged,
  *   v_mfma_f32_32x32x16_bf16, fp32 accumulate and epilogue (BASELINE configs "bf16 with MFMA conv path"): needs
  *   16-byte rows, Cin % 4 == 0 (mode 0) / Cout % 4 == 0 (mode 1), > 32 GEMM columns, and in mode 1 `w` =
  *   vrnet_pack_weight_t_f32's [kh*kw][Cin][Cout] pack with kscale folded in (kscale itself must then be NULL).
@@ -54,6 +58,11 @@ int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sram
  *   shapes on their own parameters (vr_coc.py:589-600: network[idx](x), network_radar[idx](x_radar)); with both
  *   streams stacked along the batch, GEMM rows < pair_rows use (w, bias, res_scale, kscale) and rows >= pair_rows use
  *   (w2, bias2, res_scale2, kscale2) -- one launch with twice the tiles instead of two.  pair_rows % 128 == 0. */
+/* Tile the LDS-DMA x6 / bf16 kernels would use for a GEMM of `rows` x `cols` (mode 0: output pixels x Cout; mode 1: input
+ * pixels x Cin): 22 (128 x 128), 21 (128 x 64) or 0 = no such kernel for the shape.  precision 2 falls back to the fp32
+ * MFMA by itself; precision 3 (bf16-rounded operands with the STANDARD weight layout in both modes, kscale allowed) is only
+ * accepted where this returns non-zero. */
+int vrnet_conv2d_dma_tile(long rows, int cols);
 int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias, float* y, long ldy,
                      int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride, int pad,
                      int dil, int mode, int act, float* ypre, long ldypre, const float* res, long ldres,
