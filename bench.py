@@ -262,8 +262,10 @@ def main():
                          "bf16 x bf16 products per fp32 product on the bf16 MFMA where a kernel exists, fp32 MFMA elsewhere), "
                          "f32-mfma (fp32 MFMA only) or bf16-operand dense convs (configs[2..4])")
     ap.add_argument("--serial", action="store_true", help="one stream: no concurrent chains (diagnostic)")
-    ap.add_argument("--no-pair", action="store_true",
-                    help="image and radar chain of a stage as two launches on two streams instead of one two-stream launch (diagnostic)")
+    ap.add_argument("--pair", action="store_true",
+                    help="image and radar chain of every backbone stage as ONE two-stream batch (one launch per layer) "
+                         "instead of two chains on two forked streams")
+    ap.add_argument("--no-pair", action="store_true", help="(default) two chains on two forked streams")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     args = ap.parse_args()
 
@@ -302,8 +304,7 @@ def main():
     model.compute_dtype = args.dtype
     if args.serial:
         model.concurrent = False
-    if args.no_pair:
-        model.pair_streams = False
+    model.pair_streams = bool(args.pair)
     net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 

@@ -100,9 +100,33 @@ def check_train_step_properties(A, net, batch, size, lin_tol, perm_tol):
     assert (num / den) ** 0.5 < perm_tol
 
 
-def test_bs8_train_step_is_repeatable_linear_and_permutation_equivariant(A, net):
-    """BASELINE configs[1]: phi=l, 512 px, bs 8, fp32."""
-    check_train_step_properties(A, net, 8, 512, lin_tol=1e-4, perm_tol=1e-3)
+@pytest.mark.parametrize("pair", [False, True])
+def test_bs8_train_step_is_repeatable_linear_and_permutation_equivariant(A, net, pair):
+    """BASELINE configs[1]: phi=l, 512 px, bs 8, fp32; pair = the two-stream chain mode (model.pair_streams)."""
+    net.pair_streams = pair
+    try:
+        check_train_step_properties(A, net, 8, 512, lin_tol=1e-4, perm_tol=1e-3)
+    finally:
+        net.pair_streams = False
+
+
+def test_x6_and_fp32_mfma_paths_agree(A, net):
+    """compute_dtype "f32" (fp32 products as six exact bf16 x bf16 products wherever a kernel exists) against
+    "f32-mfma" (the fp32 MFMA everywhere) on BASELINE configs[1] in eval mode (no BatchNorm batch statistics, so two
+    correct fp32 evaluations differ by rounding only -- unless a Cluster point is numerically tied, which moves single
+    pixels: compared by quantile)."""
+    net.eval()
+    x, r = A.synthetic_inputs(8, 512, 5, "cuda")
+    with torch.no_grad():
+        net.compute_dtype = "f32"
+        d6, s6 = net(x, r)
+        net.compute_dtype = "f32-mfma"
+        d0, s0 = net(x, r)
+        net.compute_dtype = "f32"
+    for a, b in list(zip(d6, d0)) + [(s6, s0)]:
+        e = ((a.double() - b.double()).abs() / b.double().abs().max()).flatten()
+        assert float(e.kthvalue(int(0.999 * e.numel()))[0]) < 1e-4, float(e.kthvalue(int(0.999 * e.numel()))[0])
+        assert float(e.max()) < 0.1
 
 
 def test_bs16_bf16_train_step_properties(A, net):

@@ -19,9 +19,11 @@ def A():
     return asy_vrnet_amd
 
 
-def build(A, phi, size, pseed, training):
+def build(A, phi, size, pseed, training, pair=False):
+    """pair: the image and the radar chain of every backbone stage as one two-stream batch (model.pair_streams)."""
     m = A.EfficientVRNet(4, 9, phi, img_size=size).cuda()
     A.randomize_state_dict(m.state_dict(), seed=pseed)
+    m.pair_streams = pair
     return m.train(training)
 
 
@@ -29,14 +31,16 @@ def build(A, phi, size, pseed, training):
     ("nano", 64, 2, True, (21, 31)), ("nano", 64, 2, False, (21, 31)), ("nano", 128, 2, True, (21, 31)),
     ("tiny", 128, 3, True, (21, 31)), ("nano", 256, 2, True, (21, 31)), ("l", 128, 2, True, (21, 31)),
     ("s", 128, 2, True, (21, 31)), ("m", 128, 2, True, (21, 31)), ("m", 128, 2, True, (3, 9)),
-    ("nano", 128, 2, True, (11, 5)), ("nano", 128, 2, True, (11, 6))])
+    ("nano", 128, 2, True, (11, 5)), ("nano", 128, 2, True, (11, 6)),
+    ("nano", 256, 2, True, (21, 31, "pair")), ("l", 128, 2, True, (21, 31, "pair")), ("nano", 128, 4, False, (21, 31, "pair")),
+    ("s", 256, 2, True, (3, 9, "pair"))])
 def test_against_oracle(A, phi, size, batch, training, seeds):
     """One seed pair for every width, nothing hand-picked: with (21, 31) phi=m has ONE BatchNorm+ReLU pre-activation (of
     98 304 in that layer) within fp32 rounding of zero whose mask bit differs between this path and the fp64 oracle;
     (11, 5) and (11, 6) are two more such cases found by a seed scan.  The comparison is ReLU-mask-aware (tests/parity.py,
     2b): the oracle takes the path's masks and every differing element must be within rounding of zero."""
     from tests.parity import compare_with_oracle
-    m = build(A, phi, size, seeds[0], training)
+    m = build(A, phi, size, seeds[0], training, pair=len(seeds) > 2)      # "pair": one two-stream chain per stage
     rep = compare_with_oracle(m, batch, size, iseed=seeds[1], check_grads=training, oracle_dtype=torch.float64)
     print(rep)
     assert rep["ok"], rep
@@ -115,8 +119,9 @@ def test_against_reference_golden(A, name, golden_dir):
                     assert rel_err(pd[k[2:]].grad, ref) < lim, (k, rel_err(pd[k[2:]].grad, ref))
 
 
+@pytest.mark.parametrize("pair", [False, True])
 @pytest.mark.parametrize("phi,size,batch", [("nano", 64, 2), ("nano", 256, 2), ("s", 128, 4)])
-def test_captured_step_equals_eager_step_bit_for_bit(A, phi, size, batch):
+def test_captured_step_equals_eager_step_bit_for_bit(A, phi, size, batch, pair):
     """graph.GraphedStep (what bench.py times) replays the same kernels as the eager step, with the chains really
     concurrent on their side streams: every parameter gradient, the loss and the BatchNorm statistics must equal the
     eager results exactly, replay after replay.  (This is the test that catches a missing stream dependency: the eager
@@ -126,12 +131,12 @@ def test_captured_step_equals_eager_step_bit_for_bit(A, phi, size, batch):
     def loss_of(det, seg):
         return sum((d * d).mean() for d in det) + (seg * seg).mean()
     x, r = A.synthetic_inputs(batch, size, 3, "cuda")
-    ref = build(A, phi, size, 7, True)
+    ref = build(A, phi, size, 7, True, pair)
     sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
     loss_ref = loss_of(*ref(x, r))
     loss_ref.backward()
     sd1 = {k: v.clone() for k, v in ref.state_dict().items()}
-    m = build(A, phi, size, 7, True)
+    m = build(A, phi, size, 7, True, pair)
     gs = GraphedStep(m, loss_of, batch, size, x.device, warmup=2)
     for rep in range(3):
         m.load_state_dict(sd0)
@@ -143,6 +148,54 @@ def test_captured_step_equals_eager_step_bit_for_bit(A, phi, size, batch):
                 assert torch.equal(p.grad, q.grad), (rep, k)
         for k, v in m.state_dict().items():
             assert torch.equal(v, sd1[k]), (rep, k)
+
+
+def test_runs_under_autocast_like_the_reference_training_loop(A):
+    """utils/utils_fit.py:86-88 calls the model under torch.cuda.amp.autocast: here that selects the bf16-operand conv
+    path (fp32 tensors and outputs), exactly what compute_dtype = "bf16" does; backward works through a GradScaler."""
+    m = build(A, "nano", 128, 5, True)
+    x, r = A.synthetic_inputs(2, 128, 1, "cuda")
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    for dt in (torch.bfloat16, torch.float16):
+        m.load_state_dict(sd0)
+        with torch.autocast("cuda", dtype=dt):
+            det, seg = m(x, r)
+        assert seg.dtype == torch.float32 and all(d.dtype == torch.float32 for d in det)
+        m.load_state_dict(sd0)
+        m.compute_dtype = "bf16"
+        det2, seg2 = m(x, r)
+        m.compute_dtype = "f32"
+        assert torch.equal(seg, seg2) and all(torch.equal(a, b) for a, b in zip(det, det2))
+    m.load_state_dict(sd0)
+    det3, seg3 = m(x, r)                                  # fp32 path: close to, not equal to, the autocast result
+    assert not torch.equal(seg3, seg) and ((seg3 - seg).abs().max() / seg3.abs().max()) < 0.1
+    scaler = torch.amp.GradScaler("cuda")
+    m.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        det, seg = m(x, r)
+        loss = sum((d * d).mean() for d in det) + (seg * seg).mean()
+    scaler.scale(loss).backward()
+    g = m.head.stems[0].conv.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+
+
+def test_other_device_index_and_data_parallel_replicas(A):
+    """`.cuda(i)` with i != 0 (train.py:285-287 uses cuda:1) and nn.DataParallel replicas (yolo.py:103-104): kernels
+    launch on the inputs' device and stream whatever the caller's current device is.  Needs >= 2 visible GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (the round's GPU box has one)")
+    m0 = build(A, "nano", 64, 5, False)
+    x, r = A.synthetic_inputs(2, 64, 1, "cuda:0")
+    with torch.no_grad():
+        d0, s0 = m0(x, r)
+        m1 = build(A, "nano", 64, 5, False).to("cuda:1")
+        d1, s1 = m1(x.to("cuda:1"), r.to("cuda:1"))               # current device stays cuda:0
+        assert s1.device.index == 1 and torch.equal(s1.cpu(), s0.cpu())
+        dp = torch.nn.DataParallel(m0, device_ids=[0, 1])
+        dd, sd = dp(torch.cat([x, x]), torch.cat([r, r]))
+        assert sd.shape[0] == 4 and torch.isfinite(sd).all()
+    with pytest.raises(RuntimeError, match="inputs on"):
+        m0(x.to("cuda:1"), r.to("cuda:1"))
 
 
 def test_module_surface_behaviour(A):
@@ -199,7 +252,7 @@ def test_data_parallel_wrapper_single_rank(A):
     flips = sum(1 for a, b in zip(st2, st2[1:]) if ("radar" in a) != ("radar" in b))
     assert flips >= 2, st2[:8]
     # captured step on a fresh replica
-    m2 = build(A, "nano", 64, 7, True)
+    m2 = build(A, "nano", 64, 7, True, pair=True)
     dp2 = DataParallelVRNet(m2, bucket_bytes=1 << 20)
     gs = GraphedStep(dp2, loss_of, 2, 64, x.device, warmup=2)
     assert len(gs.graphs) == 3                                          # backward cut into 3 captured segments
