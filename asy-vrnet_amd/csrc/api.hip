@@ -6,6 +6,10 @@
 static thread_local char g_err[512] = "";
 static thread_local int g_last_kernel = 0;
 void vr_note_kernel(int id) { g_last_kernel = id; }
+bool vr_ablated(const char* group) {
+  static const char* env = getenv("VRNET_ABLATE");
+  return env != nullptr && strstr(env, group) != nullptr;
+}
 // Which kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to (bench.py
 // prices each launch against the roofline of the kernel that actually ran):
 //   1 fp32 MFMA register-staged   2 fp32 MFMA LDS-DMA ring   3 bf16-rounded operands   4 direct (tiny channel counts)

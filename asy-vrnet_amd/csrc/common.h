@@ -12,6 +12,9 @@
 
 void vr_set_error(const char* fmt, ...);
 void vr_note_kernel(int id);
+// Timing ablation (diagnostic only, results are garbage): VRNET_ABLATE = comma list of kernel groups whose launches are
+// skipped -- igemm, wgrad, moments, affine, cluster, coef, spatial.  Tells how much of the step each group exposes.
+bool vr_ablated(const char* group);
 
 #define VR_CHECK_ARG(cond, ...)                 \
   do {                                          \

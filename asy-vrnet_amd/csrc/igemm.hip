@@ -1263,6 +1263,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                                 double* stats, int precision, int pair_rows, const float* w2, const float* bias2,
                                 const float* res_scale2, const float* kscale2, void* stream) {
   VR_CHECK_ARG(a && w && y, "conv2d: null tensor");
+  if (vr_ablated("igemm")) return VR_OK;
   VR_CHECK_ARG(pair_rows >= 0 && (pair_rows == 0 || (w2 && pair_rows % 128 == 0 && (!bias == !bias2) &&
                                                      (!res_scale == !res_scale2) && (!kscale == !kscale2))),
                "conv2d: a two-stream launch needs the second parameter set and a first-stream row count that is a "
@@ -1540,6 +1541,7 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
                                       const float* bias2, float* dls2, void* workspace, long workspace_bytes,
                                       void* stream) {
   VR_CHECK_ARG(x && dy && dw && workspace, "conv2d_wgrad: null tensor");
+  if (vr_ablated("wgrad")) return VR_OK;
   const long M = (long)B * OH * OW;
   VR_CHECK_ARG(M < (1L << 31) && (long)B * H * W < (1L << 31), "conv2d_wgrad: too many pixels");
   const int streams = dw2 ? 2 : 1;

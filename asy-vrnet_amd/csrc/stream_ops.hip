@@ -550,6 +550,7 @@ extern "C" long vrnet_moments_workspace(int B, long HW, int C) {
 static int moments_launch(const float* x, long ldx, const float* x2, long ldx2, const float* mask, long ldm, int B,
                           long HW, int C, void* workspace, long workspace_bytes, hipStream_t st, int* nchunks_out,
                           int total_only = 0) {
+  if (vr_ablated("moments")) { if (nchunks_out) *nchunks_out = 1; return VR_OK; }
   VR_CHECK_ARG(x && workspace, "moments: null tensor");
   VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && ldx >= C, "moments: bad shape");
   bool vec = (C % 4 == 0) && (ldx % 4 == 0) && vr_aligned16(x);
@@ -621,6 +622,7 @@ extern "C" int vrnet_affine_f32(const float* x1, long ld1, const float* A, const
                                 const float* D2, const float* S2, long coef_bstride, float* out, long ldo, int B,
                                 long HW, int C, int accumulate, const float* add, long ldadd, void* stream) {
   VR_CHECK_ARG(out && B > 0 && HW > 0 && C > 0, "affine: bad arguments");
+  if (vr_ablated("affine")) return VR_OK;
   VR_CHECK_ARG(pre != 2 || masky, "affine: mask mode without mask tensor");
   VR_CHECK_ARG(!(accumulate && add), "affine: accumulate (in place) and add (out of place) are exclusive");
   if (accumulate) { add = out; ldadd = ldo; }
