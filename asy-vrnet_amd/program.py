@@ -1118,14 +1118,17 @@ def backbone_forward(rt, bb, x, r):
             act = cluster_block(rt, act, blk, f"{prefix}.{j}.token_mixer")
         return act
 
-    def can_pair(h, w):          # rows of one stream must be whole 128-row tiles (true for every stage from 256 px at bs 2)
-        return rt.pair_streams and (B * h * w) % 128 == 0
+    mask = os.environ.get("VRNET_PAIR_MASK")      # diagnostic: which stages (bits 0-3) / reducers (bits 4-6) run two-stream
+
+    def can_pair(h, w, bit=None):    # rows of one stream must be whole 128-row tiles (true for every stage from 256 px at bs 2)
+        on = rt.pair_streams if (mask is None or bit is None) else bool(int(mask, 0) >> bit & 1)
+        return on and (B * h * w) % 128 == 0
     xr = rt.new_pair(2 * B, H // 4, W // 4, dims[0])             # stage-0 input: both patch embeddings
     xh, rh = xr.halves()
     rt.parallel([lambda: embed(xe, bb.patch_embed, out=xh), lambda: embed(re_, bb.patch_embed_radar, out=rh)])
     for i in range(4):
         pi, pr = f"backbone.backbone.network.{3 * i}", f"backbone.backbone.network_radar.{3 * i}"
-        if can_pair(xr.H, xr.W):
+        if can_pair(xr.H, xr.W, i):
             for j, (bi, br) in enumerate(zip(bb.network[3 * i], bb.network_radar[3 * i])):
                 xr = cluster_block(rt, xr, (bi, br), (f"{pi}.{j}.token_mixer", f"{pr}.{j}.token_mixer"))
             xs, rs = xr.halves()
@@ -1144,7 +1147,7 @@ def backbone_forward(rt, bb, x, r):
             outs_r.append(r)
         if i < 3:
             ci, cr = bb.network[3 * i + 2].proj, bb.network_radar[3 * i + 2].proj
-            if can_pair(fused.H // 2, fused.W // 2):
+            if can_pair(fused.H // 2, fused.W // 2, 4 + i):
                 xr = simple_conv(rt, fused, (ci, cr))
             else:
                 xr = rt.new_pair(2 * B, fused.H // 2, fused.W // 2, dims[i + 1])
@@ -1275,7 +1278,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         # measured (A/B inside one gpurun call, phi=l bs 8 512 px): two chains on two streams 30.8 ms/step, one
         # two-stream chain 31.6 ms/step (and 1 480 instead of 2 070 launches): the default is the faster one
         rt.pair_streams = bool(getattr(model, "pair_streams", False))
-        cd = str(getattr(model, "compute_dtype", "f32")).lower()
+        cd = str(os.environ.get("VRNET_COMPUTE_DTYPE") or getattr(model, "compute_dtype", "f32")).lower()   # env: diagnostics
         if cd not in ("f32", "fp32", "float32", "torch.float32", "f32-mfma", "bf16", "bfloat16", "torch.bfloat16"):
             raise RuntimeError(f"compute_dtype {cd!r}: expected 'f32', 'f32-mfma' or 'bf16'")
         rt.bf16 = cd in ("bf16", "bfloat16", "torch.bfloat16")

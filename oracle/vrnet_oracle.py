@@ -120,7 +120,11 @@ def relu_site(ctx, key, z):
     ctx.relu_report[key] = {"elements": z.numel(), "mismatch": n,
                             "max_abs": float(z.detach().abs()[diff].max()) if n else 0.0,
                             "scale": float(z.detach().abs().max())}
-    return z * forced.to(z.dtype)
+    # value = relu(z) exactly (never negative: a forced-active element whose own z is -1e-8 must not become THE
+    # minimum of data_normal's batch-wide min, which would route the whole min-gradient through that one element);
+    # gradient = the forced mask
+    lin = z * forced.to(z.dtype)
+    return lin + (torch.relu(z) - lin).detach()
 
 
 def base_conv(P, pre, x, k, ctx, stride=1):

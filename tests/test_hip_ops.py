@@ -787,3 +787,99 @@ def test_layer_scale_gradient_from_weight_gradient_slabs(hip, pair, precision):
     A = rnd(B, Co, seed=10).cuda()
     hip.affine(out, Co, B, H * W, Co, x1=gg, ld1=Co, A=A, bstride=Co, add=x, ldadd=Co)
     close(out, gg * A[:, None, None, :] + x, 1e-6, what="affine add")
+
+
+def test_torch_library_custom_ops(hip):
+    """torch.ops.vrnet.* (asy_vrnet_amd/ops.py): schema + fake kernels (opcheck) and autograd against the ATen conv / the
+    oracle's Cluster core."""
+    import asy_vrnet_amd.ops  # noqa: F401  (registers the ops)
+    from oracle import vrnet_oracle as O
+    x = rnd(2, 12, 12, 48, seed=1).cuda().requires_grad_(True)
+    w = (rnd(64, 48, 3, 3, seed=2) / 20).cuda().requires_grad_(True)
+    b = rnd(64, seed=3).cuda().requires_grad_(True)
+    y = torch.ops.vrnet.conv2d_nhwc(x, w, b, 1, 1, 1)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, 1, 1, 1).permute(0, 2, 3, 1)
+    close(y, ref, what="custom op conv")
+    g = rnd(*y.shape, seed=4).cuda()
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), g)
+    rx, rw, rb = torch.autograd.grad(ref, (x, w, b), g)
+    close(gx, rx, what="custom op conv dx"); close(gw, rw, what="custom op conv dw"); close(gb, rb, what="custom op conv db")
+    torch.library.opcheck(torch.ops.vrnet.conv2d_nhwc.default, (x.detach(), w.detach(), b.detach(), 1, 1, 1),
+                          test_utils=("test_schema", "test_faketensor"))
+    f = rnd(2, 16, 16, 128, seed=5).cuda().requires_grad_(True)
+    v = rnd(2, 16, 16, 128, seed=6).cuda().requires_grad_(True)
+    al, be = torch.tensor([1.3], device="cuda", requires_grad=True), torch.tensor([-0.2], device="cuda", requires_grad=True)
+    out, idx = torch.ops.vrnet.cluster(f, v, al, be, 4, 2)
+    fo, vo = f.detach().cpu().permute(0, 3, 1, 2).requires_grad_(True), v.detach().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    ao, bo = al.detach().cpu().requires_grad_(True), be.detach().cpu().requires_grad_(True)
+    ref, _ = O.cluster_core(fo, vo, ao, bo, 4, 2, forced_idx=idx.permute(0, 3, 1, 2).contiguous().cpu().long(), report={})
+    close(nchw(out), ref, what="custom op cluster")
+    gg = rnd(2, 128, 16, 16, seed=7)
+    ref.backward(gg)
+    df, dv, da, db = torch.autograd.grad(out, (f, v, al, be), nhwc(gg))
+    close(nchw(dv), vo.grad, what="custom op cluster dv")
+    close(nchw(df), fo.grad, 5e-4, what="custom op cluster df", floor=1e-2)
+    close(da, ao.grad, 5e-4, what="custom op cluster dalpha", floor=1e-2)
+    torch.library.opcheck(torch.ops.vrnet.cluster.default, (f.detach(), v.detach(), al.detach(), be.detach(), 4, 2),
+                          test_utils=("test_schema", "test_faketensor"))
+    with pytest.raises(Exception):
+        torch.ops.vrnet.cluster(f.detach().cpu(), v.detach().cpu(), al.detach().cpu(), be.detach().cpu(), 4, 2)
+
+
+# ---- precision 2 ("x6": fp32 products as six exact bf16 x bf16 products on the LDS-DMA tile kernels) against the fp32
+# ---- MFMA path of the same entry point, on shapes large enough for the tile kernels to be chosen (>= 256 tiles)
+X6_CASES = [
+    # B, H, W, Cin, Cout, k, s, p, d
+    (2, 128, 128, 64, 128, 1, 1, 0, 1),     # tile 21 (256 x 2 column tiles)
+    (2, 128, 128, 64, 512, 1, 1, 0, 1),     # tile 22 forward, tile 21 data gradient (Cin = 64 columns)
+    (2, 128, 128, 512, 64, 1, 1, 0, 1),     # Mlp.fc2 at stage 0
+    (8, 32, 32, 320, 1280, 1, 1, 0, 1),     # stage 2 MLP
+    (8, 32, 32, 1280, 320, 1, 1, 0, 1),
+    (4, 64, 64, 128, 96, 1, 1, 0, 1),       # 96 columns: ragged 128-wide / 64-wide tiles
+    (4, 64, 64, 72, 200, 1, 1, 0, 1),       # contraction not a multiple of 16, columns not a multiple of 64
+    (2, 128, 128, 64, 64, 3, 1, 1, 1),      # radar_projection 3x3
+    (2, 128, 128, 64, 128, 3, 2, 1, 1),     # reducer 3x3 / s2: parity-major data gradient
+    (8, 64, 64, 128, 320, 3, 2, 1, 1),
+    (8, 64, 64, 64, 64, 3, 1, 6, 6),        # dilated
+    (2, 64, 64, 128, 128, 3, 1, 1, 1),      # radar_projection at stage 1, bs 2: only the weight gradient has an x6 kernel
+    (2, 32, 32, 320, 320, 3, 1, 1, 1),
+    (2, 16, 16, 512, 512, 3, 1, 1, 1),
+    (2, 64, 64, 128, 1024, 1, 1, 0, 1),
+]
+
+
+@pytest.mark.parametrize("case", X6_CASES)
+def test_x6_conv_matches_fp32_mfma_path(hip, case):
+    B, H, W, Ci, Co, k, s, p, d = case
+    OH, OW = (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
+    x = nhwc(rnd(B, Ci, H, W, seed=1))
+    w = rnd(Co, Ci, k, k, seed=2) / np.sqrt(Ci * k * k)
+    wp, b, ls = pack(hip, w), rnd(Co, seed=3).cuda(), rnd(Co, seed=4).cuda()
+    res = nhwc(rnd(B, Co, OH, OW, seed=5))
+    outs = {}
+    for prec in (0, 2):
+        y, ypre = torch.empty(B, OH, OW, Co, device="cuda"), torch.empty(B, OH, OW, Co, device="cuda")
+        st, per = hip.conv_stats_buffer(B, OH * OW, Co, x.device)
+        hip.conv2d(x, Ci, wp, b, y, Co, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, act=2, ypre=ypre, ldypre=Co, res=res, ldres=Co,
+                   res_scale=ls, stats=st, precision=prec)
+        fam_f = hip.last_kernel()
+        g, aux = nhwc(rnd(B, Co, OH, OW, seed=6)), nhwc(rnd(B, Ci, H, W, seed=7))
+        dx = nhwc(rnd(B, Ci, H, W, seed=8))                       # accumulate into existing contents
+        hip.conv2d(g, Co, wp, None, dx, Ci, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, mode=1, kscale=ls, aux=aux, ldaux=Ci,
+                   accumulate=1, precision=prec)
+        fam_d = hip.last_kernel()
+        dw, db, dl = torch.empty(Co, Ci, k, k, device="cuda"), torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
+        kw = dict(w=w.cuda().contiguous(), bias=b, dls=dl) if k == 1 else {}
+        hip.conv2d_wgrad(x, Ci, g, Co, dw, db, ls, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, precision=prec, **kw)
+        fam_w = hip.last_kernel()
+        dw_nb = torch.full((Co, Ci, k, k), 7.0, device="cuda")     # without a bias gradient (BaseConv), accumulating
+        guard = torch.zeros(4096, device="cuda")
+        hip.conv2d_wgrad(x, Ci, g, Co, dw_nb, None, None, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, accumulate=1, precision=prec)
+        outs[prec] = (y, ypre, st.view(B, -1, 2).sum(1) if st is not None else None, dx, dw, db, dl if k == 1 else None,
+                      (fam_f, fam_d, fam_w), dw_nb)
+    assert 6 in outs[2][7], outs[2][7]                            # at least one launch ran on an x6 kernel
+    assert 6 not in outs[0][7]
+    for name, a, b_ in zip(("y", "ypre", "stats", "dx", "dw", "db", "dls"), outs[2], outs[0]):
+        if a is not None:
+            close(a, b_, 2e-5, what=f"x6 {name} {outs[2][7]}")
+    close(outs[2][8], outs[0][8], 2e-5, what="x6 dw without bias, accumulate")
