@@ -5,6 +5,8 @@
 //   (backbone/attention_modules/shuffle_attention.py:48-72), each with its backward.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------ depthwise 3x3
@@ -83,6 +85,66 @@ __global__ __launch_bounds__(256) void dwconv3x3_vec_kernel(const float* x, long
     }
     f32x4* d = reinterpret_cast<f32x4*>(y + (long)pix * ldy + 4 * cq);
     *d = accumulate ? *d + s : s;
+  }
+}
+
+// Sliding-window variant: a thread owns 4 channels of a RUN of consecutive x positions of one image row and keeps the
+// 3 x 3 window in registers: per output it loads ONE new column (3 x 16 bytes) instead of all nine taps, which is what
+// bounds the kernel above (9 x 16 B through the vector L1 per 16 B written).
+template <int RUN>
+__global__ __launch_bounds__(256) void dwconv3x3_slide_kernel(const float* x, long ldx, const float* w, float* y, long ldy,
+                                                              int B, int H, int W, int C, int flip, int accumulate) {
+  const int CQ = C >> 2;
+  const long item = (long)blockIdx.x * 256 + threadIdx.x;
+  const int cq = (int)(item % CQ);
+  const long run = item / CQ;
+  const int runs_per_row = W / RUN;
+  const long nruns = (long)B * H * runs_per_row;
+  if (run >= nruns) return;
+  const int xr = (int)(run % runs_per_row);
+  const long rowi = run / runs_per_row;                 // b * H + yy
+  const int yy = (int)(rowi % H);
+  f32x4 wt[9];
+  {
+    float raw[36];
+    const float* ws = w + (long)cq * 36;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(ws + 4 * i);
+      raw[4 * i] = t[0]; raw[4 * i + 1] = t[1]; raw[4 * i + 2] = t[2]; raw[4 * i + 3] = t[3];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ts = flip ? 8 - t : t;
+      wt[t] = f32x4{raw[ts], raw[9 + ts], raw[18 + ts], raw[27 + ts]};
+    }
+  }
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const float* rows[3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int sy = yy + ky - 1;
+    rows[ky] = (sy >= 0 && sy < H) ? x + ((rowi + ky - 1) * W) * ldx + 4 * cq : nullptr;
+  }
+  const int x0 = xr * RUN;
+  auto column = [&](int sx, f32x4 (&col)[3]) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+      col[ky] = (rows[ky] != nullptr && sx >= 0 && sx < W) ? *reinterpret_cast<const f32x4*>(rows[ky] + (long)sx * ldx) : zero;
+  };
+  f32x4 c0[3], c1[3], c2[3];
+  column(x0 - 1, c0);
+  column(x0, c1);
+#pragma unroll
+  for (int i = 0; i < RUN; ++i) {
+    column(x0 + i + 1, c2);
+    f32x4 sacc = zero;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) sacc += c0[ky] * wt[ky * 3] + c1[ky] * wt[ky * 3 + 1] + c2[ky] * wt[ky * 3 + 2];
+    f32x4* d = reinterpret_cast<f32x4*>(y + ((rowi * W) + x0 + i) * ldy + 4 * cq);
+    *d = accumulate ? *d + sacc : sacc;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) { c0[ky] = c1[ky]; c1[ky] = c2[ky]; }
   }
 }
 
@@ -515,36 +577,46 @@ __global__ __launch_bounds__(256) void sa_coef_bwd_kernel(const double* T, const
       F[e] = (float)(-r * m1);
     }
   } else {
-    for (int i = threadIdx.x; i < cp; i += 256) {
-      double gcw = 0, gcb = 0, gsw = 0, gsb = 0, ggw = 0, ggb = 0;
-      for (int b = 0; b < B; ++b)
-        for (int g = 0; g < G; ++g) {
-          {
-            const long e = (long)b * C + g * 2 * cp + i;
-            const double mean = mom[2 * e] / (double)HW;
-            gcw += mean * T[2 * e];
-            gcb += T[2 * e];
-          }
-          {
-            const long e = (long)b * C + g * 2 * cp + cp + i;
-            const double t1 = T[2 * e], t2 = T[2 * e + 1];
-            const double mean = mom[2 * e] / (double)HW;
-            double var = mom[2 * e + 1] / (double)HW - mean * mean;
-            if (var < 0) var = 0;
-            const double r = 1.0 / sqrt(var + 1e-5);
-            const double xh = r * (t2 - mean * t1);   // sum dz * xhat
-            gsw += (double)sp.gnw[i] * xh + (double)sp.gnb[i] * t1;
-            gsb += t1;
-            ggw += (double)sp.sw[i] * xh;
-            ggb += (double)sp.sw[i] * t1;
-          }
-        }
-      dcw[i] = (accumulate ? dcw[i] : 0.f) + (float)gcw;
-      dcb[i] = (accumulate ? dcb[i] : 0.f) + (float)gcb;
-      dsw[i] = (accumulate ? dsw[i] : 0.f) + (float)gsw;
-      dsb[i] = (accumulate ? dsb[i] : 0.f) + (float)gsb;
-      dgnw[i] = (accumulate ? dgnw[i] : 0.f) + (float)ggw;
-      dgnb[i] = (accumulate ? dgnb[i] : 0.f) + (float)ggb;
+    // one workgroup per parameter index i: the B * G (sample, group) terms are spread over the threads and added in a
+    // fixed tree (was: one thread per i walking all B * G terms, a 50 us serial chain of dependent loads)
+    __shared__ double red[6][4];
+    const int i = (int)blockIdx.x - nb1;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (int pidx = threadIdx.x; pidx < B * G; pidx += 256) {
+      const int b = pidx / G, g = pidx - b * G;
+      {
+        const long e = (long)b * C + g * 2 * cp + i;
+        const double mean = mom[2 * e] / (double)HW;
+        v[0] += mean * T[2 * e];
+        v[1] += T[2 * e];
+      }
+      {
+        const long e = (long)b * C + g * 2 * cp + cp + i;
+        const double t1 = T[2 * e], t2 = T[2 * e + 1];
+        const double mean = mom[2 * e] / (double)HW;
+        double var = mom[2 * e + 1] / (double)HW - mean * mean;
+        if (var < 0) var = 0;
+        const double r = 1.0 / sqrt(var + 1e-5);
+        const double xh = r * (t2 - mean * t1);   // sum dz * xhat
+        v[2] += (double)sp.gnw[i] * xh + (double)sp.gnb[i] * t1;
+        v[3] += t1;
+        v[4] += (double)sp.sw[i] * xh;
+        v[5] += (double)sp.sw[i] * t1;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double w = wave_sum(v[k]);
+      if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float* outs[6] = {dcw, dcb, dsw, dsb, dgnw, dgnb};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double tot = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+        outs[k][i] = (accumulate ? outs[k][i] : 0.f) + (float)tot;
+      }
     }
   }
 }
@@ -594,7 +666,12 @@ extern "C" int vrnet_dwconv3x3_f32(const float* x, long ldx, const float* w, flo
   VR_CHECK_ARG((long)B * H * W * C < (1L << 31), "dwconv3x3: tensor too large");
   const bool vec = C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && ldx % 4 == 0 && ldy % 4 == 0 && vr_aligned16(x) &&
                    vr_aligned16(y) && vr_aligned16(w);
-  if (vec) {
+  static const int slide = getenv("VRNET_DW_SLIDE") ? atoi(getenv("VRNET_DW_SLIDE")) : 1;     // tuning aid
+  if (vec && slide && W % 8 == 0) {
+    const long items = (long)B * H * (W / 8) * (C / 4);
+    hipLaunchKernelGGL((dwconv3x3_slide_kernel<8>), dim3(vr_cdiv(items, 256)), dim3(256), 0, vr_stream(stream), x, ldx, w, y,
+                       ldy, B, H, W, C, flip, accumulate);
+  } else if (vec) {
     const long npix = (long)B * H * W;
     const int pp = 256 / (C / 4);
     long ppb = pp * 8L;                              // >= 8 pixels per thread, at least ~2048 workgroups when possible
@@ -756,7 +833,7 @@ extern "C" int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long
   const int nb1 = (int)vr_cdiv((long)B * C, 256);
   float* E = EF;
   float* F = EF + (long)B * C;
-  hipLaunchKernelGGL(sa_coef_bwd_kernel, dim3(nb1 + 1), dim3(256), 0, st, T, mom, sp, B, HW, C, G, nb1, E, F, dcw, dcb,
+  hipLaunchKernelGGL(sa_coef_bwd_kernel, dim3(nb1 + C / (2 * G)), dim3(256), 0, st, T, mom, sp, B, HW, C, G, nb1, E, F, dcw, dcb,
                      dsw, dsb, dgnw, dgnb, accumulate_params);
   VR_LAUNCH_CHECK("sa_coef_bwd");
   hipLaunchKernelGGL(sa_bwd_apply_kernel, dim3(grid_for(HW * C), B), dim3(256), 0, st, dy, lddy, x, ldx, P, Q, Mn, E, F, dx,
