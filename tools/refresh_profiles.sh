@@ -7,9 +7,19 @@ out=gpurun_out/refresh
 rm -rf $out; mkdir -p $out
 python3 bench.py > $out/bench_phi-l_bs8_512.json 2> $out/bench_l.err
 python3 bench.py --phi nano --no-cpu-baseline > $out/bench_phi-nano_bs8_512.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --pair > $out/bench_phi-l_bs8_512_pair.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --dtype f32-mfma > $out/bench_phi-l_bs8_512_f32-mfma.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --dtype bf16 > $out/bench_phi-l_bs8_512_bf16.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --dtype bf16 --batch 16 > $out/bench_phi-l_bs16_512_bf16.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --dtype bf16 --batch 4 --size 1024 > $out/bench_phi-l_bs4_1024_bf16.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --batch 4 --size 1024 > $out/bench_phi-l_bs4_1024.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --detail 2> $out/per_shape_detail_phi-l_bs8_512.txt > /dev/null
+VRNET_BENCH_FORCE_DP=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
+    bench.py --gpus 1 --no-cpu-baseline --no-roofline 2>/dev/null | grep metric > $out/bench_phi-l_bs8_512_dp1_rccl_3segments.json
+python3 tools/x6_probe.py > $out/x6_vs_fp32_mfma_gemm_probe.txt 2>/dev/null
+python3 tools/x6_probe.py wgrad >> $out/x6_vs_fp32_mfma_gemm_probe.txt 2>/dev/null
+tools/sweep_env.sh "" "VRNET_ABLATE=igemm" "VRNET_ABLATE=wgrad" "VRNET_ABLATE=igemm,wgrad" "VRNET_ABLATE=moments,affine" \
+    "VRNET_ABLATE=igemm,wgrad,moments,affine" > $out/ablation_ms_per_step.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/graph -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > $out/graph.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --serial --no-graph > $out/serial.log 2>&1
 cp $(ls $out/graph/*/*kernel_stats.csv | head -1) $out/kernel_stats_phi-l_bs8_512_hipgraph.csv
@@ -19,4 +29,5 @@ bash tools/pmc_traffic.sh $out/hbm_traffic_pmc_phi-l_bs8_512.csv > $out/pmc.log 
 rm -rf gpurun_out/pmc_traffic
 bash tools/pmc_mfma.sh $out/mfma_util_pmc_phi-l_bs8_512.csv > $out/pmc_mfma.log 2>&1
 rm -rf gpurun_out/pmc_mfma
+python3 tools/join_hbm_rate.py $out/hbm_traffic_pmc_phi-l_bs8_512.csv $out/kernel_stats_phi-l_bs8_512_serial.csv > $out/hbm_rate_per_kernel_phi-l_bs8_512.csv 2>/dev/null
 ls -la $out
