@@ -30,6 +30,26 @@ def test_committed_bench_lines_carry_every_field():
     head = json.loads(open(os.path.join(ROOT, "profiles", "r01_bench_phi-l_bs8_512.json")).read().strip().splitlines()[-1])
     assert head["dtype"] == "f32" and head["n_gpus"] == 1 and head["cpu_baseline"] is not None
     assert "configs[1]" in head["config"]["workload"] and head["roofline"]["traffic"]
+    head2 = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_phi-l_bs8_512.json")).read().strip().splitlines()[-1])
+    assert head2["dtype"] == "f32" and head2["n_gpus"] == 1 and "configs[1]" in head2["config"]["workload"]
+    cb = head2["cpu_baseline"]
+    assert cb is not None and "bs=8" in cb["sample"] and "warm-up" in cb["sample"] and cb["cpu_model"] and cb["fwd_bs1_images_per_sec"] > 0
+    fam = head2["roofline"]["families"]             # the roofline is priced per kernel family that actually ran
+    assert any("x6" in k for k in fam) and abs(sum(v["share_of_flops"] for v in fam.values()) - 1.0) < 1e-2
+
+
+def test_traffic_is_reported_only_for_the_measured_kernel_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed PMC table: it must be None as soon as the kernel sources differ from the
+    ones the table was measured on."""
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc_phi-l_bs8_512.csv")))
+    meta = files[-1] + ".meta.json"
+    assert os.path.exists(meta)
+    same = json.load(open(meta))["kernel_source_hash"] == bench.kernel_source_hash()
+    assert (bench.pmc_traffic_bytes("l") is not None) == same
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "0" * 16)
+    assert bench.pmc_traffic_bytes("l") is None
+    assert bench.pmc_traffic_bytes("nano") is None
 
 
 def test_bench_defaults_are_the_headline_config():

@@ -15,7 +15,7 @@ python3 bench.py --no-cpu-baseline --dtype bf16 --batch 4 --size 1024 > $out/ben
 python3 bench.py --no-cpu-baseline --batch 4 --size 1024 > $out/bench_phi-l_bs4_1024.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --detail 2> $out/per_shape_detail_phi-l_bs8_512.txt > /dev/null
 VRNET_BENCH_FORCE_DP=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
-    bench.py --gpus 1 --no-cpu-baseline --no-roofline 2>/dev/null | grep metric > $out/bench_phi-l_bs8_512_dp1_rccl_3segments.json
+    bench.py --gpus 1 --no-cpu-baseline --no-roofline 2>/dev/null | grep metric > $out/line_dp1_rccl_3segments_phi-l_bs8_512.json
 python3 tools/x6_probe.py > $out/x6_vs_fp32_mfma_gemm_probe.txt 2>/dev/null
 python3 tools/x6_probe.py wgrad >> $out/x6_vs_fp32_mfma_gemm_probe.txt 2>/dev/null
 tools/sweep_env.sh "" "VRNET_ABLATE=igemm" "VRNET_ABLATE=wgrad" "VRNET_ABLATE=igemm,wgrad" "VRNET_ABLATE=moments,affine" \
