@@ -389,6 +389,84 @@ __global__ void bn_coef_bwd_kernel(const double* mom2, const float* mean_rstd, c
   dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
 }
 
+// BatchNorm coefficients straight from the moments kernel's chunk partials [B][nchunks][C][2]: 16 lanes per channel add
+// the B * nchunks partials of their channel in a fixed pattern, lane 0 finishes the channel -- the separate
+// moments_reduce launch and the [B][C][2] table disappear (100 launches per training step).
+__device__ __forceinline__ void bn_channel_sums(const double* partial, int B, int nchunks, int C, int c, bool live,
+                                                double (&red)[16][16][2], double& s1, double& s2) {
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  double a1 = 0.0, a2 = 0.0;
+  if (live) {
+    const int total = B * nchunks;
+    for (int j = sl; j < total; j += 16) {
+      const double* src = partial + ((long)j * C + c) * 2;
+      a1 += src[0];
+      a2 += src[1];
+    }
+  }
+  red[sl][o][0] = a1;
+  red[sl][o][1] = a2;
+  __syncthreads();
+  s1 = 0.0; s2 = 0.0;
+  if (sl == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s1 += red[k][o][0]; s2 += red[k][o][1]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_coef_fwd_partial_kernel(const double* partial, int nchunks, const float* gamma,
+                                                                  const float* beta, float eps, float momentum,
+                                                                  float* running_mean, float* running_var, long long* nbt,
+                                                                  int B, long HW, int C, float* A, float* D, float* S,
+                                                                  float* mean_rstd) {
+  __shared__ double red[16][16][2];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const bool live = c < C;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  double s1, s2;
+  bn_channel_sums(partial, B, nchunks, C, c, live, red, s1, s2);
+  if ((threadIdx.x >> 4) != 0 || !live) return;
+  const double n = (double)B * HW;
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0) var = 0;
+  running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+  running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (n / (n - 1.0)));
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  A[c] = (float)(rstd * gamma[c]);     // y = A * (z - S) + D
+  D[c] = beta[c];
+  S[c] = (float)mean;
+  mean_rstd[2 * c] = (float)mean;
+  mean_rstd[2 * c + 1] = (float)rstd;
+}
+
+__global__ __launch_bounds__(256) void bn_coef_bwd_partial_kernel(const double* partial, int nchunks, const float* mean_rstd,
+                                                                  const float* gamma, int training, int B, long HW, int C,
+                                                                  float* A, float* E, float* D, float* S, float* dgamma,
+                                                                  float* dbeta, int accumulate) {
+  __shared__ double red[16][16][2];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const bool live = c < C;
+  double s1, s2;
+  bn_channel_sums(partial, B, nchunks, C, c, live, red, s1, s2);
+  if ((threadIdx.x >> 4) != 0 || !live) return;
+  const double mu = mean_rstd[2 * c], r = mean_rstd[2 * c + 1], g = gamma[c];
+  const double n = (double)B * HW;
+  const double dxh = r * (s2 - mu * s1);   // sum dy * xhat
+  A[c] = (float)(g * r);
+  if (training) {
+    const double m1 = s1 / n, m2 = dxh / n;
+    E[c] = (float)(-g * r * r * m2);     // dz = A*dy' + E*(z - S) + D
+    D[c] = (float)(-g * r * m1);
+  } else {
+    E[c] = 0.f;
+    D[c] = 0.f;
+  }
+  S[c] = (float)mu;
+  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dxh;
+  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+}
+
 // gate[b][c] = sigmoid(sum_j wk[j] * mean[b][c + j - pad]);  eca.py:16-22
 __global__ void eca_coef_fwd_kernel(const double* mom, const float* wk, int k, int B, long HW, int C, float* gate) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -674,6 +752,41 @@ extern "C" int vrnet_bn_coef_fwd(const double* mom, const float* gamma, const fl
   hipLaunchKernelGGL(bn_coef_fwd_kernel, dim3(vr_cdiv(C, 128)), dim3(128), 0, vr_stream(stream), mom, gamma, beta, eps,
                      momentum, running_mean, running_var, num_batches_tracked, training, B, HW, C, A, D, S, mean_rstd);
   VR_LAUNCH_CHECK("bn_coef_fwd");
+  return VR_OK;
+}
+
+// Train-mode BatchNorm statistics + coefficients in two launches (moments over x, then reduce + coefficients + running
+// statistics); workspace as vrnet_moments_workspace.
+extern "C" int vrnet_bn_stats_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, float momentum,
+                                  float* running_mean, float* running_var, long long* num_batches_tracked, int B, long HW,
+                                  int C, float* A, float* D, float* S, float* mean_rstd, void* workspace,
+                                  long workspace_bytes, void* stream) {
+  VR_CHECK_ARG(gamma && beta && running_mean && running_var && A && D && S && mean_rstd, "bn_stats_fwd: null tensor");
+  VR_CHECK_ARG((long)B * HW > 1, "Expected more than 1 value per channel when training");
+  hipStream_t st = vr_stream(stream);
+  int nchunks;
+  int rc = moments_launch(x, ldx, nullptr, 0, nullptr, 0, B, HW, C, workspace, workspace_bytes, st, &nchunks);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_coef_fwd_partial_kernel, dim3(vr_cdiv(C, 16)), dim3(256), 0, st, reinterpret_cast<double*>(workspace),
+                     nchunks, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, B, HW, C, A, D, S,
+                     mean_rstd);
+  VR_LAUNCH_CHECK("bn_stats_fwd");
+  return VR_OK;
+}
+
+// Backward counterpart: moments of (dy [masked by the ReLU output], dy * z), then reduce + coefficients + d gamma / d beta.
+extern "C" int vrnet_bn_stats_bwd(const float* dy, long lddy, const float* z, long ldz, const float* mask, long ldm,
+                                  const float* mean_rstd, const float* gamma, int training, int B, long HW, int C, float* A,
+                                  float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                                  long workspace_bytes, void* stream) {
+  VR_CHECK_ARG(dy && z && mean_rstd && gamma && A && E && D && S && dgamma && dbeta, "bn_stats_bwd: null tensor");
+  hipStream_t st = vr_stream(stream);
+  int nchunks;
+  int rc = moments_launch(dy, lddy, z, ldz, mask, ldm, B, HW, C, workspace, workspace_bytes, st, &nchunks);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_coef_bwd_partial_kernel, dim3(vr_cdiv(C, 16)), dim3(256), 0, st, reinterpret_cast<double*>(workspace),
+                     nchunks, mean_rstd, gamma, training, B, HW, C, A, E, D, S, dgamma, dbeta, accumulate);
+  VR_LAUNCH_CHECK("bn_stats_bwd");
   return VR_OK;
 }
 

@@ -41,6 +41,8 @@ _SIGS = {
     "vrnet_gn_coef_bwd": ([P, P, P, I, L, I, P, P, P, P, P, P, I, P, P, P, P], I),
     "vrnet_bn_coef_fwd": ([P, P, P, F, F, P, P, P, I, I, L, I, P, P, P, P, P], I),
     "vrnet_bn_coef_bwd": ([P, P, P, I, I, L, I, P, P, P, P, P, P, I, P], I),
+    "vrnet_bn_stats_fwd": ([P, L, P, P, F, F, P, P, P, I, L, I, P, P, P, P, P, L, P], I),
+    "vrnet_bn_stats_bwd": ([P, L, P, L, P, L, P, P, I, I, L, I, P, P, P, P, P, P, I, P, L, P], I),
     "vrnet_eca_coef_fwd": ([P, P, I, I, L, I, P, P], I),
     "vrnet_eca_coef_bwd": ([P, P, P, P, I, I, L, I, P, P, I, P], I),
     "vrnet_ls_coef_bwd": ([P, P, I, I, P, P, I, I, P, P, P, P], I),
@@ -257,6 +259,20 @@ def bn_coef_fwd(mom, gamma, beta, eps, momentum, rm, rv, nbt, training, B, HW, C
 def bn_coef_bwd(mom2, mean_rstd, gamma, training, B, HW, C, A, E, Dc, S, dgamma, dbeta, accumulate):
     _check(_lib.vrnet_bn_coef_bwd(ptr(mom2), ptr(mean_rstd), ptr(gamma), int(training), B, HW, C, ptr(A), ptr(E),
                                   ptr(Dc), ptr(S), ptr(dgamma), ptr(dbeta), accumulate, stream()), "bn_coef_bwd")
+
+
+def bn_stats_fwd(x, ldx, gamma, beta, eps, momentum, rm, rv, nbt, B, HW, C, A, Dc, S, mean_rstd):
+    """Train-mode BatchNorm: batch moments of x + coefficients + running statistics in two launches."""
+    ws = _ws.get(_lib.vrnet_moments_workspace(B, HW, C), x.device)
+    _check(_lib.vrnet_bn_stats_fwd(ptr(x), ldx, ptr(gamma), ptr(beta), eps, momentum, ptr(rm), ptr(rv), ptr(nbt), B, HW, C,
+                                   ptr(A), ptr(Dc), ptr(S), ptr(mean_rstd), ptr(ws), ws.numel(), stream()), "bn_stats_fwd")
+
+
+def bn_stats_bwd(dy, lddy, z, ldz, mask, ldm, mean_rstd, gamma, training, B, HW, C, A, E, Dc, S, dgamma, dbeta, accumulate):
+    ws = _ws.get(_lib.vrnet_moments_workspace(B, HW, C), dy.device)
+    _check(_lib.vrnet_bn_stats_bwd(ptr(dy), lddy, ptr(z), ldz, ptr(mask), ldm, ptr(mean_rstd), ptr(gamma), int(training), B,
+                                   HW, C, ptr(A), ptr(E), ptr(Dc), ptr(S), ptr(dgamma), ptr(dbeta), accumulate, ptr(ws),
+                                   ws.numel(), stream()), "bn_stats_bwd")
 
 
 def eca_coef_fwd(mom, wk, k, B, HW, C, gate):

@@ -531,9 +531,12 @@ def bn_forward(rt, z, bn, relu, out=None, residual=None):
     """y = [relu](BN(z)) [+ residual].  Returns (y, ctx) where ctx feeds bn_backward."""
     B, HW, C = z.B, z.HW, z.C
     A, D, S, ms = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C, 2)
-    mom = hip.moments(z.t, z.ld, B, HW, C) if rt.training else None
-    hip.bn_coef_fwd(mom, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                    bn.num_batches_tracked, rt.training, B, HW, C, A, D, S, ms)
+    if rt.training:
+        hip.bn_stats_fwd(z.t, z.ld, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                         bn.num_batches_tracked, B, HW, C, A, D, S, ms)
+    else:
+        hip.bn_coef_fwd(None, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                        bn.num_batches_tracked, False, B, HW, C, A, D, S, ms)
     y = out if out is not None else rt.new(z.B, z.H, z.W, C)
     hip.affine(y.t, y.ld, B, HW, C, x1=z.t, ld1=z.ld, A=A, D1=D, S1=S, pre=1 if relu else 0,
                x2=None if residual is None else residual.t, ld2=0 if residual is None else residual.ld)
@@ -545,8 +548,6 @@ def bn_forward(rt, z, bn, relu, out=None, residual=None):
 def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
     """dz of y = [relu](BN(z)); mask = the ReLU output (None: no ReLU).  Returns contiguous dz tensor."""
     B, HW, C = z.B, z.HW, z.C
-    mom2 = hip.moments(dy, lddy, B, HW, C, x2=z.t, ldx2=z.ld, mask=None if mask is None else mask.t,
-                       ldm=0 if mask is None else mask.ld)
     A, E, D, S = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C)
     gw, accw = rt.pgrad(bn.weight)
     gb, accb = rt.pgrad(bn.bias)
@@ -554,7 +555,8 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
         gw, accw = rt.buf(C), 0
     if gb is None:
         gb = rt.buf(C)
-    hip.bn_coef_bwd(mom2, ms, bn.weight, rt.training, B, HW, C, A, E, D, S, gw, gb, accw)
+    hip.bn_stats_bwd(dy, lddy, z.t, z.ld, None if mask is None else mask.t, 0 if mask is None else mask.ld, ms, bn.weight,
+                     rt.training, B, HW, C, A, E, D, S, gw, gb, accw)
     if rt.on_param_grad:
         rt.on_param_grad(bn.weight)
         rt.on_param_grad(bn.bias)

@@ -136,6 +136,17 @@ int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* g
 int vrnet_bn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, float momentum,
                       float* running_mean, float* running_var, long long* num_batches_tracked, int training, int B,
                       long HW, int C, float* A, float* D, float* S, float* mean_rstd, void* stream);
+/* Train-mode BatchNorm in two launches instead of three: vrnet_moments_f32's first kernel over z, then ONE kernel that
+ * adds the chunk partials per channel, updates the running statistics and writes the coefficients (no [B][C][2] table, no
+ * separate reduce launch).  workspace as vrnet_moments_workspace.  The backward counterpart does the same for
+ * moments(dy, x2 = z, mask). */
+int vrnet_bn_stats_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, long long* num_batches_tracked, int B, long HW, int C,
+                       float* A, float* D, float* S, float* mean_rstd, void* workspace, long workspace_bytes, void* stream);
+int vrnet_bn_stats_bwd(const float* dy, long lddy, const float* z, long ldz, const float* mask, long ldm,
+                       const float* mean_rstd, const float* gamma, int training, int B, long HW, int C, float* A, float* E,
+                       float* D, float* S, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                       long workspace_bytes, void* stream);
 /* mom2 = moments(dy, x2 = z, mask = relu output): dz = A*dy' + E*(z - S) + D with A,E,D,S [C]. */
 int vrnet_bn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int training, int B, long HW,
                       int C, float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,

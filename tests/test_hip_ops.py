@@ -238,6 +238,20 @@ def test_batch_norm_relu_chain(hip, training, shape):
     close(nchw(dz), z.grad, what="bn dz")
     close(dgam, gam.grad, what="bn dgamma")
     close(dbet, bet.grad, what="bn dbeta")
+    # the two-launch forms (moments kernel + one reduce-and-coefficients kernel) the network uses
+    if training:
+        rm2, rv2, nbt2 = rm0.cuda(), rv0.cuda(), torch.zeros((), dtype=torch.int64, device="cuda")
+        A3, D3, S3 = (torch.empty(C, device="cuda") for _ in range(3))
+        ms3 = torch.empty(C, 2, device="cuda")
+        hip.bn_stats_fwd(zg, C, gam.detach().cuda(), bet.detach().cuda(), 1e-3, 0.03, rm2, rv2, nbt2, B, H * W, C, A3, D3, S3, ms3)
+        for a_, b_, nm in ((A3, A, "A"), (D3, D, "D"), (S3, S, "S"), (ms3, ms, "mean_rstd"), (rm2, rmg, "rm"), (rv2, rvg, "rv")):
+            close(a_, b_, 1e-6, what="bn_stats_fwd " + nm)
+        assert int(nbt2.item()) == 1
+    A4, E4, D4, S4 = (torch.empty(C, device="cuda") for _ in range(4))
+    dg4, db4 = torch.full((C,), 3.0, device="cuda"), torch.full((C,), 3.0, device="cuda")
+    hip.bn_stats_bwd(gg, C, zg, C, out, C, ms, gam.detach().cuda(), training, B, H * W, C, A4, E4, D4, S4, dg4, db4, 1)
+    for a_, b_, nm in ((A4, A2, "A"), (E4, E2, "E"), (D4, D2, "D"), (S4, S2, "S"), (dg4, dgam + 3, "dgamma"), (db4, dbet + 3, "dbeta")):
+        close(a_, b_, 1e-5, what="bn_stats_bwd " + nm, floor=1e-3)
 
 
 CLUSTER_CASES = [
