@@ -8,7 +8,11 @@ static thread_local int g_last_kernel = 0;
 void vr_note_kernel(int id) { g_last_kernel = id; }
 bool vr_ablated(const char* group) {
   static const char* env = getenv("VRNET_ABLATE");
-  return env != nullptr && strstr(env, group) != nullptr;
+  if (env == nullptr) return false;
+  const size_t n = strlen(group);
+  for (const char* t = env; (t = strstr(t, group)) != nullptr; t += n)      // whole comma-separated tokens only
+    if ((t == env || t[-1] == ',') && (t[n] == 0 || t[n] == ',' || t[n] == ' ')) return true;
+  return false;
 }
 // Which kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to (bench.py
 // prices each launch against the roofline of the kernel that actually ran):

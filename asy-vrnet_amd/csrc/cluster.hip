@@ -8,6 +8,7 @@
 // minimum: read f, v, write out (forward); read f, v, g, write df, dv (backward).
 // All reductions have a fixed order: results are bitwise reproducible run to run.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -707,6 +708,8 @@ int cluster_plan(int N, long blocks, int* T, int* npt) {
   // few region-heads (stages 2-3: B*E*fold^2 = 256 / 64 workgroups): spread each region over 4x the threads
   // (2 points per thread instead of 8) so that the chip holds 4x the waves and loads in flight
   if (blocks <= 256 && N > 4 * (t / 8)) t *= 4;     // measured: 512 workgroups of 256 threads already do better as they are
+  static const int force_t = getenv("VRNET_CLUSTER_T") ? atoi(getenv("VRNET_CLUSTER_T")) : 0;      // tuning aid
+  if (force_t >= 64 && force_t % 64 == 0 && blocks > 256) t = force_t;
   if (t > 1024) t = 1024;
   const int pp = t / 8;
   const int np = (N + pp - 1) / pp;

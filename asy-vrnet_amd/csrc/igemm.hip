@@ -328,6 +328,8 @@ __device__ __forceinline__ f32x16 vr_mfma_x6(const vr_bf16x8 (&a)[3], const vr_b
 // whose grid still fills the chip with 128-row tiles.  Both stage 16 KB per K step.
 // Asymmetric tiles (TM != TN, e.g. 128 x 64 x 16) serve outputs of 64 / 192 / 320 channels and grids that 128 x 128
 // tiles would leave half empty.
+// (128 x 64 x 32 stages -- half the barriers / waits per MFMA -- were measured for launches with <= 2 workgroups per CU:
+// +5..14 % on such launches alone, -0.5 % on the step, where the second chain's kernels already fill those CUs.)
 template <int MODE, int NST, int TM, int TN, int PROD = 0>      // PROD: 0 fp32 MFMA, 6 x6, 1 bf16-rounded operands
 __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_dma_kernel(const IgemmArgs p_in, int MT, int NT) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = (TM == 1 && TN == 1) ? 32 : 16;
@@ -962,14 +964,17 @@ __global__ __launch_bounds__(256, 3) void wgrad_x6_kernel(const WgradArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[NST * ST_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  int bid = blockIdx.x;
+  int bid = blockIdx.x, m_begin, m_end, split;
+  if (p.xcd_group) {
+    if (!wgrad_rows_xcd(p, bid, m_begin, m_end, split)) return;
+  } else {
+    wgrad_rows(p, m_begin, m_end, split);
+  }
   const int ct = bid % p.c_tiles; bid /= p.c_tiles;
   const int nt = bid % p.n_tiles; bid /= p.n_tiles;
   const int t = bid;
   const int ky = t / p.kw, kx = t - ky * p.kw;
   const int n0 = nt * BN, c0 = ct * BC;
-  int m_begin, m_end, split;
-  wgrad_rows(p, m_begin, m_end, split);
   const bool do_bias = p.bslab != nullptr && ct == 0 && t == 0;
   float bsum = 0.f;
   int y_kr[NY], y_cq[NY], x_kr[NX], x_cq[NX];
@@ -1264,6 +1269,10 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                                 const float* res_scale2, const float* kscale2, void* stream) {
   VR_CHECK_ARG(a && w && y, "conv2d: null tensor");
   if (vr_ablated("igemm")) return VR_OK;
+  {   // finer timing ablations by output-row class (diagnostic): stage-0/1 maps, stage-2 maps, neck / head maps
+    const long rows_ = (long)B * (mode == 0 ? OH * OW : H * W);
+    if (rows_ >= 32768 ? vr_ablated("igemm_big") : (rows_ > 2048 ? vr_ablated("igemm_mid") : vr_ablated("igemm_small"))) return VR_OK;
+  }
   VR_CHECK_ARG(pair_rows >= 0 && (pair_rows == 0 || (w2 && pair_rows % 128 == 0 && (!bias == !bias2) &&
                                                      (!res_scale == !res_scale2) && (!kscale == !kscale2))),
                "conv2d: a two-stream launch needs the second parameter set and a first-stream row count that is a "
@@ -1467,8 +1476,16 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
     const long tiles = (long)*n_tiles * *c_tiles * T;
     long s = vr_cdiv(768, tiles);
     long smax = vr_cdiv(M, 256);
-    if (s > smax) s = smax;
     const long sbytes = (48L << 20) / (wsz * 4);
+    // XCD-grouped launch (wgrad_rows_xcd): all tiles of a row split on one XCD, 8 k splits, and at most the 96
+    // workgroups an XCD holds at once (32 CUs x 3) per XCD -- otherwise its second round would run nearly empty
+    static const int s8 = getenv("VRNET_X6_WGRAD_S8") ? atoi(getenv("VRNET_X6_WGRAD_S8")) : 1;      // tuning aid
+    if (s8 && tiles <= 96) {
+      long g = 8 * (96 / tiles);
+      while (g > 8 && (g > smax || g > sbytes)) g -= 8;
+      if (g <= smax && g <= sbytes) s = g;
+    }
+    if (s > smax) s = smax;
     if (s > sbytes) s = sbytes;
     if (s < 1) s = 1;
     const long r = vr_cdiv(vr_cdiv(M, s), 16) * 16;
@@ -1542,6 +1559,10 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
                                       void* stream) {
   VR_CHECK_ARG(x && dy && dw && workspace, "conv2d_wgrad: null tensor");
   if (vr_ablated("wgrad")) return VR_OK;
+  {
+    const long rows_ = (long)B * OH * OW;
+    if (rows_ >= 32768 ? vr_ablated("wgrad_big") : (rows_ > 2048 ? vr_ablated("wgrad_mid") : vr_ablated("wgrad_small"))) return VR_OK;
+  }
   const long M = (long)B * OH * OW;
   VR_CHECK_ARG(M < (1L << 31) && (long)B * H * W < (1L << 31), "conv2d_wgrad: too many pixels");
   const int streams = dw2 ? 2 : 1;
@@ -1581,7 +1602,7 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   float* ls_part = dls ? p.slab + (long)streams * S * ((long)T * Cout * Cin + Cout) : nullptr;
   p.M = (int)M; p.OH = OH; p.OW = OW; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
-  p.rows_per_split = rows; p.n_tiles = nt; p.c_tiles = ct;
+  p.rows_per_split = rows; p.n_tiles = nt; p.c_tiles = ct; p.splits = S;
   const bool vec = (Cin % 4 == 0) && (ldx % 4 == 0) && vr_aligned16(x) && (Cout % 4 == 0) && (lddy % 4 == 0) &&
                    vr_aligned16(dy);
   const bool ident = kh == 1 && kw == 1 && stride == 1 && pad == 0;
@@ -1595,14 +1616,16 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   } while (0)
   VR_CHECK_ARG(precision >= 0 && precision <= 2, "conv2d_wgrad: precision 0 (fp32 MFMA), 1 (bf16 operands) or 2 (x6)");
   if (x6cfg) {
+    p.xcd_group = (S % 8 == 0 && (long)nt * ct * T * (S / 8) <= 96) ? 1 : 0;      // see wgrad_plan / wgrad_rows_xcd
+    const dim3 grid8 = grid;
 #define VR_WX6(TN_, TC_)                                                                                            \
   do {                                                                                                              \
     if (precision == 2) {                                                                                           \
-      if (ident) hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, true, 6>), grid, block, 0, st, p);                   \
-      else hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, false, 6>), grid, block, 0, st, p);                        \
+      if (ident) hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, true, 6>), grid8, block, 0, st, p);                   \
+      else hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, false, 6>), grid8, block, 0, st, p);                        \
     } else {                                                                                                        \
-      if (ident) hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, true, 1>), grid, block, 0, st, p);                   \
-      else hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, false, 1>), grid, block, 0, st, p);                        \
+      if (ident) hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, true, 1>), grid8, block, 0, st, p);                   \
+      else hipLaunchKernelGGL((wgrad_x6_kernel<TN_, TC_, false, 1>), grid8, block, 0, st, p);                        \
     }                                                                                                               \
   } while (0)
     if (x6cfg == 22) VR_WX6(2, 2);

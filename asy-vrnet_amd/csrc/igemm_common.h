@@ -218,6 +218,8 @@ struct WgradArgs {
   int kh, kw, stride, pad, dil;
   int rows_per_split, n_tiles, c_tiles;
   int M_half;      // rows per stream: gridDim.z = 2 streams each contract their own M_half rows into their own slabs
+  int splits;      // row splits per stream
+  int xcd_group;   // x6 kernels: all tiles of a row split on one XCD (splits % 8 == 0), see wgrad_rows_xcd
 };
 
 // (first row, end row, slab index) of this workgroup: blockIdx.y = split within the stream, blockIdx.z = stream
@@ -228,6 +230,25 @@ __device__ __forceinline__ void wgrad_rows(const WgradArgs& p, int& m_begin, int
   const int limit = gridDim.z > 1 ? base + p.M_half : p.M;
   m_end = min(limit, m_begin + p.rows_per_split);
   split = z * gridDim.y + blockIdx.y;
+}
+
+// XCD-grouped variant (splits % 8 == 0): workgroups are dealt to the 8 XCDs round-robin in
+// dispatch order, so dispatch ids j, j + 8, ... share an L2.  All tiles of one row split are mapped to ONE XCD: the
+// split's dy / x rows then enter a single L2 once instead of once per XCD that holds one of its tiles.  `tile`
+// replaces blockIdx.x.
+__device__ __forceinline__ bool wgrad_rows_xcd(const WgradArgs& p, int& tile, int& m_begin, int& m_end, int& split) {
+  const int tiles = gridDim.x;
+  const int L = blockIdx.x + tiles * blockIdx.y, j = L >> 3;
+  const int y = (j / tiles) * 8 + (L & 7);
+  tile = j % tiles;
+  if (y >= p.splits) return false;
+  const int z = blockIdx.z;
+  const int base = z * p.M_half;
+  m_begin = base + y * p.rows_per_split;
+  const int limit = gridDim.z > 1 ? base + p.M_half : p.M;
+  m_end = min(limit, m_begin + p.rows_per_split);
+  split = z * p.splits + y;
+  return true;
 }
 
 }  // namespace

@@ -4,12 +4,12 @@ LDS-DMA igemm launch -- prologue / main loop / epilogue durations, workgroups pe
     python tools/stamp_wg.py B H W Cin Cout [mode]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["VRNET_IGEMM_DMA"] = "2"
 import torch
 import numpy as np
 from asy_vrnet_amd import hip
 B, H, W, Ci, Co = [int(v) for v in sys.argv[1:6]]
 mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+precision = int(sys.argv[7]) if len(sys.argv) > 7 else 2
 x = torch.randn(B, H, W, Ci if mode == 0 else Co, device="cuda")
 w = torch.randn(Co, Ci, 1, 1, device="cuda") * 0.05
 y = torch.empty(B, H, W, Co if mode == 0 else Ci, device="cuda")
@@ -20,7 +20,7 @@ ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=
 for it in range(3):
     st.zero_()
     ev0.record()
-    hip.conv2d(x, x.shape[-1], w, None, y, y.shape[-1], B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=mode, stats=st)
+    hip.conv2d(x, x.shape[-1], w, None, y, y.shape[-1], B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=mode, stats=st, precision=precision)
     ev1.record()
 torch.cuda.synchronize()
 ms = ev0.elapsed_time(ev1)
@@ -52,6 +52,6 @@ for tt, d in ev:
     live += d
 print(f"mean workgroups resident: {area/span:.1f} (of 768 slots)")
 order = np.argsort(start)
-print("start times of the first / last workgroups (us):", np.round(start[order][[0, 255, 511, 767, min(len(t)-1, 768), len(t)-1]]/100, 1))
+print("start times of workgroups at rank 0, 25%, 50%, 75%, 100% (ticks):", np.round(start[order][[0, len(t)//4, len(t)//2, 3*len(t)//4, len(t)-1]], 1))
 stage = (loop_end - first) / (Ci / 32)
 print(f"per-stage time inside the loop: mean {np.mean(stage)/100*1e3:.0f} ns  (16 MFMAs = {1024/2.4:.0f} ns at 2.4 GHz)")

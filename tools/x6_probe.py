@@ -72,4 +72,8 @@ for mode in (0, 1):
     for M, N, K in SHAPES:
         u0, t0, e0 = run(M, N, K, mode, 0)
         u2, t2, e2 = run(M, N, K, mode, 2)
-        print(f"mode {mode} M{M:7d} N{N:5d} K{K:5d}: fp32 {u0:8.1f} us {t0:6.1f} TF err {e0:.1e} | x6 {u2:8.1f} us {t2:6.1f} TF err {e2:.1e} | x{u0 / u2:.2f}")
+        tail = ""
+        if "bf16" in sys.argv and mode == 0:      # same tiles, one bf16 product per fp32 product: the non-arithmetic floor of the x6 kernel
+            u3, t3, e3 = run(M, N, K, mode, 3)
+            tail = f" | bf16-on-tile {u3:8.1f} us (bytes {4e-6 * (M * K + M * N + N * K) / u3:5.2f} TB/s)"
+        print(f"mode {mode} M{M:7d} N{N:5d} K{K:5d}: fp32 {u0:8.1f} us {t0:6.1f} TF err {e0:.1e} | x6 {u2:8.1f} us {t2:6.1f} TF err {e2:.1e} | x{u0 / u2:.2f}{tail}")
