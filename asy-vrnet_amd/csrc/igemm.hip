@@ -1480,8 +1480,10 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
     // XCD-grouped launch (wgrad_rows_xcd): all tiles of a row split on one XCD, 8 k splits, and at most the 96
     // workgroups an XCD holds at once (32 CUs x 3) per XCD -- otherwise its second round would run nearly empty
     static const int s8 = getenv("VRNET_X6_WGRAD_S8") ? atoi(getenv("VRNET_X6_WGRAD_S8")) : 1;      // tuning aid
+    static const int per_xcd = getenv("VRNET_X6_WGRAD_PER_XCD") ? atoi(getenv("VRNET_X6_WGRAD_PER_XCD")) : 96;      // tuning aid
     if (s8 && tiles <= 96) {
-      long g = 8 * (96 / tiles);
+      long g = 8 * (per_xcd / tiles);
+      if (g < 8) g = 8;
       while (g > 8 && (g > smax || g > sbytes)) g -= 8;
       if (g <= smax && g <= sbytes) s = g;
     }

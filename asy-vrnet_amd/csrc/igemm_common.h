@@ -89,10 +89,12 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
   // the staging tile is private to this wave and a wave's LDS operations complete in program order: no workgroup
   // barrier, only a fence against compiler reordering
   __builtin_amdgcn_wave_barrier();
-  // statistics of the stored values: per thread in fp32 around its first value (deviations from a nearby value stay
-  // small when |mean| >> std), un-shifted and combined across the wave in fp64
-  float sh = 0.f, d1 = 0.f, d2 = 0.f;
-  int cnt = 0;
+  // statistics of the stored values, accumulated per thread in fp64.  (An fp32 form -- deviations from the thread's first
+  // value, un-shifted at the end -- was SLP-vectorised by hipcc into v_pk_*_f32 sequences with op_sel lane swaps whose
+  // sum of squares came out short in ~1 launch of 30 whenever another kernel shared the CU: tools/debug/stats_race_dbg.py.
+  // The same source built with -fno-slp-vectorize, or this fp64 form, is repeatable; the library is built without the
+  // SLP vectoriser for that reason, see the Makefile.)
+  double q1 = 0.0, q2 = 0.0;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int q = lane + 64 * t;
@@ -125,23 +127,17 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
       if (p.accumulate) v += *dst;
       *dst = v;
       if (p.stats) {
-        if (cnt == 0) sh = v[0];
-        cnt += 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float d = v[e] - sh;
-          d1 += d;
-          d2 += d * d;
+          const double dv = (double)v[e];
+          q1 += dv;
+          q2 = __builtin_fma(dv, dv, q2);
         }
       }
     }
   }
   if (p.stats) {      // statistics of exactly what was stored (fp64, as the moments kernel): GroupNorm of the consumer
-    const double x0 = (double)sh, n = (double)cnt;
-    double st1 = (double)d1 + n * x0;
-    double st2 = (double)d2 + 2.0 * x0 * (double)d1 + n * x0 * x0;
-    st1 = wave_sum(st1);
-    st2 = wave_sum(st2);
+    const double st1 = wave_sum(q1), st2 = wave_sum(q2);
     const int mb = (m0 + wm * TM * 32 + ti * 32) >> 5, nb = (n0 + wn * TN * 32 + tj * 32) >> 5;
     if (lane == 0 && mb * 32 < p.M && nb < p.stats_nb) {
       double* d = p.stats + ((long)mb * p.stats_nb + nb) * 2;

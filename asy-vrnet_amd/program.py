@@ -10,6 +10,7 @@ exposes the whole network to torch.autograd, so `loss.backward()`, optimizers, E
 and state_dict work exactly as with the reference module.
 """
 import os
+import weakref
 
 import torch
 
@@ -23,7 +24,8 @@ class Act:
     Two-stream buffers: the image and the radar stream of a backbone stage live in ONE (2B,H,W,C) tensor (image
     samples first) so that a stage's ClusterBlocks run as one launch per layer; `half(k)` is the Act of one stream --
     a view whose gradient is the matching half of the parent's gradient buffer (`written[k]`: that half holds data)."""
-    __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad", "pairs", "parent", "slot", "written", "_halves")
+    __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad", "pairs", "parent", "slot", "written", "_halves",
+                 "__weakref__")
 
     def __init__(self, t, need_grad=True):
         self.t = t
@@ -35,15 +37,20 @@ class Act:
         self.parent, self.slot, self.written, self._halves = None, 0, None, None
 
     def half(self, k):
+        """The Act of stream k.  A half references its parent; the parent only remembers its halves WEAKLY (a strong link
+        both ways would be a reference cycle that keeps the buffer alive until Python's cycle collector runs).  A half
+        carries no state of its own -- its gradient is the parent's (`written[k]`) -- so one that died is simply rebuilt."""
         if self._halves is None:
             assert self.B % 2 == 0 and self.ld == self.C
+            self._halves = [None, None]
+        ref = self._halves[k]
+        a = ref() if ref is not None else None
+        if a is None:
             n = self.B // 2
-            self._halves = []
-            for i in range(2):
-                a = Act(self.t[i * n:(i + 1) * n], self.need_grad)
-                a.parent, a.slot = self, i
-                self._halves.append(a)
-        return self._halves[k]
+            a = Act(self.t[k * n:(k + 1) * n], self.need_grad)
+            a.parent, a.slot = self, k
+            self._halves[k] = weakref.ref(a)
+        return a
 
     def halves(self):
         return self.half(0), self.half(1)
@@ -58,6 +65,7 @@ class Act:
 
 
 ASIDE_LAG = int(os.environ.get("VRNET_ASIDE_LAG", "1"))           # tape closures a main-chain weight gradient may trail by
+_SERIAL_SITES = int(os.environ.get("VRNET_SERIAL_SITES", "0"), 0)   # diagnostic: parallel sections (bit = site id) run serially
 WGRAD_STREAMS = int(os.environ.get("VRNET_WGRAD_STREAMS", "2"))   # side streams for weight gradients (measured: 2 < 1 < 4 ms/step)
 
 
@@ -179,13 +187,15 @@ class RT:
             cur.wait_stream(st)
         work.clear()
 
-    def parallel(self, fns):
+    def parallel(self, fns, site=None):
         """Runs independent chains `fns` (callables issuing kernels) on forked HIP streams and joins them.
         Each chain records its backward closures on its own sub-tape; one closure on the main tape replays the
         sub-tapes concurrently.  Allocator safety: inside a chain the side stream is torch's current stream, so
         its temporaries live in that stream's pool; buffers crossing the fork / join are ordered by the events
         (wait_stream) on both sides.  Under hipGraph capture the fork / join become graph edges."""
         if not self.concurrent or len(fns) < 2 or self._depth > 0:      # no nested forks (star topology only)
+            return [fn() for fn in fns]
+        if _SERIAL_SITES and site is not None and (_SERIAL_SITES >> site) & 1:      # diagnostic: VRNET_SERIAL_SITES bit mask
             return [fn() for fn in fns]
         cur = torch.cuda.current_stream(self.device)
         streams = self._streams(len(fns))
@@ -241,6 +251,13 @@ class RT:
             a.grad = self.buf(B2, H, W, C)
             a.written = [False, False]
         return a
+
+    def release(self):
+        """End of the call's life (after the backward pass, or after a forward that recorded nothing)."""
+        self.tape = None
+        self.pgrads.clear()
+        self._aside_batches = []
+        self._deferred_wgrads = []
 
     def buf(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -1021,7 +1038,7 @@ def aspp(rt, x, m):
         return gm, z5, q5, ms5
     record, rt.record = rt.record, False          # one hand-written closure below covers all five branches
     res = rt.parallel([(lambda k=k, br=br: conv_branch(k, br))
-                       for k, br in enumerate((m.branch1, m.branch2, m.branch3, m.branch4))] + [pool_branch])
+                       for k, br in enumerate((m.branch1, m.branch2, m.branch3, m.branch4))] + [pool_branch], site=6)
     rt.record = record
     saved, (gm, z5, q5, ms5) = res[:4], res[4]
     convc, bnc = m.conv_cat[0], m.conv_cat[1]
@@ -1059,7 +1076,7 @@ def backbone_forward(rt, bb, x, r):
     B, H, W = x.B, x.H, x.W
     x0, r0 = x, r
     x, r = rt.parallel([lambda: simple_conv(rt, x0, bb.image_initial.proj),
-                        lambda: simple_conv(rt, r0, bb.radar_initial.proj)])
+                        lambda: simple_conv(rt, r0, bb.radar_initial.proj)], site=0)
     x = image_enhance(rt, x, r, bb.image_enhance_by_radar1)
     r = radar_enhance(rt, x, r, bb.radar_enhance_by_image1)
     if tuple(bb.fea_pos.shape[:2]) != (H, W):
@@ -1127,7 +1144,7 @@ def backbone_forward(rt, bb, x, r):
         return on and (B * h * w) % 128 == 0
     xr = rt.new_pair(2 * B, H // 4, W // 4, dims[0])             # stage-0 input: both patch embeddings
     xh, rh = xr.halves()
-    rt.parallel([lambda: embed(xe, bb.patch_embed, out=xh), lambda: embed(re_, bb.patch_embed_radar, out=rh)])
+    rt.parallel([lambda: embed(xe, bb.patch_embed, out=xh), lambda: embed(re_, bb.patch_embed_radar, out=rh)], site=1)
     for i in range(4):
         pi, pr = f"backbone.backbone.network.{3 * i}", f"backbone.backbone.network_radar.{3 * i}"
         if can_pair(xr.H, xr.W, i):
@@ -1136,7 +1153,7 @@ def backbone_forward(rt, bb, x, r):
             xs, rs = xr.halves()
         else:                                                    # tiny maps (test sizes): two chains on two forked streams
             xi, ri = xr.halves()
-            xs, rs = rt.parallel([lambda: chain(xi, bb.network[3 * i], pi), lambda: chain(ri, bb.network_radar[3 * i], pr)])
+            xs, rs = rt.parallel([lambda: chain(xi, bb.network[3 * i], pi), lambda: chain(ri, bb.network_radar[3 * i], pr)], site=2)
         if i < 3:                                                # fused maps go into the reducer's two-stream input
             fused = rt.new_pair(2 * B, xs.H, xs.W, xs.C)
             fx, fr = fused.halves()
@@ -1154,7 +1171,7 @@ def backbone_forward(rt, bb, x, r):
             else:
                 xr = rt.new_pair(2 * B, fused.H // 2, fused.W // 2, dims[i + 1])
                 ox, orr = xr.halves()
-                rt.parallel([lambda: simple_conv(rt, fx, ci, out=ox), lambda: simple_conv(rt, fr, cr, out=orr)])
+                rt.parallel([lambda: simple_conv(rt, fx, ci, out=ox), lambda: simple_conv(rt, fr, cr, out=orr)], site=3)
             if i < 2:
                 xs, rs = xr.halves()
                 outs.append(xs)
@@ -1180,7 +1197,7 @@ def neck_forward(rt, nk, x, r, seg_out):
         p3 = coc_conv(rt, cat2(rt, r3, coc_upsample(rt, p4, nk.p4_3_det), False), nk.p3_out_det,
                       "backbone.p3_out_det.coc.token_mixer")
         return (p3, p4, p5)
-    seg_lo, feats = rt.parallel([seg_branch, det_branch])
+    seg_lo, feats = rt.parallel([seg_branch, det_branch], site=4)
     return feats, seg_lo
 
 
@@ -1211,7 +1228,7 @@ def head_forward(rt, hd, feats, det_outs):
             conv_backward(rt, c, hd.cls_preds[k], d[..., 5:], ctot)
         rt.push(bwd)
         return None
-    rt.parallel([(lambda k=k, x=x: level(k, x)) for k, x in enumerate(feats)])
+    rt.parallel([(lambda k=k, x=x: level(k, x)) for k, x in enumerate(feats)], site=5)
 
 
 class FusedQKV:
@@ -1399,6 +1416,7 @@ def backward_end(rt, model, inputs, needs, params=None, needs_params=None):
                         hip.add_(p.grad, g)
         rt.pgrads.clear()
         rt.det_grads = rt.seg_grad = None
+        rt.release()
     return outs, pouts
 
 
@@ -1407,6 +1425,10 @@ class _VRNetFunction(torch.autograd.Function):
     def forward(ctx, model, x, x_radar, *params):
         record = any(ctx.needs_input_grad)
         rt, inputs, dets, seg = forward_pass(model, x, x_radar, record, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        # The tape belongs to the autograd node, not to the runtime: its closures capture `rt`, and rt -> tape -> closure ->
+        # rt would be a reference cycle that keeps every saved activation (GBs) alive until Python's cycle collector runs
+        # when an output is dropped without a backward pass.  Without the back edge the node's death frees them at once.
+        ctx.tape, rt.tape = rt.tape, None
         ctx.rt, ctx.inputs = rt, inputs
         ctx.params = params
         ctx.model = model
@@ -1416,6 +1438,9 @@ class _VRNetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g0, g1, g2, gseg):
         rt, model = ctx.rt, ctx.model
+        if ctx.tape is None:
+            raise RuntimeError("EfficientVRNet: backward through the same forward twice (its saved activations were freed)")
+        rt.tape, ctx.tape = ctx.tape, None
         backward_begin(rt, (g0, g1, g2), gseg)
         rec = rt.bucketer is not None and rt.bucketer.recording
         backward_range(rt, 0, len(rt.tape), flush_each=rec)
@@ -1427,5 +1452,10 @@ class _VRNetFunction(torch.autograd.Function):
 
 def run_forward(model, x, x_radar):
     params = tuple(model.parameters())
+    if not torch.is_grad_enabled() or not (x.requires_grad or x_radar.requires_grad or any(p.requires_grad for p in params)):
+        # nothing to differentiate (torch.no_grad(), frozen model): no tape, no saved activations, no autograd node
+        rt, _, dets, seg = forward_pass(model, x, x_radar, record=False)
+        rt.release()
+        return list(dets), seg
     out = _VRNetFunction.apply(model, x, x_radar, *params)
     return [out[0], out[1], out[2]], out[3]

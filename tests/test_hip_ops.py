@@ -897,3 +897,37 @@ def test_x6_conv_matches_fp32_mfma_path(hip, case):
         if a is not None:
             close(a, b_, 2e-5, what=f"x6 {name} {outs[2][7]}")
     close(outs[2][8], outs[0][8], 2e-5, what="x6 dw without bias, accumulate")
+
+
+@pytest.mark.parametrize("precision", [2, 0])
+def test_conv_epilogue_statistics_repeat_bitwise_beside_a_busy_stream(hip, precision):
+    """The conv epilogue's (sum, sum of squares) pairs -- the GroupNorm statistics of the consumer -- must not depend on
+    what else shares the CU.  (A build whose fp32 statistics code had been SLP-vectorised into packed-fp32 sequences
+    produced a short sum of squares in ~3 % of launches next to a second stream: tools/debug/stats_race_dbg.py.)"""
+    B, H, W, ci, co = 8, 128, 128, 64, 64
+    x, w = rnd(B, H, W, ci, seed=1).cuda(), (rnd(co, ci, 1, 1, seed=2) / ci ** 0.5).cuda()
+    b, res, ls = rnd(co, seed=3).cuda(), rnd(B, H, W, co, seed=4).cuda(), rnd(co, seed=5, kind="uniform").cuda()
+    bx, bw = rnd(8, 64, 64, 256, seed=6).cuda(), (rnd(256, 256, 1, 1, seed=7) / 16).cuda()
+    by = torch.empty(8, 64, 64, 256, device="cuda")
+    side, main = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ref, bad = None, 0
+    for it in range(400):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                hip.conv2d(bx, 256, bw, None, by, 256, 8, 64, 64, 256, 64, 64, 256, 1, 1, 1, 0, 1, mode=0, precision=precision)
+        with torch.cuda.stream(main):
+            y = torch.empty(B, H, W, co, device="cuda")
+            pairs, per = hip.conv_stats_buffer(B, H * W, co, "cuda")
+            hip.conv2d(x, ci, w, b, y, co, B, H, W, ci, H, W, co, 1, 1, 1, 0, 1, mode=0, res=res, ldres=co, res_scale=ls,
+                       stats=pairs, precision=precision)
+            cur = (y.clone(), pairs.clone())
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = cur
+            tot = y.double().view(-1, co)          # the pairs are the tile sums of what was stored
+            close(pairs[..., 0].sum(), tot.sum(), 1e-9, what="sum")
+            close(pairs[..., 1].sum(), (tot * tot).sum(), 1e-9, what="sum of squares")
+        else:
+            bad += int(not (torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1])))
+    assert bad == 0, f"{bad} of 399 launches differ"

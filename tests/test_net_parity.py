@@ -307,3 +307,42 @@ def test_bf16_operand_mode_against_oracle(A, phi, size, batch):
     assert rep["flips"] <= max(30, rep["points"] // 1000), rep
     assert rep["det_err"] < 4e-2 and rep["seg_err"] < 4e-2, rep
     assert rep["grad_cos"] > 0.97 and rep["grad_rel_l2"] < 0.25, rep
+
+
+@pytest.mark.gpu
+def test_forward_without_backward_frees_its_activations_at_once(A):
+    """Inference / validation loops: a forward whose outputs are dropped holds no memory afterwards -- under
+    torch.no_grad() nothing is recorded at all, and with autograd on the saved activations die with the autograd node
+    (no reference cycle that only Python's cycle collector would break; it is switched off here)."""
+    import gc
+    net = A.EfficientVRNet(4, 9, "nano", img_size=256).cuda().train()
+    x, r = A.synthetic_inputs(4, 256, 3, "cuda")
+    det, seg = net(x, r)                            # workspaces, caches
+    (seg.mean() + sum(d.mean() for d in det)).backward()
+    del det, seg
+    net.zero_grad(set_to_none=True)
+    gc.collect()
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated()
+        for mode in ("no_grad", "recorded, no backward", "backward"):
+            for _ in range(3):
+                if mode == "no_grad":
+                    with torch.no_grad():
+                        det, seg = net(x, r)
+                    assert not seg.requires_grad
+                else:
+                    det, seg = net(x, r)
+                    assert seg.requires_grad
+                    if mode == "backward":
+                        net.zero_grad(set_to_none=True)
+                        (seg.mean() + sum(d.mean() for d in det)).backward()
+                peak = torch.cuda.memory_allocated() - base
+                del det, seg
+                net.zero_grad(set_to_none=True)
+                torch.cuda.synchronize()
+                held = torch.cuda.memory_allocated() - base
+                assert held <= max(1 << 20, peak // 50), (mode, held, peak)
+    finally:
+        gc.enable()
