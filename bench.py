@@ -387,6 +387,10 @@ def main():
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
                 "frac": round(ach / peak, 4),
                 "peak_note": "FLOP-weighted matrix-pipe ceiling of the kernel mix that ran (x6 416.7 = bf16 2500 / 6; fp32 MFMA 157.3)",
+                "x6_issue_ceiling": {"value": 250.0, "unit": "TFLOP/s (fp32-equivalent)",
+                                     "note": "measured, register-resident x6 loop: the fragment splits (VALU) and the MFMAs do not "
+                                             "overlap on gfx950, their times add -- tools/micro/x6_peak.hip, "
+                                             "profiles/r02_x6_issue_ceiling_micro.txt"},
                 "achieved_over_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 "families": fam_rep,
                 "traffic": pmc_traffic_bytes(args.phi) if (args.batch == 8 and args.size == 512 and not bf16) else None,
