@@ -73,7 +73,10 @@ class GraphedStep:
         bounds = None
         for k in range(len(cuts) + 1):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=self.stream):
+            # thread_local: with a process group alive, RCCL's watchdog thread polls its work events (hipEventQuery) at any
+            # moment; under the default "global" capture mode such a call from ANOTHER thread invalidates the capture
+            # (hipErrorStreamCaptureInvalidated) and raises in the watchdog, which aborts the process at exit
+            with torch.cuda.graph(g, pool=pool, stream=self.stream, capture_error_mode="thread_local"):
                 if k == 0:
                     seg0()
                     n = state["n"]

@@ -19,7 +19,8 @@ VRNET_BENCH_FORCE_DP=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-n
 python3 tools/x6_probe.py > $out/x6_vs_fp32_mfma_gemm_probe.txt 2>/dev/null
 python3 tools/x6_probe.py wgrad >> $out/x6_vs_fp32_mfma_gemm_probe.txt 2>/dev/null
 tools/sweep_env.sh "" "VRNET_ABLATE=igemm" "VRNET_ABLATE=wgrad" "VRNET_ABLATE=igemm,wgrad" "VRNET_ABLATE=moments,affine" \
-    "VRNET_ABLATE=igemm,wgrad,moments,affine" > $out/ablation_ms_per_step.txt 2>&1
+    "VRNET_ABLATE=igemm,wgrad,moments,affine" "VRNET_ABLATE=igemm_big" "VRNET_ABLATE=igemm_mid" "VRNET_ABLATE=igemm_small" \
+    "VRNET_ABLATE=wgrad_big" "VRNET_ABLATE=wgrad_mid" "VRNET_ABLATE=wgrad_small" > $out/ablation_ms_per_step.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/graph -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > $out/graph.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --serial --no-graph > $out/serial.log 2>&1
 cp $(ls $out/graph/*/*kernel_stats.csv | head -1) $out/kernel_stats_phi-l_bs8_512_hipgraph.csv
@@ -30,4 +31,9 @@ rm -rf gpurun_out/pmc_traffic
 bash tools/pmc_mfma.sh $out/mfma_util_pmc_phi-l_bs8_512.csv > $out/pmc_mfma.log 2>&1
 rm -rf gpurun_out/pmc_mfma
 python3 tools/join_hbm_rate.py $out/hbm_traffic_pmc_phi-l_bs8_512.csv $out/kernel_stats_phi-l_bs8_512_serial.csv > $out/hbm_rate_per_kernel_phi-l_bs8_512.csv 2>/dev/null
+# the headline line last, with the PMC traffic of THIS kernel source in place (bench.py checks the source hash)
+cp $out/hbm_traffic_pmc_phi-l_bs8_512.csv profiles/r02_hbm_traffic_pmc_phi-l_bs8_512.csv
+cp $out/hbm_traffic_pmc_phi-l_bs8_512.csv.meta.json profiles/r02_hbm_traffic_pmc_phi-l_bs8_512.csv.meta.json
+python3 bench.py > $out/bench_phi-l_bs8_512.json 2> $out/bench_l.err
+(echo "# tools/micro/x6_peak.hip: register-resident x6 inner loop, no memory (mfma only / splits only / both)"; timeout 120 tools/micro/x6_peak.bin) > $out/x6_issue_ceiling_micro.txt 2>&1
 ls -la $out
