@@ -206,3 +206,27 @@ def test_bs8_eval_is_permutation_equivariant_bit_for_bit(A, net):
         detp, segp = net(x[perm].contiguous(), r[perm].contiguous())
     assert torch.equal(segp, seg8[perm])
     assert all(torch.equal(a, b[perm]) for a, b in zip(detp, det8))
+
+
+
+def test_forward_backward_repeat_bitwise_over_many_runs(A, net):
+    """25 forward + backward passes at the benchmark configuration with the chains concurrent: outputs and every parameter
+    gradient identical bit for bit.  (The two-run property above misses a fault that strikes one launch in thirty; this
+    soak is what found the conv-epilogue statistics defect of DESIGN 4a.)"""
+    net.train()
+    x, r = A.synthetic_inputs(8, 512, 11, "cuda")
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        d0, s0 = net(x, r)
+    gdet, gseg = upstream(d0, s0, 3)
+    ref, bad = None, []
+    for it in range(25):
+        net.load_state_dict(state)
+        det, seg, grads = run(net, x, r, gdet, gseg)
+        cur = [seg] + det + [grads[k] for k in sorted(grads)]
+        if ref is None:
+            ref = cur
+        elif not all(torch.equal(a, b) for a, b in zip(cur, ref)):
+            bad.append(it)
+    net.load_state_dict(state)
+    assert not bad, f"runs {bad} differ from run 0"
