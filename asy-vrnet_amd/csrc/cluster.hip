@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void cluster_ab_reduce_kernel(const float* par
   }
 }
 
-int cluster_plan(int N, long blocks, int* T, int* npt) {
+int cluster_plan(int N, long blocks, int* T, int* npt, int bwd) {
   if (N > 256) {      // streaming kernel (points re-read in chunks): any region size
     *T = 0;
     *npt = 0;
@@ -708,6 +708,9 @@ int cluster_plan(int N, long blocks, int* T, int* npt) {
   // few region-heads (stages 2-3: B*E*fold^2 = 256 / 64 workgroups): spread each region over 4x the threads
   // (2 points per thread instead of 8) so that the chip holds 4x the waves and loads in flight
   if (blocks <= 256 && N > 4 * (t / 8)) t *= 4;     // measured: 512 workgroups of 256 threads already do better as they are
+  // forward, many region-heads of 256 points: 512 threads x 4 points (110 VGPRs, 16 waves per CU) instead of 256 x 8
+  // (183 VGPRs, 8 waves per CU): +8 % (stage 0: 54.2 -> 49.9 us).  The backward kernel would spill at 128 VGPRs: it stays.
+  if (!bwd && blocks > 256 && t == 256 && N > 128) t = 512;
   static const int force_t = getenv("VRNET_CLUSTER_T") ? atoi(getenv("VRNET_CLUSTER_T")) : 0;      // tuning aid
   if (force_t >= 64 && force_t % 64 == 0 && blocks > 256) t = force_t;
   if (t > 1024) t = 1024;
@@ -745,7 +748,7 @@ int cluster_launch(const ClusterArgs& p, int T, int npt, long blocks, hipStream_
 }
 
 int cluster_check(const char* name, const void* f, const void* v, long ld, int B, int H, int W, int E, int D, int fold,
-                  int* T, int* npt) {
+                  int* T, int* npt, int bwd) {
   VR_CHECK_ARG(f && v, "%s: null tensor", name);
   VR_CHECK_ARG(B > 0 && H > 0 && W > 0 && E > 0 && fold >= 1, "%s: bad shape", name);
   VR_CHECK_ARG(D > 0 && D <= 32 && D % 4 == 0, "%s: head_dim %d unsupported (multiple of 4, <= 32)", name, D);
@@ -753,7 +756,7 @@ int cluster_check(const char* name, const void* f, const void* v, long ld, int B
                "Ensure the feature map size (%d*%d) can be divided by fold %d*%d", H, W, fold, fold);
   VR_CHECK_ARG(ld % 4 == 0 && vr_aligned16(f) && vr_aligned16(v), "%s: rows must be 16-byte aligned", name);
   const int N = (H / fold) * (W / fold);
-  VR_CHECK_ARG(cluster_plan(N, (long)B * E * fold * fold, T, npt) == 0, "%s: unsupported region of %d points", name, N);
+  VR_CHECK_ARG(cluster_plan(N, (long)B * E * fold * fold, T, npt, bwd) == 0, "%s: unsupported region of %d points", name, N);
   return VR_OK;
 }
 
@@ -763,7 +766,7 @@ extern "C" int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, co
                                      float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E,
                                      int D, int fold, const float* alpha2, const float* beta2, void* stream) {
   int T, npt;
-  int rc = cluster_check("cluster_fwd", f, v, ld, B, H, W, E, D, fold, &T, &npt);
+  int rc = cluster_check("cluster_fwd", f, v, ld, B, H, W, E, D, fold, &T, &npt, 0);
   if (rc) return rc;
   VR_CHECK_ARG(out && idx && alpha && beta && ldo % 4 == 0 && vr_aligned16(out), "cluster_fwd: bad output");
   VR_CHECK_ARG(T != 0 || wgt, "cluster_fwd: regions of more than 256 points need the similarity map `wgt` (B,H,W,E)");
@@ -789,7 +792,7 @@ extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, co
                                      int E, int D, int fold, const float* alpha2, const float* beta2, float* dalpha2,
                                      float* dbeta2, void* workspace, long workspace_bytes, void* stream) {
   int T, npt;
-  int rc = cluster_check("cluster_bwd", f, v, ld, B, H, W, E, D, fold, &T, &npt);
+  int rc = cluster_check("cluster_bwd", f, v, ld, B, H, W, E, D, fold, &T, &npt, 1);
   if (rc) return rc;
   VR_CHECK_ARG(idx && dout && df && dv && dalpha && dbeta && workspace, "cluster_bwd: null tensor");
   VR_CHECK_ARG(lddo % 4 == 0 && lddf % 4 == 0 && vr_aligned16(dout) && vr_aligned16(df) && vr_aligned16(dv),
