@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VRNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libvrnet_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -32,6 +32,11 @@ _SIGS = {
     "vrnet_conv2d_wgrad_workspace": ([I] * 8, L),
     "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 14 + [P, P, P, P, P, P, P, P, P, P, L, P], I),
     "vrnet_pack_weight_f32": ([P, P, I, I, I, I, P], I),
+    "vrnet_mlp_fused_ok": ([I, I, L], I),
+    "vrnet_mlp_pack_bytes": ([I, I, I], L),
+    "vrnet_mlp_pack_f32": ([P, P, I, I, I, P, P, P], I),
+    "vrnet_mlp_fwd_f32": ([P, L, P, P, P, P, L, P, P, L, P, L, P, L, I, I, I, P], I),
+    "vrnet_mlp_bwd_f32": ([P, L, P, P, P, L, P, L, P, L, P, L, L, I, I, I, P], I),
     "vrnet_moments_workspace": ([I, L, I], L),
     "vrnet_moments_f32": ([P, L, P, L, P, L, I, L, I, P, P, L, P], I),
     "vrnet_affine_f32": ([P, L, P, P, P, I, P, L, P, L, P, P, P, L, P, L, I, L, I, I, P, L, P], I),
@@ -208,6 +213,30 @@ def bf16_wgrad_ok(ldx, lddy, Cin, Cout):
 
 def pack_weight(w_oihw, out, Cout, Cin, kh, kw):
     _check(_lib.vrnet_pack_weight_f32(ptr(w_oihw), ptr(out), Cout, Cin, kh, kw, stream()), "pack_weight")
+
+
+def mlp_fused_ok(C, HID, M):
+    """Whether the fused fc1 -> GELU -> fc2 kernels exist for block width C, hidden width HID and M rows."""
+    return bool(_lib.vrnet_mlp_fused_ok(C, HID, M))
+
+
+def mlp_pack(w1, w2, C, HID, precision, want_bwd=True):
+    """(forward planes, backward planes) of an Mlp's weights: bf16 planes in MFMA fragment order (vrnet_mlp_pack_f32)."""
+    n = _lib.vrnet_mlp_pack_bytes(C, HID, precision)
+    fwd = torch.empty((n,), dtype=torch.uint8, device=w1.device)
+    bwd = torch.empty((n,), dtype=torch.uint8, device=w1.device) if want_bwd else None
+    _check(_lib.vrnet_mlp_pack_f32(ptr(w1), ptr(w2), C, HID, precision, ptr(fwd), ptr(bwd), stream()), "mlp_pack")
+    return fwd, bwd
+
+
+def mlp_fwd(x, ldx, pack, b1, b2, res, ldres, res_scale, y, ldy, upre, ldu, stats, M, C, HID, precision):
+    _check(_lib.vrnet_mlp_fwd_f32(ptr(x), ldx, ptr(pack), ptr(b1), ptr(b2), ptr(res), ldres, ptr(res_scale), ptr(y), ldy,
+                                  ptr(upre), ldu, ptr(stats), M, C, HID, precision, stream()), "mlp_fwd")
+
+
+def mlp_bwd(dy, lddy, dy_scale, pack, upre, ldu, h, ldh, du, lddu, dx, lddx, M, C, HID, precision):
+    _check(_lib.vrnet_mlp_bwd_f32(ptr(dy), lddy, ptr(dy_scale), ptr(pack), ptr(upre), ldu, ptr(h), ldh, ptr(du), lddu,
+                                  ptr(dx), lddx, M, C, HID, precision, stream()), "mlp_bwd")
 
 
 def moments(x, ldx, B, HW, C, x2=None, ldx2=0, mask=None, ldm=0, out=None):

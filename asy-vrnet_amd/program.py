@@ -80,6 +80,7 @@ class RT:
         self.packed_t = {}
         self.bf16 = False           # dense convs with bf16-rounded operands on the bf16 MFMA (model.compute_dtype)
         self.fp32_precision = 2     # fp32 layers: 2 = six-bf16-product kernels where available, 0 = fp32 MFMA only
+        self.fused_mlp = True       # Mlp of a ClusterBlock as one kernel per direction where the library has one
         self.consts = {}
         self.idx_maps = {}
         self.relu_masks = None      # {BatchNorm module: ReLU output Act} when model.record_relu_masks (parity tests)
@@ -292,6 +293,15 @@ class RT:
             return 1 if hip.bf16_conv_ok(lda, ci, co, 0) else self.fp32_precision
         return self.fp32_precision
 
+    def prec_mlp(self, C, hid, rows, HW):
+        """precision flag of the fused fc1 -> GELU -> fc2 kernels (hip.mlp_fwd / mlp_bwd) for a block, 0 = not fused:
+        2 = x6 (compute_dtype "f32"), 1 = bf16-rounded operands (compute_dtype "bf16"); "f32-mfma" keeps the two convs."""
+        if not self.fused_mlp or HW % 32 or not hip.mlp_fused_ok(C, hid, rows):
+            return 0
+        if self.bf16:
+            return 1
+        return 2 if self.fp32_precision == 2 else 0
+
     def prec_wgrad(self, ldx, lddy, ci, co):
         if self.bf16 and hip.bf16_wgrad_ok(ldx, lddy, ci, co):
             return 1
@@ -457,11 +467,12 @@ def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw
 
 
 def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, skip_bias=False, dx_to=None,
-                  defer_ok=True, ls_grad=None):
+                  defer_ok=True, ls_grad=None, no_dx=False):
     """Gradients of y = conv(x): weight/bias into the parameter table, dx accumulated into x.grad
     (or written to the Act `dx_to`).  dy: tensor whose data_ptr is the (0,0) element, row stride lddy.
     conv / kscale / row_scale / ls_grad may be pairs (two-stream launch).  ls_grad: the layer-scale parameter(s) behind
-    this (1x1) conv: their gradient comes out of the weight-gradient slabs (hip.conv2d_wgrad, dls)."""
+    this (1x1) conv: their gradient comes out of the weight-gradient slabs (hip.conv2d_wgrad, dls).
+    no_dx: parameter gradients only (the fused Mlp kernel has produced the data gradient)."""
     c0, c1 = _pair(conv)
     co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, c0)
     gw, accw = rt.pgrad(c0.weight)
@@ -506,7 +517,7 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
         else:                    # dy is updated in place later in this closure: the weight gradient must read it now
             wgrad()
     target = dx_to if dx_to is not None else (x if x.need_grad else None)
-    if target is not None:
+    if target is not None and not no_dx:
         if dx_to is not None:
             buf, acc, ld = dx_to.t, 0, dx_to.ld
         else:
@@ -722,11 +733,23 @@ def cluster_block(rt, x, m, name=None):
     conv_call(rt, o, _attr(tm, "fc2"), x1, res=x, res_scale=ls1, stats=True)
     xn2, ms2 = gn_forward(rt, x1, _attr(m, "norm2"))
     hid = mlp0.fc1.weight.shape[0]
-    u = rt.new(B, H, W, hid) if rt.record else None
-    h = rt.new(B, H, W, hid)
-    conv_call(rt, xn2, _attr(mlp, "fc1"), h, act=2, ypre=u)
+    u = rt.new(B, H, W, hid, need_grad=False) if rt.record else None
     x2 = rt.new(B, H, W, C)
-    conv_call(rt, h, _attr(mlp, "fc2"), x2, res=x1, res_scale=ls2, stats=True)
+    pmlp = 0 if paired else rt.prec_mlp(C, hid, B * H * W, H * W)
+    if pmlp:
+        # fc1 -> GELU -> fc2 (+ layer-scale residual, + GroupNorm statistics of the output) as ONE kernel: the hidden
+        # activation never reaches HBM; only the pre-activation is stored, for the backward pass
+        packs = hip.mlp_pack(mlp0.fc1.weight, mlp0.fc2.weight, C, hid, pmlp, want_bwd=rt.record)
+        pairs, per = hip.conv_stats_buffer(B, H * W, C, x.t.device)
+        hip.mlp_fwd(xn2.t, xn2.ld, packs[0], mlp0.fc1.bias, mlp0.fc2.bias, x1.t, x1.ld, ls2, x2.t, C,
+                    None if u is None else u.t, hid, pairs, B * H * W, C, hid, pmlp)
+        if pairs is not None:
+            x2.pairs = (pairs, per)
+        h = None
+    else:
+        h = rt.new(B, H, W, hid)
+        conv_call(rt, xn2, _attr(mlp, "fc1"), h, act=2, ypre=u)
+        conv_call(rt, h, _attr(mlp, "fc2"), x2, res=x1, res_scale=ls2, stats=True)
 
     def bwd():
         dx2 = take_grad(x2)
@@ -737,9 +760,17 @@ def cluster_block(rt, x, m, name=None):
         # (conv_backward, ls_grad): the branch outputs are not stored and no (dx, branch) moments pass exists.
         # ---- MLP branch
         du = rt.new(B, H, W, hid)
-        conv_backward(rt, h, _attr(mlp, "fc2"), dx2, C, kscale=ls2, aux=u, row_scale=ls2, dx_to=du, ls_grad=ls2)
         dxn2 = rt.new(B, H, W, C)
-        conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2)
+        if pmlp:
+            # one kernel: d(pre-activation) and the recomputed activation are written once for the two weight gradients,
+            # which run beside the rest of the block's backward like every other weight gradient
+            hb = rt.new(B, H, W, hid, need_grad=False)
+            hip.mlp_bwd(dx2, C, ls2, packs[1], u.t, hid, hb.t, hid, du.t, hid, dxn2.t, C, B * H * W, C, hid, pmlp)
+            conv_backward(rt, hb, mlp0.fc2, dx2, C, row_scale=ls2, ls_grad=ls2, no_dx=True)
+            conv_backward(rt, xn2, mlp0.fc1, du.t, hid, no_dx=True)
+        else:
+            conv_backward(rt, h, _attr(mlp, "fc2"), dx2, C, kscale=ls2, aux=u, row_scale=ls2, dx_to=du, ls_grad=ls2)
+            conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2)
         dx1 = rt.buf(B, H, W, C)
         gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx1, add=dx2)               # dx1 = dx2 + d(GN -> Mlp branch)
         # ---- Cluster branch
@@ -1297,6 +1328,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         # measured (A/B inside one gpurun call, phi=l bs 8 512 px): two chains on two streams 30.8 ms/step, one
         # two-stream chain 31.6 ms/step (and 1 480 instead of 2 070 launches): the default is the faster one
         rt.pair_streams = bool(getattr(model, "pair_streams", False))
+        rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
         cd = str(os.environ.get("VRNET_COMPUTE_DTYPE") or getattr(model, "compute_dtype", "f32")).lower()   # env: diagnostics
         if cd not in ("f32", "fp32", "float32", "torch.float32", "f32-mfma", "bf16", "bfloat16", "torch.bfloat16"):
             raise RuntimeError(f"compute_dtype {cd!r}: expected 'f32', 'f32-mfma' or 'bf16'")

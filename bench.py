@@ -33,9 +33,12 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense bf16 MFMA (no sparsity)
 X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # fp32-equivalent FLOP/s of the x6 kernels: six bf16 MFMAs per fp32 product block
 # matrix-pipe ceiling per kernel family (hip.last_kernel()): fp32-equivalent TFLOP/s
-FAMILY_PEAK = {1: FP32_MFMA_PEAK_TFLOPS, 2: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS, 4: None, 6: X6_PEAK_TFLOPS}
+FAMILY_PEAK = {1: FP32_MFMA_PEAK_TFLOPS, 2: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS, 4: None, 6: X6_PEAK_TFLOPS,
+               7: X6_PEAK_TFLOPS, 8: BF16_MFMA_PEAK_TFLOPS}
 FAMILY_NAME = {1: "fp32 MFMA, register-staged", 2: "fp32 MFMA, LDS-DMA ring", 3: "bf16-rounded operands",
-               4: "direct (tiny channel counts, no MFMA)", 6: "x6: six exact bf16 x bf16 products per fp32 product"}
+               4: "direct (tiny channel counts, no MFMA)", 6: "x6: six exact bf16 x bf16 products per fp32 product",
+               7: "fused Mlp (fc1 -> GELU -> fc2 in one kernel), x6, weights pre-split into bf16 planes",
+               8: "fused Mlp, bf16-rounded operands"}
 
 
 def kernel_source_hash():
@@ -110,6 +113,7 @@ class ConvTimer:
         self.hip = hip
         self.rec = {"igemm": [], "wgrad": [], "cluster_fwd": [], "cluster_bwd": []}
         self.orig = (hip.conv2d, hip.conv2d_wgrad, hip.cluster_fwd, hip.cluster_bwd)
+        self.orig_mlp = (hip.mlp_fwd, hip.mlp_bwd)
 
     def __enter__(self):
         hip, rec = self.hip, self.rec
@@ -146,10 +150,31 @@ class ConvTimer:
             e1.record()
             rec["cluster_bwd"].append((5.0 * B * H * W * E * Dh * 4, e0, e1, f"{H}x{W} E{E} D{Dh} fold{fold}"))      # read f, v, g; write df, dv
         hip.conv2d, hip.conv2d_wgrad, hip.cluster_fwd, hip.cluster_bwd = conv2d, conv2d_wgrad, cluster_fwd, cluster_bwd
+        o_mf, o_mb = self.orig_mlp
+
+        # the fused Mlp launches belong to the same kernel class (dense conv forward / data gradient): one launch does
+        # the work of two 1x1 convs, 2 * (2 * M * C * HID) FLOPs
+        def mlp_fwd(*a):
+            M, C, HID = a[-4], a[-3], a[-2]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_mf(*a)
+            e1.record()
+            rec["igemm"].append((4.0 * M * C * HID, e0, e1, f"mlpF M{M} C{C} H{HID} k{hip.last_kernel()}", hip.last_kernel()))
+
+        def mlp_bwd(*a):
+            M, C, HID = a[-4], a[-3], a[-2]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_mb(*a)
+            e1.record()
+            rec["igemm"].append((4.0 * M * C * HID, e0, e1, f"mlpB M{M} C{C} H{HID} k{hip.last_kernel()}", hip.last_kernel()))
+        hip.mlp_fwd, hip.mlp_bwd = mlp_fwd, mlp_bwd
         return self
 
     def __exit__(self, *a):
         self.hip.conv2d, self.hip.conv2d_wgrad, self.hip.cluster_fwd, self.hip.cluster_bwd = self.orig
+        self.hip.mlp_fwd, self.hip.mlp_bwd = self.orig_mlp
 
     def summary(self, key):
         torch.cuda.synchronize()
@@ -266,6 +291,7 @@ def main():
                     help="image and radar chain of every backbone stage as ONE two-stream batch (one launch per layer) "
                          "instead of two chains on two forked streams")
     ap.add_argument("--no-pair", action="store_true", help="(default) two chains on two forked streams")
+    ap.add_argument("--no-fused-mlp", action="store_true", help="Mlp as two conv launches (A/B aid)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     args = ap.parse_args()
 
@@ -305,6 +331,7 @@ def main():
     if args.serial:
         model.concurrent = False
     model.pair_streams = bool(args.pair)
+    model.fused_mlp = not args.no_fused_mlp
     net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 

@@ -22,10 +22,11 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------- */
-int vrnet_abi_version(void);                 /* == 3 */
+int vrnet_abi_version(void);                 /* == 4 */
 /* Kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to: 1 fp32 MFMA
  * (register-staged), 2 fp32 MFMA (LDS-DMA ring), 3 bf16-rounded operands, 4 direct kernels for tiny channel counts,
- * 6 "x6": every fp32 product as six exact bf16 x bf16 products on the bf16 MFMA, fp32 accumulate. */
+ * 6 "x6": every fp32 product as six exact bf16 x bf16 products on the bf16 MFMA, fp32 accumulate;
+ * 7 / 8: the fused Mlp kernels (vrnet_mlp_fwd_f32 / vrnet_mlp_bwd_f32) at precision 2 (x6) / 1 (bf16-rounded operands). */
 int vrnet_last_kernel(void);
 const char* vrnet_last_error(void);          /* host string, thread local */
 int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sramecc+:xnack-" (synchronous) */
@@ -91,6 +92,37 @@ int vrnet_pack_weight_f32(const float* w_oihw, float* w_tnc, int Cout, int Cin, 
 /* [kh*kw][Cin][Cout] = w_oihw[n][c][t] * kscale[n] (kscale NULL = 1): the data-gradient operand of the bf16 path. */
 int vrnet_pack_weight_t_f32(const float* w_oihw, const float* kscale, float* w_tcn, int Cout, int Cin, int kh, int kw,
                             void* stream);
+
+/* ---- fused Mlp: fc1 -> GELU -> fc2 in ONE kernel per direction ---------------------------------------
+ * Replaces Mlp.forward (backbone/fusion/vr_coc.py:217-223; neck variant backbone/vision/context_cluster.py) together with
+ * the layer-scale residual around it (vr_coc.py:270-271: x + layer_scale_2 * mlp(norm2(x))) and their autograd: the
+ * hidden activation (8x / 4x the block width) never makes a round trip through HBM.  Rows are pixels (M = B*H*W),
+ * C = block width, HID = hidden width; kernels exist for C in {64, 128}, HID % 32 == 0, HID <= 2560, M % 32 == 0
+ * (vrnet_mlp_fused_ok; callers keep the two vrnet_conv2d_f32 launches elsewhere).
+ * Weights are consumed as bf16 PLANES in MFMA fragment order, written once per step by vrnet_mlp_pack_f32 from the
+ * state_dict tensors w1 = fc1.weight [HID][C], w2 = fc2.weight [C][HID] (1x1 OIHW): precision 2 = three planes per weight,
+ * w = p0 + p1 + p2 exactly (round-to-nearest-even splits), and every fp32 product is evaluated as the six bf16 x bf16
+ * products p_i q_j with i + j <= 2 (exact in fp32), fp32 accumulate -- the "x6" arithmetic of vrnet_conv2d_f32 precision
+ * 2; precision 1 = one plane, operands rounded to bf16.  Activations are split / rounded in registers.  vrnet_mlp_pack_bytes
+ * = size of ONE direction's planes.
+ * forward:  u = x w1^T + b1 (stored to upre when non-NULL: the backward pass needs it);  y = res + res_scale * (gelu(u) w2^T
+ *   + b2)  (exact-erf GELU; res / res_scale / b1 / b2 optional);  stats as in vrnet_conv2d_f32 ([M/32][C/32][2] fp64).
+ * backward: given dy and the stored u:  du = gelu'(u) * ((dy * dy_scale) w2);  dx = du w1;  h = gelu(u) is recomputed.
+ *   du and h are written once (operands of the two weight gradients, vrnet_conv2d_wgrad_f32), dx is the data gradient.
+ * x6 on non-finite / tiny operands (both here and in vrnet_conv2d_f32 precision 2): an operand of +-Inf splits into
+ *   (Inf, NaN, NaN), so an Inf in the data yields NaN where fp32 arithmetic yields Inf; NaN stays NaN.  The low planes of an
+ *   operand below 2^-110 in magnitude fall into the bf16 denormal range, which the matrix pipe flushes: such operands
+ *   carry 8-16 instead of 24 significant bits (the product is below 2^-110 |other operand|). */
+int vrnet_mlp_fused_ok(int C, int HID, long M);
+long vrnet_mlp_pack_bytes(int C, int HID, int precision);
+int vrnet_mlp_pack_f32(const float* w1, const float* w2, int C, int HID, int precision, void* pack_fwd, void* pack_bwd,
+                       void* stream);
+int vrnet_mlp_fwd_f32(const float* x, long ldx, const void* pack_fwd, const float* b1, const float* b2, const float* res,
+                      long ldres, const float* res_scale, float* y, long ldy, float* upre, long ldu, double* stats, long M,
+                      int C, int HID, int precision, void* stream);
+int vrnet_mlp_bwd_f32(const float* dy, long lddy, const float* dy_scale, const void* pack_bwd, const float* upre, long ldu,
+                      float* h, long ldh, float* du, long lddu, float* dx, long lddx, long M, int C, int HID, int precision,
+                      void* stream);
 
 /* ---- per-(sample, channel) moments in fp64 ---------------------------------------------------------
  * out[b][c] = { sum_p x, sum_p x*x }                    (x2 == NULL)

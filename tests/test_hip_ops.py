@@ -931,3 +931,105 @@ def test_conv_epilogue_statistics_repeat_bitwise_beside_a_busy_stream(hip, preci
         else:
             bad += int(not (torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1])))
     assert bad == 0, f"{bad} of 399 launches differ"
+
+
+# ---- fused Mlp (fc1 -> GELU -> fc2 in one kernel per direction, vr_coc.py:195-223) against fp64 ATen ------------------
+def _bf16r(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+MLP_CASES = [
+    # B, H, W, C, hid
+    (2, 32, 32, 64, 512),          # stage 0 of phi = l
+    (2, 16, 16, 128, 1024),        # stage 1
+    (1, 8, 12, 64, 128),           # 96 rows: the last wave of the only workgroup is idle
+    (3, 8, 8, 128, 96),            # 3 chunks: odd chunk count
+    (1, 4, 8, 64, 32),             # a single chunk, a single live wave
+]
+
+
+@pytest.mark.parametrize("precision", [2, 1])
+@pytest.mark.parametrize("case", MLP_CASES)
+def test_fused_mlp_against_fp64(hip, case, precision):
+    B, H, W, C, hid = case
+    M = B * H * W
+    assert hip.mlp_fused_ok(C, hid, M)
+    x, res = rnd(M, C, seed=1), rnd(M, C, seed=2)
+    w1, b1 = rnd(hid, C, seed=3) / np.sqrt(C), rnd(hid, seed=4)
+    w2, b2 = rnd(C, hid, seed=5) / np.sqrt(hid), rnd(C, seed=6)
+    ls, dy = rnd(C, seed=7), rnd(M, C, seed=8)
+    d = lambda t: t.double()
+    rd = _bf16r if precision == 1 else (lambda t: t)          # precision 1: both operands of both GEMMs rounded to bf16
+    # ---- reference (fp64 ATen on the CPU)
+    u_ref = d(rd(x)) @ d(rd(w1)).T + d(b1)
+    h_ref = F.gelu(u_ref)
+    y_ref = d(res) + d(ls) * (d(rd(h_ref.float())) @ d(rd(w2)).T + d(b2))
+    # ---- HIP
+    xg, resg = x.cuda(), res.cuda()
+    fwd, bwd = hip.mlp_pack(w1.cuda(), w2.cuda(), C, hid, precision)
+    y, u = torch.empty(M, C, device="cuda"), torch.empty(M, hid, device="cuda")
+    pairs, per = hip.conv_stats_buffer(B, H * W, C, "cuda")
+    assert pairs is not None
+    hip.mlp_fwd(xg, C, fwd, b1.cuda(), b2.cuda(), resg, C, ls.cuda(), y, C, u, hid, pairs, M, C, hid, precision)
+    assert hip.last_kernel() == (7 if precision == 2 else 8)
+    tol = 2e-5 if precision == 2 else 2e-3       # (precision 1: one bf16 rounding of h / du that falls the other way = 2^-8 of that element)
+    close(u, u_ref, 2e-5, what="u")
+    close(y, y_ref, tol, what="y")
+    yd = y.double().view(B, H * W // 32, 32, C // 32, 32)
+    close(pairs[..., 0].view(B, H * W // 32, C // 32), yd.sum((2, 4)), 1e-9, what="tile sums")
+    close(pairs[..., 1].view(B, H * W // 32, C // 32), (yd * yd).sum((2, 4)), 1e-9, what="tile sums of squares")
+    # without the pre-activation output and without statistics (eval / no_grad)
+    y2 = torch.empty(M, C, device="cuda")
+    hip.mlp_fwd(xg, C, fwd, b1.cuda(), b2.cuda(), resg, C, ls.cuda(), y2, C, None, 0, None, M, C, hid, precision)
+    assert torch.equal(y2, y)
+    # ---- backward: given u (as stored by the forward kernel) and dy
+    uu = u.double().cpu()
+    cdf = 0.5 * (1 + torch.erf(uu / np.sqrt(2.0)))
+    gp = cdf + uu * torch.exp(-0.5 * uu * uu) / np.sqrt(2 * np.pi)
+    dh = d(rd((dy * ls))) @ d(rd(w2))
+    du_ref = dh * gp
+    dx_ref = d(rd(du_ref.float())) @ d(rd(w1))
+    hb, du, dx = torch.empty(M, hid, device="cuda"), torch.empty(M, hid, device="cuda"), torch.empty(M, C, device="cuda")
+    hip.mlp_bwd(dy.cuda(), C, ls.cuda(), bwd, u, hid, hb, hid, du, hid, dx, C, M, C, hid, precision)
+    close(hb, uu * cdf, 2e-6, what="recomputed h")
+    close(du, du_ref, 2e-5, what="du")
+    close(dx, dx_ref, tol, what="dx")
+
+
+def test_fused_mlp_rejects_bad_arguments(hip):
+    assert not hip.mlp_fused_ok(96, 512, 1024) and not hip.mlp_fused_ok(64, 500, 1024) and not hip.mlp_fused_ok(64, 512, 1000)
+    w1, w2 = torch.zeros(512, 64, device="cuda"), torch.zeros(64, 512, device="cuda")
+    fwd, _ = hip.mlp_pack(w1, w2, 64, 512, 2)
+    x, y = torch.zeros(128, 64, device="cuda"), torch.zeros(128, 64, device="cuda")
+    with pytest.raises(RuntimeError, match="row stride"):
+        hip.mlp_fwd(x, 32, fwd, None, None, None, 0, None, y, 64, None, 0, None, 128, 64, 512, 2)
+    with pytest.raises(RuntimeError, match="precision"):
+        hip.mlp_fwd(x, 64, fwd, None, None, None, 0, None, y, 64, None, 0, None, 128, 64, 512, 0)
+    with pytest.raises(RuntimeError, match="no fused Mlp kernel"):
+        hip.mlp_fwd(x, 64, fwd, None, None, None, 0, None, y, 64, None, 0, None, 128, 96, 512, 2)
+
+
+def test_gelu_and_derivative_accuracy(hip):
+    """The kernels' exact-erf GELU (common.h: branch-free erf(z) = 1 - Q(s) exp(-z^2)) against fp64, through an identity 1x1
+    conv on the fp32 MFMA (exact for a 0/1 weight matrix): absolute error at the level of torch's own fp32 formula."""
+    C, M = 64, 4096
+    vals = torch.cat([torch.linspace(-9, 9, C * M - 8), torch.tensor([0.0, -0.0, 1e-20, -1e-20, 30.0, -30.0, 1e-4, -1e-4])])
+    x = vals[torch.randperm(C * M, generator=torch.Generator().manual_seed(0))].view(1, 64, 64, C).cuda().contiguous()
+    eye = torch.eye(C).view(C, C, 1, 1).cuda().contiguous()
+    y = torch.empty_like(x)
+    hip.conv2d(x, C, eye, None, y, C, 1, 64, 64, C, 64, 64, C, 1, 1, 1, 0, 1, act=2, precision=0)
+    xd = x.double().cpu()
+    ref = 0.5 * xd * (1 + torch.erf(xd / np.sqrt(2.0)))
+    err = (y.double().cpu() - ref).abs()
+    assert (err / xd.abs().clamp_min(1.0)).max().item() < 2.5e-7          # (torch's own fp32 formula: 1.1e-7 |x|)
+    g = torch.ones_like(x)
+    dx = torch.empty_like(x)
+    hip.conv2d(g, C, eye, None, dx, C, 1, 64, 64, C, 64, 64, C, 1, 1, 1, 0, 1, mode=1, aux=x, ldaux=C, precision=0)
+    gref = 0.5 * (1 + torch.erf(xd / np.sqrt(2.0))) + xd * torch.exp(-0.5 * xd * xd) / np.sqrt(2 * np.pi)
+    assert (dx.double().cpu() - gref).abs().max().item() < 3e-7
+    # non-finite pre-activations: NaN stays NaN (and, as in any fp32 GEMM, poisons only its own pixel's outputs)
+    sp = torch.zeros(1, 8, 8, C, device="cuda")
+    sp[0, 0, 0, 2] = float("nan")
+    ys = torch.empty_like(sp)
+    hip.conv2d(sp, C, eye, None, ys, C, 1, 8, 8, C, 8, 8, C, 1, 1, 1, 0, 1, act=2, precision=0)
+    assert torch.isnan(ys[0, 0, 0, 2]) and torch.isfinite(ys[0, 1:]).all()
