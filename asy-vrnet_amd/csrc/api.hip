@@ -5,7 +5,17 @@
 
 static thread_local char g_err[512] = "";
 static thread_local int g_last_kernel = 0;
-void vr_note_kernel(int id) { g_last_kernel = id; }
+static thread_local long g_kernel_count[16] = {0};
+void vr_note_kernel(int id) {
+  g_last_kernel = id;
+  if (id >= 0 && id < 16) ++g_kernel_count[id];
+}
+#ifdef VR_TUNING
+#include <cstdlib>
+int vr_tune(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 bool vr_ablated(const char* group) {
   static const char* env = getenv("VRNET_ABLATE");
   if (env == nullptr) return false;
@@ -14,11 +24,19 @@ bool vr_ablated(const char* group) {
     if ((t == env || t[-1] == ',') && (t[n] == 0 || t[n] == ',' || t[n] == ' ')) return true;
   return false;
 }
+/* 1 in the diagnostic build (environment knobs and VRNET_ABLATE honoured), 0 in the product library. */
+extern "C" int vrnet_tuning_build(void) { return 1; }
+#else
+extern "C" int vrnet_tuning_build(void) { return 0; }
+#endif
 // Which kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to (bench.py
 // prices each launch against the roofline of the kernel that actually ran):
 //   1 fp32 MFMA register-staged   2 fp32 MFMA LDS-DMA ring   3 bf16-rounded operands   4 direct (tiny channel counts)
 //   6 six exact bf16 x bf16 products per fp32 product (x6), LDS-DMA ring
 extern "C" int vrnet_last_kernel(void) { return g_last_kernel; }
+/* Launches of kernel family `family` (the codes of vrnet_last_kernel) issued by the calling thread since the library was
+ * loaded: lets a caller assert which kernels a whole forward / backward pass actually ran on. */
+extern "C" long vrnet_kernel_launches(int family) { return (family >= 0 && family < 16) ? g_kernel_count[family] : 0; }
 
 void vr_set_error(const char* fmt, ...) {
   va_list ap;

@@ -711,7 +711,7 @@ int cluster_plan(int N, long blocks, int* T, int* npt, int bwd) {
   // forward, many region-heads of 256 points: 512 threads x 4 points (110 VGPRs, 16 waves per CU) instead of 256 x 8
   // (183 VGPRs, 8 waves per CU): +8 % (stage 0: 54.2 -> 49.9 us).  The backward kernel would spill at 128 VGPRs: it stays.
   if (!bwd && blocks > 256 && t == 256 && N > 128) t = 512;
-  static const int force_t = getenv("VRNET_CLUSTER_T") ? atoi(getenv("VRNET_CLUSTER_T")) : 0;      // tuning aid
+  static const int force_t = vr_tune("VRNET_CLUSTER_T", 0);      // tuning aid
   if (force_t >= 64 && force_t % 64 == 0 && blocks > 256) t = force_t;
   if (t > 1024) t = 1024;
   const int pp = t / 8;

@@ -12,9 +12,18 @@
 
 void vr_set_error(const char* fmt, ...);
 void vr_note_kernel(int id);
-// Timing ablation (diagnostic only, results are garbage): VRNET_ABLATE = comma list of kernel groups whose launches are
-// skipped -- igemm, wgrad, moments, affine, cluster, coef, spatial.  Tells how much of the step each group exposes.
+// Tuning knobs and timing ablations exist ONLY in the diagnostic build (make tuning -> libvrnet_hip_tuning.so, compiled
+// with -DVR_TUNING and loaded through VRNET_HIP_LIB): the product library reads no environment variable at all.
+//   vr_tune("VRNET_X", d): integer knob, d in the product build.
+//   vr_ablated(group): VRNET_ABLATE = comma list of kernel groups whose launches are skipped (results are garbage,
+//   timing valid) -- igemm, wgrad, moments, affine, cluster, coef, spatial; always false in the product build.
+#ifdef VR_TUNING
+int vr_tune(const char* name, int dflt);
 bool vr_ablated(const char* group);
+#else
+static inline int vr_tune(const char*, int dflt) { return dflt; }
+static inline bool vr_ablated(const char*) { return false; }
+#endif
 
 #define VR_CHECK_ARG(cond, ...)                 \
   do {                                          \

@@ -1177,6 +1177,15 @@ __global__ void pack_weight_kernel(const float* w, float* out, int Cout, int Cin
 int vr_igemm_bf16_launch(const void* args, int mode, hipStream_t st);
 int vr_wgrad_bf16_launch(const void* args, int ident, int blocks_x, int splits, int streams, hipStream_t st);
 
+// narrowconv.hip
+bool vr_narrow_conv_ok(int Cin, int Cout, int kh, int kw, int stride, int pad);
+bool vr_narrow_wgrad_ok(int Cin, int Cout, int kh, int kw, int stride, int pad);
+int vr_narrow_conv(int mode, const float* a, long lda, const float* w, const float* bias, float* y, long ldy, long M, long HW,
+                   int Cin, int Cout, int out_nchw, int out_ctot, int out_coff, int accumulate, hipStream_t st);
+long vr_narrow_wgrad_workspace(long M, int Cin, int Cout);
+int vr_narrow_wgrad(const float* x, long ldx, const float* dy, long lddy, long M, int Cin, int Cout, void* workspace,
+                    int want_bias, float** slab_out, float** bslab_out, int* splits, hipStream_t st);
+
 // tinyconv.hip
 int vr_tiny_conv(int mode, const float* a, long lda, const float* w, const float* bias, float* y, long ldy, int B, int H,
                  int W, int Cin, int Cout, int k, int pad, int dil, int accumulate, hipStream_t st);
@@ -1194,9 +1203,9 @@ static bool tiny_shape(int H, int W, int Cin, int OH, int OW, int Cout, int kh, 
 // Tile of the LDS-DMA x6 / bf16 kernels for a GEMM of M rows and CN columns: 22 = 128 x 128, 21 = 128 x 64, 0 = none
 // (too few tiles to fill the chip, or <= 32 columns).
 static int vr_dma_tile(long M, int CN) {
-  static const int min_n = getenv("VRNET_X6_MIN_N") ? atoi(getenv("VRNET_X6_MIN_N")) : 96;
-  static const int min_tiles = getenv("VRNET_X6_MIN_TILES") ? atoi(getenv("VRNET_X6_MIN_TILES")) : 256;
-  static const int force = getenv("VRNET_X6_TILE") ? atoi(getenv("VRNET_X6_TILE")) : 0;     // tuning aid: 22 / 21
+  static const int min_n = vr_tune("VRNET_X6_MIN_N", 96);
+  static const int min_tiles = vr_tune("VRNET_X6_MIN_TILES", 256);
+  static const int force = vr_tune("VRNET_X6_TILE", 0);     // tuning aid: 22 / 21
   const long mt = vr_cdiv(M, 128), nt22 = vr_cdiv(CN, 128), nt21 = vr_cdiv(CN, 64);
   const bool waste22 = nt22 * 128 - CN > 16 * nt22;          // more than 12 % of the column tiles is padding
   int tile = 0;
@@ -1238,13 +1247,25 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                "conv2d: output size %dx%d inconsistent with input %dx%d k%d s%d p%d d%d", OH, OW, H, W, kh,
                stride, pad, dil);
   const bool plain = !ypre && !res && !kscale && !aux && !out_nchw && act == 0 && !stats && precision != 1 && !pair_rows;
-  vr_note_kernel(4);
+  if (plain && tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride)) vr_note_kernel(4);
   if (plain && tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride))
     return vr_tiny_conv(mode, a, lda, w, mode == 0 ? bias : nullptr, y, ldy, B, H, W, Cin, Cout, kh, pad, dil, accumulate,
                         vr_stream(stream));
+  // narrow outputs over wide inputs (head predictions, seg logits): direct HBM-streaming kernels (narrowconv.hip)
+  if ((vr_tune("VRNET_NARROW", 3) >> mode & 1) && !ypre && !res && !kscale && !aux && act == 0 && !stats && !pair_rows && precision != 1 &&
+      precision != 3 && vr_narrow_conv_ok(Cin, Cout, kh, kw, stride, pad) && !tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride) && vr_aligned16(w) &&
+      (mode == 0 ? (lda % 4 == 0 && vr_aligned16(a)) : (!out_nchw && ldy % 4 == 0 && vr_aligned16(y)))) {
+    VR_CHECK_ARG(lda >= (mode == 0 ? Cin : Cout) && (out_nchw || ldy >= (mode == 0 ? Cout : Cin)),
+                 "conv2d: row stride smaller than channel count");
+    vr_note_kernel(5);
+    return vr_narrow_conv(mode, a, lda, w, mode == 0 ? bias : nullptr, y, ldy, (long)B * H * W, (long)H * W, Cin, Cout,
+                          mode == 0 ? out_nchw : 0, out_ctot, out_coff, accumulate, vr_stream(stream));
+  }
   if (plain && mode == 1 && Cin <= 8 && kh == kw && kh == stride && pad == 0 && dil == 1 && H == OH * kh &&
-      W == OW * kw && (size_t)kh * kw * Cout * Cin * 4 <= 60000)
+      W == OW * kw && (size_t)kh * kw * Cout * Cin * 4 <= 60000) {
+    vr_note_kernel(4);
     return vr_patch_dgrad(a, lda, w, y, ldy, B, H, W, Cin, Cout, kh, accumulate, vr_stream(stream));
+  }
   IgemmArgs p{};
   p.a = a; p.lda = lda; p.w = w; p.bias = bias; p.y = y; p.ldy = ldy;
   p.ypre = ypre; p.ldypre = ldypre; p.res = res; p.ldres = ldres; p.res_scale = res_scale;
@@ -1310,8 +1331,8 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   const int bn128 = p.CN > 64 ? 128 : (p.CN > 32 ? 64 : 32);
   const long blocks128 = mt128 * vr_cdiv(p.CN, bn128);
   const bool vec = p.a_vec && p.b_vec;
-  static const int force_cfg = getenv("VRNET_IGEMM_CFG") ? atoi(getenv("VRNET_IGEMM_CFG")) : -1;   // tuning aid
-  static const int force_bk = getenv("VRNET_IGEMM_BK") ? atoi(getenv("VRNET_IGEMM_BK")) : 0;   // tuning aid
+  static const int force_cfg = vr_tune("VRNET_IGEMM_CFG", -1);   // tuning aid
+  static const int force_bk = vr_tune("VRNET_IGEMM_BK", 0);   // tuning aid
   const bool bk32 = force_bk == 32;        // BK = 32 measured 3 % slower over the net's shapes (tools/tune_igemm.py --bk)
 #define VR_IGEMM_(BM_, BN_, BK_, TM_, TN_, WM_, WN_, GRID)                                                              \
   do {                                                                                                                  \
@@ -1332,7 +1353,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   // (7 workgroups per CU) beat 128 x 128 (2 per CU) and 128 x 64 on 90 % of the shapes -- 21.4 vs 30.7 / 25.9 ms
   // per step over all forward + data-gradient launches; the exceptions are within 10 %.
   (void)blocks128;
-  static const int use_dma = getenv("VRNET_IGEMM_DMA") ? atoi(getenv("VRNET_IGEMM_DMA")) : 1;   // tuning aid
+  static const int use_dma = vr_tune("VRNET_IGEMM_DMA", 1);   // tuning aid
   // Measured per shape (bench.py --detail): the DMA ring wins where the grid cannot fill the chip with 8 workgroups
   // per CU (M <= 8192 pixels: +5..40 %) and on long contractions; the register-staged kernel keeps the large-M,
   // short-K layers (2048 row tiles x few K steps: its 8 workgroups per CU hide the store-heavy epilogues better).
@@ -1385,7 +1406,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
     return VR_OK;
   }
   int cfg = p.CN > 32 ? 2 : 3;
-  static const int narrow = getenv("VRNET_IGEMM_NARROW") ? atoi(getenv("VRNET_IGEMM_NARROW")) : 1;   // tuning aid
+  static const int narrow = vr_tune("VRNET_IGEMM_NARROW", 1);   // tuning aid
   if (narrow && vec && p.CN > 32 && p.CN <= 192 && ktot >= 512) cfg = 1;      // 128 x 64 tiles for narrow outputs
   if (force_cfg >= 0 && p.CN > 32) cfg = (force_cfg == 0 && p.CN <= 64) ? 1 : force_cfg;
   if (cfg == 2) {
@@ -1418,7 +1439,7 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
                        int* rows, int bf16 = 0) {
   const long wsz = (long)T * Cout * Cin;
   if (bf16 == 2) {      // x6 kernels: cfg = 10 TN + TC, tiles of (64 TN) x (64 TC); 0 = no x6 kernel for this shape
-    static const int x6_wgrad = getenv("VRNET_X6_WGRAD") ? atoi(getenv("VRNET_X6_WGRAD")) : 1;   // tuning aid
+    static const int x6_wgrad = vr_tune("VRNET_X6_WGRAD", 1);   // tuning aid
     *cfg = 0;
     if (!x6_wgrad || Cout <= 32 || Cin <= 32) return;
     const int tn = Cout > 64 ? 2 : 1, tc = Cin > 64 ? 2 : 1;
@@ -1431,8 +1452,8 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
     const long sbytes = (48L << 20) / (wsz * 4);
     // XCD-grouped launch (wgrad_rows_xcd): all tiles of a row split on one XCD, 8 k splits, and at most the 96
     // workgroups an XCD holds at once (32 CUs x 3) per XCD -- otherwise its second round would run nearly empty
-    static const int s8 = getenv("VRNET_X6_WGRAD_S8") ? atoi(getenv("VRNET_X6_WGRAD_S8")) : 1;      // tuning aid
-    static const int per_xcd = getenv("VRNET_X6_WGRAD_PER_XCD") ? atoi(getenv("VRNET_X6_WGRAD_PER_XCD")) : 96;      // tuning aid
+    static const int s8 = vr_tune("VRNET_X6_WGRAD_S8", 1);      // tuning aid
+    static const int per_xcd = vr_tune("VRNET_X6_WGRAD_PER_XCD", 96);      // tuning aid
     if (s8 && tiles <= 96) {
       long g = 8 * (per_xcd / tiles);
       if (g < 8) g = 8;
@@ -1462,7 +1483,7 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
   const long tiles128 = vr_cdiv(Cout, 128) * vr_cdiv(Cin, bn128) * T;
   const long s128 = splits(tiles128);
   const long tiles64 = vr_cdiv(Cout, 64) * vr_cdiv(Cin, 64) * T;
-  static const int force = getenv("VRNET_WGRAD_CFG") ? atoi(getenv("VRNET_WGRAD_CFG")) : -1;   // tuning aid
+  static const int force = vr_tune("VRNET_WGRAD_CFG", -1);   // tuning aid
   const bool small_ok = Cin > 32 && Cout > 32;
   // Measured (tools/tune_igemm.py --wgrad): 64 x 64 tiles win except for the large weight matrices whose
   // 128-wide tiling already yields >= 64 tiles (2560x640, 3x3 512x512, ...).
@@ -1479,6 +1500,38 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
     const long r = vr_cdiv(vr_cdiv(M, s128), BK) * BK;
     *rows = (int)r; *S = (int)vr_cdiv(M, r);
   }
+}
+
+// Slab reduction shared by every weight-gradient kernel: dw / dbias (+ layer-scale partials) from S slabs per stream.
+static int wgrad_reduce_launch(float* slab, float* bslab, float* ls_part, long ls_stride, int S, int T, int Cout, int Cin,
+                               int streams, const float* row_scale, float* dw, float* dbias, int accumulate,
+                               const float* row_scale2, float* dw2, float* dbias2, const float* w, const float* w2,
+                               const float* bias, const float* bias2, float* dls, float* dls2, hipStream_t st) {
+  const bool rvec = (Cin % 4 == 0);                 // slabs are 16-byte aligned (workspace arena), rows of Cin floats
+  const long total = (long)T * Cout * Cin / (rvec ? 4 : 1) + (dbias ? Cout : 0);
+#define VR_WREDUCE(VEC_, SL_)                                                                                        \
+  hipLaunchKernelGGL((wgrad_reduce_kernel<VEC_, SL_>), dim3(vr_cdiv(total, 256 / SL_), streams), dim3(256), 0, st, slab, \
+                     bslab, row_scale, dw, dbias, S, T, Cout, Cin, accumulate, row_scale2, dw2, dbias2, w, w2, ls_part)
+  // lanes per output: enough of them to cover the serial slab loop of the small matrices, one thread per output
+  // once the matrix alone yields >= 64K threads (a 16-lane block there is 6 K workgroups of 256 B of output each)
+  const int sl = (total >= 65536 || S <= 2) ? 1 : ((total >= 16384 || S <= 8) ? 4 : 16);
+  if (rvec) {
+    if (sl == 16) VR_WREDUCE(4, 16);
+    else if (sl == 4) VR_WREDUCE(4, 4);
+    else VR_WREDUCE(4, 1);
+  } else {
+    if (sl == 16) VR_WREDUCE(1, 16);
+    else if (sl == 4) VR_WREDUCE(1, 4);
+    else VR_WREDUCE(1, 1);
+  }
+#undef VR_WREDUCE
+  VR_LAUNCH_CHECK("conv2d_wgrad_reduce");
+  if (dls) {
+    hipLaunchKernelGGL(wgrad_rowdot_kernel, dim3(Cout, streams), dim3(64), 0, st, ls_part, bias, dls, Cout,
+                       (int)((ls_stride - Cout) / Cout), ls_stride, accumulate, bias2, dls2);
+    VR_LAUNCH_CHECK("conv2d_wgrad_rowdot");
+  }
+  return VR_OK;
 }
 
 // pair = 1: two-stream launch (the B samples are two streams of B/2, each with its own weight gradient)
@@ -1499,6 +1552,10 @@ extern "C" long vrnet_conv2d_wgrad_workspace(int B, int OH, int OW, int Cin, int
   need += streams * ((long)Cout * Cin + Cout) * 4;      // layer-scale dot partials (1x1 convs, conv2d_wgrad dls)
   if (Cin <= 8 && Cout <= 8) {
     const long t = vr_tiny_wgrad_workspace((long)B * OH * OW, Cin, Cout, kh * kw);
+    if (t > need) need = t;
+  }
+  if (!pair && vr_narrow_wgrad_ok(Cin, Cout, kh, kw, 1, 0)) {
+    const long t = vr_narrow_wgrad_workspace((long)B * OH * OW, Cin, Cout);
     if (t > need) need = t;
   }
   return need;
@@ -1542,10 +1599,20 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   }
   VR_CHECK_ARG(streams == 1 || !tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride),
                "conv2d_wgrad: two-stream launch of a tiny-channel layer");
-  vr_note_kernel(4);
+  if (tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride)) vr_note_kernel(4);
   if (tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride))
     return vr_tiny_wgrad(x, ldx, dy, lddy, dw, dbias, row_scale, B, H, W, Cin, Cout, kh, pad, dil, accumulate, workspace,
                          vr_stream(stream));
+  if (vr_tune("VRNET_NARROW_WGRAD", 1) && streams == 1 && !dls && vr_narrow_wgrad_ok(Cin, Cout, kh, kw, stride, pad) && ldx % 4 == 0 && vr_aligned16(x)) {
+    float *nslab, *nbslab;
+    int nS;
+    const int rc = vr_narrow_wgrad(x, ldx, dy, lddy, M, Cin, Cout, workspace, dbias != nullptr, &nslab, &nbslab, &nS,
+                                   vr_stream(stream));
+    if (rc) return rc;
+    vr_note_kernel(5);
+    return wgrad_reduce_launch(nslab, nbslab, nullptr, 0, nS, 1, Cout, Cin, 1, row_scale, dw, dbias, accumulate, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, vr_stream(stream));
+  }
   WgradArgs p{};
   p.x = x; p.ldx = ldx; p.dy = dy; p.lddy = lddy;
   p.slab = reinterpret_cast<float*>(workspace);
@@ -1591,7 +1658,7 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
                                                     "are multiples of 4 and more than 32 channels on both sides");
     vr_wgrad_bf16_launch(&p, ident ? 1 : 0, nt * ct * T, S, streams, st);
   } else {
-  static const int use_dma = getenv("VRNET_WGRAD_DMA") ? atoi(getenv("VRNET_WGRAD_DMA")) : 1;   // tuning aid
+  static const int use_dma = vr_tune("VRNET_WGRAD_DMA", 1);   // tuning aid
   // measured (bench.py --detail): the ring wins only for the smallest weight matrices (<= 4 tiles: +5..19 %); with
   // more tiles the row-split grid already fills the chip and the 8-workgroups-per-CU kernel is 5-15 % faster
   if (cfg == 1 && vec && (use_dma == 2 || (use_dma && nt * ct * T <= 4))) {
@@ -1605,31 +1672,8 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
 #undef VR_WGRAD
   vr_note_kernel(x6cfg ? (precision == 2 ? 6 : 3) : (precision == 1 ? 3 : 1));
   VR_LAUNCH_CHECK("conv2d_wgrad");
-  const bool rvec = (Cin % 4 == 0);                 // slabs are 16-byte aligned (workspace arena), rows of Cin floats
-  const long total = (long)T * Cout * Cin / (rvec ? 4 : 1) + (dbias ? Cout : 0);
-#define VR_WREDUCE(VEC_, SL_)                                                                                        \
-  hipLaunchKernelGGL((wgrad_reduce_kernel<VEC_, SL_>), dim3(vr_cdiv(total, 256 / SL_), streams), dim3(256), 0, st, p.slab, \
-                     p.bslab, row_scale, dw, dbias, S, T, Cout, Cin, accumulate, row_scale2, dw2, dbias2, w, w2, ls_part)
-  // lanes per output: enough of them to cover the serial slab loop of the small matrices, one thread per output
-  // once the matrix alone yields >= 64K threads (a 16-lane block there is 6 K workgroups of 256 B of output each)
-  const int sl = (total >= 65536 || S <= 2) ? 1 : ((total >= 16384 || S <= 8) ? 4 : 16);
-  if (rvec) {
-    if (sl == 16) VR_WREDUCE(4, 16);
-    else if (sl == 4) VR_WREDUCE(4, 4);
-    else VR_WREDUCE(4, 1);
-  } else {
-    if (sl == 16) VR_WREDUCE(1, 16);
-    else if (sl == 4) VR_WREDUCE(1, 4);
-    else VR_WREDUCE(1, 1);
-  }
-#undef VR_WREDUCE
-  VR_LAUNCH_CHECK("conv2d_wgrad_reduce");
-  if (dls) {
-    hipLaunchKernelGGL(wgrad_rowdot_kernel, dim3(Cout, streams), dim3(64), 0, st, ls_part, bias, dls, Cout,
-                       (int)((ls_stride - Cout) / Cout), ls_stride, accumulate, bias2, dls2);
-    VR_LAUNCH_CHECK("conv2d_wgrad_rowdot");
-  }
-  return VR_OK;
+  return wgrad_reduce_launch(p.slab, p.bslab, ls_part, ls_stride, S, T, Cout, Cin, streams, row_scale, dw, dbias, accumulate,
+                             row_scale2, dw2, dbias2, w, w2, bias, bias2, dls, dls2, st);
 }
 
 extern "C" int vrnet_pack_weight_f32(const float* w_oihw, float* w_tnc, int Cout, int Cin, int kh, int kw,

@@ -34,6 +34,8 @@ struct MlpArgs {
   const float* res_scale;              // forward: layer scale [C] (NULL = 1)
   double* stats; int stats_nb;         // forward: (sum, sumsq) of the stored outputs per 32 x 32 tile (igemm_common.h)
   int M, HID;
+  int dbg;                             // diagnostic build only (VRNET_MLP_DBG): bit 0 = skip the hidden-sized stores, bit 1 =
+                                       // counted wait that leaves the stores in flight (unsafe: timing experiments only)
 };
 
 constexpr int MLP_HID_MAX = 2560;
@@ -101,6 +103,12 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
   }
   issue(0);
   for (int hc = 0; hc < nchunks; ++hc) {
+#ifdef VR_TUNING
+    if (p.dbg & 2) {
+      if (MODE == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
 #pragma unroll
         for (int j = 0; j < 4; ++j) t4[j] += *reinterpret_cast<const f32x4*>(bias_s + 32 * hc + 8 * j + 4 * hf);
       }
-      if (p.upre && live) {
+      if (p.upre && live && !(p.dbg & 1)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(p.upre + row * p.ldu + 32 * hc + 8 * j + 4 * hf) = t4[j];
       }
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
           h4[j][e] = vr_gelu_both(uin[j][e], grad);
           t4[j][e] *= grad;
         }
-      if (live) {
+      if (live && !(p.dbg & 1)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           *reinterpret_cast<f32x4*>(p.hout + row * p.ldh + 32 * hc + 8 * j + 4 * hf) = h4[j];
@@ -338,6 +346,7 @@ extern "C" int vrnet_mlp_fwd_f32(const float* x, long ldx, const void* pack_fwd,
   p.x = x; p.ldx = ldx; p.wpack = reinterpret_cast<const unsigned short*>(pack_fwd); p.bias_a = b1;
   p.upre = upre; p.ldu = ldu; p.y = y; p.ldy = ldy; p.bias_b = b2; p.res = res; p.ldres = ldres; p.res_scale = res_scale;
   p.stats = stats; p.stats_nb = C / 32; p.M = (int)M; p.HID = HID;
+  p.dbg = vr_tune("VRNET_MLP_DBG", 0);
   if (C == 64) mlp_launch<64>(p, 0, precision, vr_stream(stream));
   else mlp_launch<128>(p, 0, precision, vr_stream(stream));
   vr_note_kernel(precision == 2 ? 7 : 8);
@@ -361,6 +370,7 @@ extern "C" int vrnet_mlp_bwd_f32(const float* dy, long lddy, const float* dy_sca
   p.x = dy; p.ldx = lddy; p.xscale = dy_scale; p.wpack = reinterpret_cast<const unsigned short*>(pack_bwd);
   p.upre = const_cast<float*>(upre); p.ldu = ldu; p.hout = h; p.ldh = ldh; p.du = du; p.lddu = lddu; p.y = dx; p.ldy = lddx;
   p.M = (int)M; p.HID = HID;
+  p.dbg = vr_tune("VRNET_MLP_DBG", 0);
   if (C == 64) mlp_launch<64>(p, 1, precision, vr_stream(stream));
   else mlp_launch<128>(p, 1, precision, vr_stream(stream));
   vr_note_kernel(precision == 2 ? 7 : 8);

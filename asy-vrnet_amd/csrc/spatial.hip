@@ -666,7 +666,7 @@ extern "C" int vrnet_dwconv3x3_f32(const float* x, long ldx, const float* w, flo
   VR_CHECK_ARG((long)B * H * W * C < (1L << 31), "dwconv3x3: tensor too large");
   const bool vec = C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && ldx % 4 == 0 && ldy % 4 == 0 && vr_aligned16(x) &&
                    vr_aligned16(y) && vr_aligned16(w);
-  static const int slide = getenv("VRNET_DW_SLIDE") ? atoi(getenv("VRNET_DW_SLIDE")) : 1;     // tuning aid
+  static const int slide = vr_tune("VRNET_DW_SLIDE", 1);     // tuning aid
   if (vec && slide && W % 8 == 0) {
     const long items = (long)B * H * (W / 8) * (C / 4);
     hipLaunchKernelGGL((dwconv3x3_slide_kernel<8>), dim3(vr_cdiv(items, 256)), dim3(256), 0, vr_stream(stream), x, ldx, w, y,

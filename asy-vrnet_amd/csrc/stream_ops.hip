@@ -389,29 +389,37 @@ __global__ void bn_coef_bwd_kernel(const double* mom2, const float* mean_rstd, c
   dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
 }
 
-// BatchNorm coefficients straight from the moments kernel's chunk partials [B][nchunks][C][2]: 16 lanes per channel add
-// the B * nchunks partials of their channel in a fixed pattern, lane 0 finishes the channel -- the separate
-// moments_reduce launch and the [B][C][2] table disappear (100 launches per training step).
+// BatchNorm coefficients straight from the moments kernel's chunk partials [B][nchunks][C][2]: ONE WAVE per channel -- lane l
+// adds partials l, l + 64, ... (four independent loads in flight per trip), the 64 lane sums are added by a butterfly in a
+// fixed pattern (deterministic), lane 0 finishes the channel.  The separate moments_reduce launch and the [B][C][2] table
+// disappear (100 launches per training step).  (Round 2 gave a channel 16 lanes of a workgroup that covered 16 channels:
+// C / 16 workgroups -- 4 at the widest maps -- each walking up to 128 partials per lane in a dependent loop, 18 us per
+// launch on average for an O(C) result.)
 __device__ __forceinline__ void bn_channel_sums(const double* partial, int B, int nchunks, int C, int c, bool live,
-                                                double (&red)[16][16][2], double& s1, double& s2) {
-  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  double a1 = 0.0, a2 = 0.0;
+                                                double& s1, double& s2) {
+  const int lane = threadIdx.x & 63;
+  double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0, c1 = 0.0, c2 = 0.0, d1 = 0.0, d2 = 0.0;
   if (live) {
     const int total = B * nchunks;
-    for (int j = sl; j < total; j += 16) {
-      const double* src = partial + ((long)j * C + c) * 2;
-      a1 += src[0];
-      a2 += src[1];
+    const double* base = partial + (long)c * 2;
+    const long step = (long)C * 2;
+    int j = lane;
+    for (; j + 192 < total; j += 256) {
+      const double* q0 = base + (long)j * step;
+      const double* q1 = q0 + 64 * step;
+      const double* q2 = q1 + 64 * step;
+      const double* q3 = q2 + 64 * step;
+      const double v0 = q0[0], w0 = q0[1], v1 = q1[0], w1 = q1[1], v2 = q2[0], w2 = q2[1], v3 = q3[0], w3 = q3[1];
+      a1 += v0; a2 += w0; b1 += v1; b2 += w1; c1 += v2; c2 += w2; d1 += v3; d2 += w3;
+    }
+    for (; j < total; j += 64) {
+      const double* q0 = base + (long)j * step;
+      a1 += q0[0];
+      a2 += q0[1];
     }
   }
-  red[sl][o][0] = a1;
-  red[sl][o][1] = a2;
-  __syncthreads();
-  s1 = 0.0; s2 = 0.0;
-  if (sl == 0) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { s1 += red[k][o][0]; s2 += red[k][o][1]; }
-  }
+  s1 = wave_sum((a1 + b1) + (c1 + d1));
+  s2 = wave_sum((a2 + b2) + (c2 + d2));
 }
 
 __global__ __launch_bounds__(256) void bn_coef_fwd_partial_kernel(const double* partial, int nchunks, const float* gamma,
@@ -419,13 +427,12 @@ __global__ __launch_bounds__(256) void bn_coef_fwd_partial_kernel(const double* 
                                                                   float* running_mean, float* running_var, long long* nbt,
                                                                   int B, long HW, int C, float* A, float* D, float* S,
                                                                   float* mean_rstd) {
-  __shared__ double red[16][16][2];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool live = c < C;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   double s1, s2;
-  bn_channel_sums(partial, B, nchunks, C, c, live, red, s1, s2);
-  if ((threadIdx.x >> 4) != 0 || !live) return;
+  bn_channel_sums(partial, B, nchunks, C, c, live, s1, s2);
+  if ((threadIdx.x & 63) != 0 || !live) return;
   const double n = (double)B * HW;
   const double mean = s1 / n;
   double var = s2 / n - mean * mean;
@@ -444,12 +451,11 @@ __global__ __launch_bounds__(256) void bn_coef_bwd_partial_kernel(const double* 
                                                                   const float* gamma, int training, int B, long HW, int C,
                                                                   float* A, float* E, float* D, float* S, float* dgamma,
                                                                   float* dbeta, int accumulate) {
-  __shared__ double red[16][16][2];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool live = c < C;
   double s1, s2;
-  bn_channel_sums(partial, B, nchunks, C, c, live, red, s1, s2);
-  if ((threadIdx.x >> 4) != 0 || !live) return;
+  bn_channel_sums(partial, B, nchunks, C, c, live, s1, s2);
+  if ((threadIdx.x & 63) != 0 || !live) return;
   const double mu = mean_rstd[2 * c], r = mean_rstd[2 * c + 1], g = gamma[c];
   const double n = (double)B * HW;
   const double dxh = r * (s2 - mu * s1);   // sum dy * xhat
@@ -601,7 +607,7 @@ __global__ void fill_kernel(float* dst, float v, long n) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) dst[e] = v;
 }
 
-static int moments_plan(long HW, int C, int vec, int* TPR, int* ncb, int* nchunks, long* rows) {
+static int moments_plan(int B, long HW, int C, int vec, int* TPR, int* ncb, int* nchunks, long* rows) {
   const int CV = C / vec;
   int t = 1;
   while (t < CV && t < 256) t <<= 1;
@@ -610,6 +616,9 @@ static int moments_plan(long HW, int C, int vec, int* TPR, int* ncb, int* nchunk
   long nc = vr_cdiv(HW * C, 4096);    // >= 16 elements per thread: B x nc x ncb workgroups must cover 256 CUs several
   if (nc < 1) nc = 1;                  // times over even for one 16x16 map; the chunk reduce is lane-parallel
   if (nc > 512) nc = 512;
+  // ... but not more chunks than ~1024 workgroups need (4 per CU): every chunk is one more partial for the reduce pass
+  const long by_grid = vr_cdiv(1024, (long)B * *ncb);
+  if (nc > by_grid) nc = by_grid;
   if (nc > HW) nc = HW;
   *rows = vr_cdiv(HW, nc);
   *nchunks = (int)vr_cdiv(HW, *rows);
@@ -621,7 +630,10 @@ static int moments_plan(long HW, int C, int vec, int* TPR, int* ncb, int* nchunk
 extern "C" long vrnet_moments_workspace(int B, long HW, int C) {
   int TPR, ncb, nchunks;
   long rows;
-  moments_plan(HW, C, 1, &TPR, &ncb, &nchunks, &rows);
+  moments_plan(B, HW, C, 1, &TPR, &ncb, &nchunks, &rows);
+  int nchunks4 = 0;
+  if (C % 4 == 0) moments_plan(B, HW, C, 4, &TPR, &ncb, &nchunks4, &rows);      // the vector kernel may plan more chunks
+  if (nchunks4 > nchunks) nchunks = nchunks4;
   return (long)B * nchunks * C * 2 * 8 + 256;
 }
 
@@ -636,7 +648,7 @@ static int moments_launch(const float* x, long ldx, const float* x2, long ldx2, 
   if (mask) vec = vec && (ldm % 4 == 0) && vr_aligned16(mask);
   int TPR, ncb, nchunks;
   long rows;
-  moments_plan(HW, C, vec ? 4 : 1, &TPR, &ncb, &nchunks, &rows);
+  moments_plan(B, HW, C, vec ? 4 : 1, &TPR, &ncb, &nchunks, &rows);
   if (workspace_bytes < vrnet_moments_workspace(B, HW, C)) {
     vr_set_error("moments: workspace too small");
     return VR_ERR_WORKSPACE;
@@ -767,7 +779,7 @@ extern "C" int vrnet_bn_stats_fwd(const float* x, long ldx, const float* gamma, 
   int nchunks;
   int rc = moments_launch(x, ldx, nullptr, 0, nullptr, 0, B, HW, C, workspace, workspace_bytes, st, &nchunks);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_coef_fwd_partial_kernel, dim3(vr_cdiv(C, 16)), dim3(256), 0, st, reinterpret_cast<double*>(workspace),
+  hipLaunchKernelGGL(bn_coef_fwd_partial_kernel, dim3(vr_cdiv(C, 4)), dim3(256), 0, st, reinterpret_cast<double*>(workspace),
                      nchunks, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, B, HW, C, A, D, S,
                      mean_rstd);
   VR_LAUNCH_CHECK("bn_stats_fwd");
@@ -784,7 +796,7 @@ extern "C" int vrnet_bn_stats_bwd(const float* dy, long lddy, const float* z, lo
   int nchunks;
   int rc = moments_launch(dy, lddy, z, ldz, mask, ldm, B, HW, C, workspace, workspace_bytes, st, &nchunks);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_coef_bwd_partial_kernel, dim3(vr_cdiv(C, 16)), dim3(256), 0, st, reinterpret_cast<double*>(workspace),
+  hipLaunchKernelGGL(bn_coef_bwd_partial_kernel, dim3(vr_cdiv(C, 4)), dim3(256), 0, st, reinterpret_cast<double*>(workspace),
                      nchunks, mean_rstd, gamma, training, B, HW, C, A, E, D, S, dgamma, dbeta, accumulate);
   VR_LAUNCH_CHECK("bn_stats_bwd");
   return VR_OK;

@@ -18,10 +18,30 @@ import torch
 from . import program
 
 
+def replay_segments(graphs, bucketer):
+    """One captured step: replays the segment graphs in order; with a data-parallel bucketer, the all-reduce of the arena
+    slice segment k completed is issued right behind graph k (it runs beside the replay of k + 1), and the step ends when
+    every collective has finished.  `graphs`: objects with .replay()."""
+    if bucketer is None:
+        graphs[0].replay()
+    elif len(graphs) == 1:
+        graphs[0].replay()
+        bucketer.allreduce_all()
+    else:
+        for k, g in enumerate(graphs):
+            g.replay()
+            bucketer.allreduce_segment(k)
+        bucketer.wait()
+
+
 class GraphedStep:
     """step(x, x_radar) -> loss tensor; parameter .grad tensors are static and rewritten by each replay.
 
-    `net` is EfficientVRNet or parallel.DataParallelVRNet; loss_fn(det list, seg) -> scalar tensor."""
+    `net` is EfficientVRNet or parallel.DataParallelVRNet; loss_fn(det list, seg) -> scalar tensor.
+    Construction runs `warmup` eager passes on zero inputs (workspaces, caches, with data parallelism the recording pass
+    and its collectives -- so every rank must construct it) and then captures; the module's buffers (BatchNorm running
+    statistics, num_batches_tracked) are restored afterwards, so building a GraphedStep on a loaded checkpoint leaves
+    the checkpoint's statistics untouched."""
 
     def __init__(self, net, loss_fn, batch, size, device, warmup=2, segments=None):
         self.net, self.loss_fn = net, loss_fn
@@ -31,6 +51,7 @@ class GraphedStep:
         self.x = torch.zeros((batch, 3, size, size), device=device)
         self.r = torch.zeros((batch, 4, size, size), device=device)
         cur = torch.cuda.current_stream(device)
+        saved = [(b, b.detach().clone()) for b in self.model.buffers() if b.numel()]
         self.stream = torch.cuda.Stream(device)          # warm-up AND capture run here: scratch arenas (hip.Workspace is
         self.stream.wait_stream(cur)                     # keyed by stream) exist before the capture and belong to no graph pool
         with torch.cuda.stream(self.stream):
@@ -40,14 +61,22 @@ class GraphedStep:
                     self.bucketer.rebuild_from_recording()      # arena in execution order before anything is captured
         cur.wait_stream(self.stream)
         torch.cuda.synchronize(device)
+        with torch.no_grad():
+            for b, old in saved:                         # the warm-up's zero-input statistics must not leak into the model
+                b.copy_(old)
         if self.bucketer is None:
             self.model.zero_grad(set_to_none=True)
             cuts = []
         else:
-            self.bucketer.deferred = True
             cuts = list(self.bucketer.cuts) if (segments is None or segments > 1) else []
         self.graphs = []
-        self._capture(cuts)
+        if self.bucketer is None:
+            self._capture(cuts)
+        else:
+            # no collective may be issued from inside the captured backward; OUTSIDE the capture the bucketer is back in
+            # its eager, overlapped mode, so a plain `net(x, r)` + backward (odd last batch, validation) still reduces
+            with self.bucketer.deferring():
+                self._capture(cuts)
 
     def _eager(self):
         det, seg = self.net(self.x, self.r)
@@ -96,15 +125,7 @@ class GraphedStep:
     def __call__(self, x, x_radar):
         self.x.copy_(x, non_blocking=True)
         self.r.copy_(x_radar, non_blocking=True)
-        bk = self.bucketer
-        if bk is None:
-            self.graphs[0].replay()
-        elif len(self.graphs) == 1:
-            self.graphs[0].replay()
-            bk.allreduce_all()
-        else:
-            for k, g in enumerate(self.graphs):
-                g.replay()
-                bk.allreduce_segment(k)
-            bk.wait()
+        if getattr(self.net, "broadcast_buffers", False) and self.model.training:
+            self.net.sync_buffers()
+        replay_segments(self.graphs, self.bucketer)
         return self.loss

@@ -25,6 +25,8 @@ _SIGS = {
     "vrnet_abi_version": ([], I),
     "vrnet_last_error": ([], ctypes.c_char_p),
     "vrnet_last_kernel": ([], I),
+    "vrnet_tuning_build": ([], I),
+    "vrnet_kernel_launches": ([I], L),
     "vrnet_device_arch": ([ctypes.c_char_p, I], I),
     "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
@@ -104,6 +106,16 @@ def _check(rc, name):
 
 
 _DTYPES = frozenset((torch.float32, torch.float64, torch.uint8, torch.int64, torch.int32))
+
+
+def tuning_build():
+    """True when the loaded library is the diagnostic build (environment knobs / launch-skipping ablations compiled in)."""
+    return bool(_lib.vrnet_tuning_build())
+
+
+def kernel_launches(family):
+    """Launches of a kernel family (codes of last_kernel) by this thread so far."""
+    return _lib.vrnet_kernel_launches(family)
 
 
 def last_kernel():

@@ -134,3 +134,265 @@ def _conv_bwd(ctx, g):
 
 
 conv2d_nhwc.register_autograd(_conv_bwd, setup_context=_conv_setup)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Further fused ops of the path, same pattern: custom op + fake kernel + backward op + autograd + autocast.
+#   y = torch.ops.vrnet.mlp(x, w1, b1, w2, b2, res, ls)            # res + ls * fc2(gelu(fc1(x))): ONE kernel per direction
+#   y = torch.ops.vrnet.group_norm1(x, gamma, beta, eps)             # GroupNorm(1, C) over NHWC, vr_coc.py:105-111
+#   y = torch.ops.vrnet.batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu)
+#   y = torch.ops.vrnet.dwconv3x3(x, w)                              # depthwise 3x3, stride 1, pad 1, NHWC
+#   y = torch.ops.vrnet.upsample_bilinear(x, scale)                  # align_corners=True, NHWC
+def _rows(x):
+    B, H, W, C = x.shape
+    return B, H, W, C, B * H * W
+
+
+@torch.library.custom_op("vrnet::mlp", mutates_args=(), device_types="cuda")
+def mlp(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, res: torch.Tensor,
+        ls: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """x, res: (B,H,W,C) NHWC fp32; w1: (HID,C,1,1), w2: (C,HID,1,1) as in Mlp.state_dict(); ls: (C,) layer scale.
+    Returns (res + ls * (gelu(x w1^T + b1) w2^T + b2), pre-activation (B,H,W,HID) for the backward pass)."""
+    x, res = x.contiguous(), res.contiguous()
+    B, H, W, C, M = _rows(x)
+    hid = w1.shape[0]
+    if not hip.mlp_fused_ok(C, hid, M):
+        raise RuntimeError(f"vrnet::mlp: no fused kernel for C={C}, hidden={hid}, rows={M} (C in (64, 128), hidden % 32 == 0, rows % 32 == 0)")
+    y, u = torch.empty_like(x), torch.empty((B, H, W, hid), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        fwd, _ = hip.mlp_pack(w1.contiguous(), w2.contiguous(), C, hid, 2, want_bwd=False)
+        hip.mlp_fwd(x, C, fwd, b1, b2, res, C, ls, y, C, u, hid, None, M, C, hid, 2)
+    return y, u
+
+
+@mlp.register_fake
+def _(x, w1, b1, w2, b2, res, ls):
+    return torch.empty_like(x), x.new_empty((*x.shape[:3], w1.shape[0]))
+
+
+@torch.library.custom_op("vrnet::mlp_backward", mutates_args=(), device_types="cuda")
+def mlp_backward(g: torch.Tensor, x: torch.Tensor, u: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
+                 ls: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    g, x = g.contiguous(), x.contiguous()
+    B, H, W, C, M = _rows(x)
+    hid = w1.shape[0]
+    h, du, dx = torch.empty_like(u), torch.empty_like(u), torch.empty_like(x)
+    dw1, db1 = torch.empty_like(w1, memory_format=torch.contiguous_format), torch.empty(hid, device=x.device)
+    dw2, db2, dls = torch.empty_like(w2, memory_format=torch.contiguous_format), torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    with torch.cuda.device(x.device):
+        _, bwd = hip.mlp_pack(w1.contiguous(), w2.contiguous(), C, hid, 2)
+        hip.mlp_bwd(g, C, ls, bwd, u, hid, h, hid, du, hid, dx, C, M, C, hid, 2)
+        hip.conv2d_wgrad(h, hid, g, C, dw2, db2, ls, B, H, W, hid, H, W, C, 1, 1, 1, 0, 1, precision=2, w=w2.contiguous(), bias=b2, dls=dls)
+        hip.conv2d_wgrad(x, C, du, hid, dw1, db1, None, B, H, W, C, H, W, hid, 1, 1, 1, 0, 1, precision=2)
+    return dx, dw1, db1, dw2, db2, dls
+
+
+@mlp_backward.register_fake
+def _(g, x, u, w1, w2, b2, ls):
+    return torch.empty_like(x), torch.empty_like(w1), w1.new_empty((w1.shape[0],)), torch.empty_like(w2), torch.empty_like(ls), torch.empty_like(ls)
+
+
+def _mlp_setup(ctx, inputs, output):
+    x, w1, b1, w2, b2, res, ls = inputs
+    ctx.save_for_backward(x, output[1], w1, w2, b2, ls)
+
+
+def _mlp_bwd(ctx, g, g_u):
+    x, u, w1, w2, b2, ls = ctx.saved_tensors
+    dx, dw1, db1, dw2, db2, dls = torch.ops.vrnet.mlp_backward(g, x, u, w1, w2, b2, ls)
+    return dx, dw1, db1, dw2, db2, g, dls
+
+
+mlp.register_autograd(_mlp_bwd, setup_context=_mlp_setup)
+
+
+@torch.library.custom_op("vrnet::group_norm1", mutates_args=(), device_types="cuda")
+def group_norm1(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """GroupNorm(1, C) of an NHWC tensor: statistics in fp64, torch's (x - mean) * rstd * gamma + beta order.
+    Returns (y, (B,2) mean / rstd)."""
+    x = x.contiguous()
+    B, H, W, C, _ = _rows(x)
+    A, D, S, ms = (torch.empty((B, C), device=x.device) for _ in range(3)) + (torch.empty((B, 2), device=x.device),)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        hip.gn_stats_fwd(x, C, gamma, beta, eps, B, H * W, C, A, D, S, ms)
+        hip.affine(y, C, B, H * W, C, x1=x, ld1=C, A=A, D1=D, S1=S, bstride=C)
+    return y, ms
+
+
+@group_norm1.register_fake
+def _(x, gamma, beta, eps):
+    return torch.empty_like(x), x.new_empty((x.shape[0], 2))
+
+
+@torch.library.custom_op("vrnet::group_norm1_backward", mutates_args=(), device_types="cuda")
+def group_norm1_backward(g: torch.Tensor, x: torch.Tensor, ms: torch.Tensor, gamma: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    g, x = g.contiguous(), x.contiguous()
+    B, H, W, C, _ = _rows(x)
+    dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+    A, E, D, S = (torch.empty((B, C), device=x.device) for _ in range(4))
+    with torch.cuda.device(x.device):
+        mom2 = hip.moments(g, C, B, H * W, C, x2=x, ldx2=C)
+        hip.gn_coef_bwd(mom2, ms, gamma, B, H * W, C, A, E, D, S, dg, db, 0)
+        hip.affine(dx, C, B, H * W, C, x1=g, ld1=C, A=A, x2=x, ld2=C, E=E, D2=D, S2=S, bstride=C)
+    return dx, dg, db
+
+
+@group_norm1_backward.register_fake
+def _(g, x, ms, gamma):
+    return torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+
+
+def _gn_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], output[1], inputs[1])
+
+
+def _gn_bwd(ctx, g, g_ms):
+    x, ms, gamma = ctx.saved_tensors
+    dx, dg, db = torch.ops.vrnet.group_norm1_backward(g, x, ms, gamma)
+    return dx, dg, db, None
+
+
+group_norm1.register_autograd(_gn_bwd, setup_context=_gn_setup)
+
+
+@torch.library.custom_op("vrnet::batch_norm_act", mutates_args=(), device_types="cuda")
+def batch_norm_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: torch.Tensor, running_var: torch.Tensor,
+                   training: bool, momentum: float, eps: float, relu: bool) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """BatchNorm2d over NHWC (+ ReLU), BaseConv's tail (normal_conv.py:45-49): batch statistics in fp64; functional -- the
+    updated running statistics (unbiased variance, as nn.BatchNorm2d) are RETURNED, the caller copies them into the
+    module's buffers.  Returns (y, (C,2) mean / rstd, new running_mean, new running_var)."""
+    x = x.contiguous()
+    B, H, W, C, _ = _rows(x)
+    A, D, S, ms = (torch.empty(C, device=x.device) for _ in range(3)) + (torch.empty((C, 2), device=x.device),)
+    rm, rv = running_mean.clone(), running_var.clone()
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        if training:
+            hip.bn_stats_fwd(x, C, gamma, beta, eps, momentum, rm, rv, None, B, H * W, C, A, D, S, ms)
+        else:
+            hip.bn_coef_fwd(None, gamma, beta, eps, momentum, rm, rv, None, False, B, H * W, C, A, D, S, ms)
+        hip.affine(y, C, B, H * W, C, x1=x, ld1=C, A=A, D1=D, S1=S, pre=1 if relu else 0)
+    return y, ms, rm, rv
+
+
+@batch_norm_act.register_fake
+def _(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    return torch.empty_like(x), x.new_empty((x.shape[-1], 2)), torch.empty_like(running_mean), torch.empty_like(running_var)
+
+
+@torch.library.custom_op("vrnet::batch_norm_act_backward", mutates_args=(), device_types="cuda")
+def batch_norm_act_backward(g: torch.Tensor, x: torch.Tensor, y: torch.Tensor, ms: torch.Tensor, gamma: torch.Tensor, training: bool,
+                            relu: bool) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    g, x = g.contiguous(), x.contiguous()
+    B, H, W, C, _ = _rows(x)
+    dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+    A, E, D, S = (torch.empty(C, device=x.device) for _ in range(4))
+    mask = y if relu else None
+    with torch.cuda.device(x.device):
+        hip.bn_stats_bwd(g, C, x, C, mask, C if relu else 0, ms, gamma, training, B, H * W, C, A, E, D, S, dg, db, 0)
+        hip.affine(dx, C, B, H * W, C, x1=g, ld1=C, A=A, pre=2 if relu else 0, masky=mask, ldm=C if relu else 0, x2=x, ld2=C, E=E,
+                   D2=D, S2=S)
+    return dx, dg, db
+
+
+@batch_norm_act_backward.register_fake
+def _(g, x, y, ms, gamma, training, relu):
+    return torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+
+
+def _bn_setup(ctx, inputs, output):
+    x, gamma, beta, rm, rv, training, momentum, eps, relu = inputs
+    ctx.save_for_backward(x, output[0], output[1], gamma)
+    ctx.flags = (training, relu)
+
+
+def _bn_bwd(ctx, g, g_ms, g_rm, g_rv):
+    x, y, ms, gamma = ctx.saved_tensors
+    dx, dg, db = torch.ops.vrnet.batch_norm_act_backward(g, x, y, ms, gamma, *ctx.flags)
+    return dx, dg, db, None, None, None, None, None, None
+
+
+batch_norm_act.register_autograd(_bn_bwd, setup_context=_bn_setup)
+
+
+@torch.library.custom_op("vrnet::dwconv3x3", mutates_args=(), device_types="cuda")
+def dwconv3x3(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """Depthwise 3x3, stride 1, pad 1 (DWConv.dconv, normal_conv.py:23-33); x (B,H,W,C) NHWC, w (C,1,3,3)."""
+    x = x.contiguous()
+    B, H, W, C, _ = _rows(x)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        hip.dwconv3x3(x, C, w.contiguous(), y, C, B, H, W, C)
+    return y
+
+
+@dwconv3x3.register_fake
+def _(x, w):
+    return torch.empty_like(x)
+
+
+@torch.library.custom_op("vrnet::dwconv3x3_backward", mutates_args=(), device_types="cuda")
+def dwconv3x3_backward(g: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    g, x = g.contiguous(), x.contiguous()
+    B, H, W, C, _ = _rows(x)
+    dx, dw = torch.empty_like(x), torch.empty_like(w, memory_format=torch.contiguous_format)
+    with torch.cuda.device(x.device):
+        hip.dwconv3x3(g, C, w.contiguous(), dx, C, B, H, W, C, flip=1)
+        hip.dwconv3x3_wgrad(x, C, g, C, dw, B, H, W, C)
+    return dx, dw
+
+
+@dwconv3x3_backward.register_fake
+def _(g, x, w):
+    return torch.empty_like(x), torch.empty_like(w)
+
+
+dwconv3x3.register_autograd(lambda ctx, g: tuple(torch.ops.vrnet.dwconv3x3_backward(g, *ctx.saved_tensors)),
+                            setup_context=lambda ctx, inputs, output: ctx.save_for_backward(*inputs))
+
+
+@torch.library.custom_op("vrnet::upsample_bilinear", mutates_args=(), device_types="cuda")
+def upsample_bilinear(x: torch.Tensor, scale: int) -> torch.Tensor:
+    """nn.Upsample(scale_factor, mode='bilinear', align_corners=True) on NHWC (coc_fpn_dual.py:19-22)."""
+    x = x.contiguous()
+    B, H, W, C, _ = _rows(x)
+    y = torch.empty((B, H * scale, W * scale, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        hip.upsample(x, C, y, C, B, H, W, C, scale)
+    return y
+
+
+@upsample_bilinear.register_fake
+def _(x, scale):
+    B, H, W, C = x.shape
+    return x.new_empty((B, H * scale, W * scale, C))
+
+
+@torch.library.custom_op("vrnet::upsample_bilinear_backward", mutates_args=(), device_types="cuda")
+def upsample_bilinear_backward(g: torch.Tensor, scale: int) -> torch.Tensor:
+    g = g.contiguous()
+    B, HS, WS, C = g.shape
+    dx = torch.empty((B, HS // scale, WS // scale, C), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        hip.upsample_bwd(g, C, 0, dx, C, B, HS // scale, WS // scale, C, scale)
+    return dx
+
+
+@upsample_bilinear_backward.register_fake
+def _(g, scale):
+    B, HS, WS, C = g.shape
+    return g.new_empty((B, HS // scale, WS // scale, C))
+
+
+def _up_setup(ctx, inputs, output):
+    ctx.scale = inputs[1]
+
+
+upsample_bilinear.register_autograd(lambda ctx, g: (torch.ops.vrnet.upsample_bilinear_backward(g, ctx.scale), None),
+                                    setup_context=_up_setup)
+
+# Autocast policy (the reference trains under torch.cuda.amp.autocast, utils/utils_fit.py:86-88): these ops compute in fp32
+# whatever the autocast dtype, i.e. floating-point arguments are cast to fp32 on the way in.
+for _op in ("cluster", "conv2d_nhwc", "mlp", "group_norm1", "batch_norm_act", "dwconv3x3", "upsample_bilinear"):
+    torch.library.register_autocast(f"vrnet::{_op}", "cuda", torch.float32)

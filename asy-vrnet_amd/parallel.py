@@ -25,6 +25,9 @@ gradients are averaged over ranks.  Differences, by design for MI355X:
   (train.py:440 freezes the backbone behind the DDP wrap) keep their slot, are reduced as zeros and get .grad = None;
 * gradients do not accumulate across backward passes in this mode (each pass overwrites).
 """
+import contextlib
+import hashlib
+
 import torch
 import torch.distributed as dist
 
@@ -47,6 +50,7 @@ class GradBucketer:
         self.force_collective = False   # issue the collectives even with one rank (single-GPU test of the RCCL path)
         self.recording = ready_pos is None          # first pass: stamp parameters with their tape position
         self.params = [p for p in params_in_backward_order if p.numel() > 0]
+        self._index = {p: i for i, p in enumerate(self.params)}     # rank-independent name of a parameter (registration order)
         self.ready_pos = dict(ready_pos) if ready_pos is not None else {}
         self._rec_order = {}
         self._layout()
@@ -128,6 +132,40 @@ class GradBucketer:
         self.reset()
         for p in self.params:
             p.grad = None
+        self.check_layout_across_ranks()
+
+    def layout_signature(self):
+        """Hash of everything the collectives depend on: arena order (by registration index), sizes, cut positions and
+        segment slices."""
+        h = hashlib.sha256()
+        h.update(repr([(self._index[p], p.numel()) for p in self.params]).encode())
+        h.update(repr((list(self.cuts), sorted(self.segment_slices.items()), [b.numel() for b in self.buckets])).encode())
+        return int.from_bytes(h.digest()[:7], "little")
+
+    def check_layout_across_ranks(self):
+        """Every rank derives the arena layout from ITS OWN recording pass; a rank that recorded something else (another
+        frozen set, an exception in its first backward) would reduce mismatched slices silently.  All ranks exchange the
+        layout hash and raise together on a mismatch."""
+        if not _dist_on(self.group) or dist.get_world_size(self.group) < 2:
+            return
+        dev = self.arena.device if self.arena is not None else "cpu"
+        mine = torch.tensor([self.layout_signature()], dtype=torch.int64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size(self.group))]
+        dist.all_gather(every, mine, group=self.group)
+        sigs = [int(t.item()) for t in every]
+        if len(set(sigs)) != 1:
+            raise RuntimeError(f"data parallel: gradient-arena layouts differ between ranks (hashes {sigs}): the ranks did "
+                               "not record the same backward pass (different frozen parameters? a failed first step?)")
+
+    @contextlib.contextmanager
+    def deferring(self):
+        """Scope in which no collective is issued from inside the backward pass (HIP-graph capture: the collectives are
+        issued between the captured segments instead).  Outside it the eager, overlapped mode is in force again."""
+        old, self.deferred = self.deferred, True
+        try:
+            yield self
+        finally:
+            self.deferred = old
 
     def reset(self):
         self.pending = list(self.pending0)
@@ -219,9 +257,17 @@ def backward_param_order(model):
 class DataParallelVRNet(torch.nn.Module):
     """Drop-in for DistributedDataParallel(EfficientVRNet) on one node (one process per GPU)."""
 
-    def __init__(self, module, bucket_bytes=32 << 20, process_group=None, force_collective=False, segments=3):
+    def __init__(self, module, bucket_bytes=32 << 20, process_group=None, force_collective=False, segments=3,
+                 broadcast_buffers=False):
+        """broadcast_buffers: the reference's DDP default (train.py:367-368 leaves broadcast_buffers=True): rank 0's
+        BatchNorm running statistics overwrite the other ranks' before every training forward.  Off by default here:
+        rank-0 checkpoints (the only ones the reference writes, utils_fit.py:213-225) are identical either way, ranks
+        != 0 then evaluate with their own running statistics, and the step saves a collective.  The constant position
+        buffers (fea_pos, fea_pos_r: 2 x 524 288 floats) are never re-sent."""
         super().__init__()
         self.module = module
+        self.group = process_group
+        self.broadcast_buffers = broadcast_buffers
         self.bucketer = GradBucketer(backward_param_order(module), bucket_bytes, process_group, segments=segments)
         self.bucketer.force_collective = force_collective   # collectives even with one rank (single-GPU RCCL rehearsal)
         module._grad_bucketer = self.bucketer
@@ -236,7 +282,26 @@ class DataParallelVRNet(torch.nn.Module):
     def forward(self, x, x_radar):
         if self.bucketer.recording and self.bucketer.ready_pos and torch.is_grad_enabled():
             self.finalize_layout()                      # the previous backward was the recording pass
+        if self.broadcast_buffers and self.module.training and torch.is_grad_enabled():
+            self.sync_buffers()
         return self.module(x, x_radar)
+
+    def sync_buffers(self):
+        """Rank 0's non-constant buffers to every rank: one broadcast per dtype (flattened), not one per buffer."""
+        if not self.bucketer._collective_on():
+            return
+        by_dtype = {}
+        for name, b in self.module.named_buffers():
+            if b.numel() and not name.endswith(("fea_pos", "fea_pos_r")):
+                by_dtype.setdefault(b.dtype, []).append(b)
+        with torch.no_grad():
+            for bufs in by_dtype.values():
+                flat = torch.cat([b.reshape(-1) for b in bufs])
+                dist.broadcast(flat, src=0, group=self.group)
+                off = 0
+                for b in bufs:
+                    b.copy_(flat[off:off + b.numel()].view_as(b))
+                    off += b.numel()
 
     def finalize_layout(self):
         """Call after the first backward pass (the recording pass): rebuilds the arena in execution order.  Done

@@ -33,10 +33,10 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense bf16 MFMA (no sparsity)
 X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # fp32-equivalent FLOP/s of the x6 kernels: six bf16 MFMAs per fp32 product block
 # matrix-pipe ceiling per kernel family (hip.last_kernel()): fp32-equivalent TFLOP/s
-FAMILY_PEAK = {1: FP32_MFMA_PEAK_TFLOPS, 2: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS, 4: None, 6: X6_PEAK_TFLOPS,
+FAMILY_PEAK = {1: FP32_MFMA_PEAK_TFLOPS, 2: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS, 4: None, 5: None, 6: X6_PEAK_TFLOPS,
                7: X6_PEAK_TFLOPS, 8: BF16_MFMA_PEAK_TFLOPS}
 FAMILY_NAME = {1: "fp32 MFMA, register-staged", 2: "fp32 MFMA, LDS-DMA ring", 3: "bf16-rounded operands",
-               4: "direct (tiny channel counts, no MFMA)", 6: "x6: six exact bf16 x bf16 products per fp32 product",
+               4: "direct (tiny channel counts, no MFMA)", 5: "direct (narrow outputs over wide inputs, HBM streams, no MFMA)", 6: "x6: six exact bf16 x bf16 products per fp32 product",
                7: "fused Mlp (fc1 -> GELU -> fc2 in one kernel), x6, weights pre-split into bf16 planes",
                8: "fused Mlp, bf16-rounded operands"}
 
@@ -78,6 +78,20 @@ def pmc_traffic_bytes(phi):
             n += k
             tot += k * float(row["avg_HBM_MB"]) * 1024 * 1024
     return round(tot / n) if n else None
+
+
+def x6_issue_ceiling():
+    """Best measured rate of the register-resident x6 loop with in-register operand splits (tools/micro/x6_peak.hip), read
+    from the committed micro-benchmark output; None when no such file exists."""
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_x6_issue_ceiling_micro.txt"))):
+        for line in open(f):
+            m = re.match(r"\s*2x2 both .*?:\s*[\d.]+ ms\s+([\d.]+) TF", line)
+            if m:
+                best = max(best or 0.0, float(m.group(1)))
+    return best
 
 
 def conv_flops(B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil):
@@ -309,6 +323,11 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
 
+    # Measurement hygiene: no tuning / diagnostic knob may be active in a benchmark run.  The product library reads no
+    # environment at all (the knobs are compiled into the diagnostic build only); the host-side ones are refused here.
+    knobs = sorted(k for k in os.environ if k.startswith("VRNET_") and k != "VRNET_BENCH_FORCE_DP")
+    if knobs:
+        raise SystemExit(f"bench.py: refusing to run with diagnostic environment variables set: {', '.join(knobs)}")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -325,6 +344,8 @@ def main():
     import asy_vrnet_amd as A
     from asy_vrnet_amd import hip
     from asy_vrnet_amd.parallel import DataParallelVRNet
+    if hip.tuning_build():
+        raise SystemExit("bench.py: the loaded library is the diagnostic build (make tuning); benchmark the product library")
     model = A.EfficientVRNet(4, 9, args.phi, img_size=args.size).to(dev).train()
     A.randomize_state_dict(model.state_dict(), seed=0)
     model.compute_dtype = args.dtype
@@ -353,10 +374,11 @@ def main():
             def step(i):
                 gs(*batches[i])
         except Exception as e:                      # capture unsupported: fall back to eager launches
+            if dist.is_initialized():
+                # data parallel: a per-rank fallback would pair one rank's bucket collectives with another rank's segment
+                # collectives (a hang); fail the whole job instead
+                raise
             print(f"hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            bk = getattr(model, "_grad_bucketer", None)
-            if bk is not None:
-                bk.deferred = False
 
     def fence():
         torch.cuda.synchronize()
@@ -414,7 +436,7 @@ def main():
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
                 "frac": round(ach / peak, 4),
                 "peak_note": "FLOP-weighted matrix-pipe ceiling of the kernel mix that ran (x6 416.7 = bf16 2500 / 6; fp32 MFMA 157.3)",
-                "x6_issue_ceiling": {"value": 250.0, "unit": "TFLOP/s (fp32-equivalent)",
+                "x6_issue_ceiling": {"value": x6_issue_ceiling(), "unit": "TFLOP/s (fp32-equivalent)",
                                      "note": "measured, register-resident x6 loop: the fragment splits (VALU) and the MFMAs do not "
                                              "overlap on gfx950, their times add -- tools/micro/x6_peak.hip, "
                                              "profiles/r02_x6_issue_ceiling_micro.txt"},
@@ -449,12 +471,16 @@ def main():
                 "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": f"EfficientVRNet(phi={args.phi}) forward+backward, {args.size}x{args.size} image + "
                                        f"4x{args.size}x{args.size} radar, bs={args.batch}/GPU, "
-                                       + ("fp32, det+seg heads (BASELINE.json configs[1])" if args.dtype == "f32" else
-                                          "bf16-operand dense convs with fp32 accumulation, everything else fp32 "
-                                          "(BASELINE.json configs[2] family; NOT the headline fp32 metric)")
+                                       + {"f32": "fp32, det+seg heads (BASELINE.json configs[1])",
+                                          "f32-mfma": "fp32, every dense conv on the fp32 MFMA (v_mfma_f32_32x32x2_f32) only -- the x6 "
+                                                      "kernels and the fused Mlp kernels switched off (comparison run, NOT the "
+                                                      "headline configuration)",
+                                          "bf16": "bf16-operand dense convs with fp32 accumulation, everything else fp32 "
+                                                  "(BASELINE.json configs[2] family; NOT the headline fp32 metric)"}[args.dtype]
                                        + "; random weights",
                            "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}", "launch": launch},
-                "roofline": roof, "cpu_baseline": cpu}
+                "roofline": roof, "cpu_baseline": cpu,
+                "env": {k: v for k, v in os.environ.items() if k.startswith("VRNET_")}, "schema": 3}
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -25,10 +25,17 @@ extern "C" {
 int vrnet_abi_version(void);                 /* == 4 */
 /* Kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to: 1 fp32 MFMA
  * (register-staged), 2 fp32 MFMA (LDS-DMA ring), 3 bf16-rounded operands, 4 direct kernels for tiny channel counts,
+ * 5 direct HBM-streaming kernels for 1x1 convs with <= 16 output channels over wide inputs (head predictions, seg logits),
  * 6 "x6": every fp32 product as six exact bf16 x bf16 products on the bf16 MFMA, fp32 accumulate;
  * 7 / 8: the fused Mlp kernels (vrnet_mlp_fwd_f32 / vrnet_mlp_bwd_f32) at precision 2 (x6) / 1 (bf16-rounded operands). */
 int vrnet_last_kernel(void);
+/* Launches of kernel family `family` (same codes) issued by the calling thread since the library was loaded. */
+long vrnet_kernel_launches(int family);
 const char* vrnet_last_error(void);          /* host string, thread local */
+/* 0 for the product library, which reads NO environment variable; 1 for the diagnostic build (make tuning:
+ * libvrnet_hip_tuning.so, -DVR_TUNING) in which the VRNET_* dispatch knobs and the VRNET_ABLATE launch-skipping timing
+ * ablation exist.  Benchmarks must refuse a library that answers 1. */
+int vrnet_tuning_build(void);
 int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sramecc+:xnack-" (synchronous) */
 
 /* ---- dense convolution as implicit GEMM on the fp32 MFMA ------------------------------------------

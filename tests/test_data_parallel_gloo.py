@@ -130,3 +130,107 @@ def test_first_guess_order_is_reverse_forward():
     names = {id(p): k for k, p in m.named_parameters()}
     order = [names[id(p)] for p in backward_param_order(m)]
     assert order[0].startswith("head.") and order[-1].startswith("backbone.backbone.image_initial")
+
+
+def _worker_hardening(rank, world, port, q):
+    """deferring() scope, layout-hash exchange, the captured step's segment / all-reduce sequencing (stub graphs) and the
+    optional buffer broadcast -- world size 2, gloo."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from asy_vrnet_amd.parallel import GradBucketer, DataParallelVRNet, backward_param_order
+    from asy_vrnet_amd.graph import replay_segments
+    import asy_vrnet_amd as A
+    torch.manual_seed(0)
+    model = A.EfficientVRNet(4, 9, "nano", img_size=64)
+    mean = sum(range(1, world + 1)) / world
+    ok = True
+    # ---- recording pass, identical on both ranks -> rebuild passes the cross-rank layout check
+    bk = GradBucketer(backward_param_order(model), bucket_bytes=1 << 20, segments=3)
+    order, pos = _execution_like_order(bk.params)
+    for p in order:
+        bk.view(p).fill_(1.0)
+        bk.mark_ready(p, pos[p])
+    bk.finish()
+    bk.rebuild_from_recording()
+    sig = bk.layout_signature()
+    ok = ok and len(bk.cuts) == 2
+    # ---- (ADVICE r2) a captured step exists, then an EAGER step runs: the bucketer must reduce again outside deferring()
+    with bk.deferring():
+        for p in order:
+            bk.view(p).fill_(float(rank + 1))
+            bk.mark_ready(p, pos[p])
+        ok = ok and not bk.works                       # nothing is sent from inside a capture
+        bk.finish()
+    ok = ok and not bk.deferred
+    for p in order:
+        bk.view(p).fill_(float(rank + 1))
+        bk.mark_ready(p, pos[p])
+    ok = ok and len(bk.works) > 0                       # eager mode again: bucket collectives in flight during the pass
+    bk.finish()
+    ok = ok and all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in order)
+    # ---- captured step with stub graphs: "graph k" writes the gradients of segment k; the slice of segment k is reduced
+    # right behind it, before graph k + 1 has written anything
+    seg_of = lambda p: sum(1 for c in bk.cuts if pos[p] < c)
+    log = []
+
+    class StubGraph:
+        def __init__(self, k):
+            self.k = k
+
+        def replay(self):
+            log.append(("replay", self.k))
+            for p in order:
+                if seg_of(p) == self.k:
+                    bk.view(p).fill_(float(rank + 1) * (self.k + 1))
+
+    orig = bk.allreduce_segment
+
+    def spy(k):
+        log.append(("allreduce", k))
+        orig(k)
+    bk.allreduce_segment = spy
+    bk.arena.zero_()
+    replay_segments([StubGraph(k) for k in range(3)], bk)
+    ok = ok and log == [("replay", 0), ("allreduce", 0), ("replay", 1), ("allreduce", 1), ("replay", 2), ("allreduce", 2)]
+    ok = ok and all(torch.allclose(bk.view(p), torch.full_like(p, mean * (seg_of(p) + 1))) for p in order) and not bk.works
+    bk.arena.zero_()
+    replay_segments([StubGraph(0)], bk)                # single-graph variant: ONE collective over the arena afterwards
+    ok = ok and all(torch.allclose(bk.view(p), torch.full_like(p, mean if seg_of(p) == 0 else 0.0)) for p in order)
+    # ---- a rank that recorded a different backward: every rank raises instead of reducing mismatched slices
+    bk2 = GradBucketer(backward_param_order(model), bucket_bytes=1 << 20, segments=3)
+    order2 = order if rank == 0 else order[1:] + order[:1]
+    for i, p in enumerate(order2):
+        bk2.view(p).fill_(1.0)
+        bk2.mark_ready(p, 40 - (40 * i) // len(order2))
+    bk2.finish()
+    try:
+        bk2.rebuild_from_recording()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "layouts differ" in str(e)
+    ok = ok and bk2.layout_signature() != sig if rank == 1 else ok
+    # ---- optional buffer broadcast (the reference's DDP default): BatchNorm statistics follow rank 0, fea_pos is not sent
+    net = DataParallelVRNet(model, broadcast_buffers=True)
+    bn = model.head.stems[0].bn
+    with torch.no_grad():
+        bn.running_mean.fill_(float(rank + 5))
+        bn.num_batches_tracked.fill_(rank + 7)
+        model.backbone.backbone.fea_pos.fill_(float(rank))
+    net.sync_buffers()
+    ok = ok and float(bn.running_mean[0]) == 5.0 and int(bn.num_batches_tracked) == 7
+    ok = ok and float(model.backbone.backbone.fea_pos.flatten()[0]) == float(rank)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_hardening_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hardening, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res), res

@@ -64,6 +64,15 @@ CONV_CASES = [
     (2, 32, 32, 48, 384, 1, 1, 0, 1),
     (8, 32, 32, 96, 48, 1, 1, 0, 1),
     (2, 16, 16, 960, 240, 1, 1, 0, 1),
+    (2, 16, 16, 256, 4, 1, 1, 0, 1),     # narrow outputs over wide inputs (narrowconv.hip): head predictions ...
+    (2, 16, 16, 256, 1, 1, 1, 0, 1),
+    (1, 32, 32, 128, 9, 1, 1, 0, 1),     # ... and the seg-logit conv
+    (3, 7, 5, 64, 5, 1, 1, 0, 1),        # ragged row count
+    (2, 8, 8, 192, 12, 1, 1, 0, 1),      # K / 4 = 48 quads on 64 threads
+    (2, 8, 8, 512, 4, 1, 1, 0, 1),       # K > 256: only the weight gradient is narrow
+    (2, 64, 64, 32, 16, 1, 1, 0, 1),     # 16 outputs: forward / data gradient on the MFMA, weight gradient narrow
+    (2, 64, 64, 32, 11, 1, 1, 0, 1),     # 8 threads per row
+    (2, 64, 64, 16, 9, 1, 1, 0, 1),
 ]
 
 
@@ -206,12 +215,16 @@ def test_group_norm_chain(hip):
     close(dbet, bet.grad, what="gn dbeta")
 
 
-@pytest.mark.parametrize("shape", [(3, 10, 12, 24), (2, 32, 32, 48), (2, 16, 16, 96), (2, 8, 8, 240)])
+@pytest.mark.parametrize("shape", [(3, 10, 12, 24), (2, 32, 32, 48), (2, 16, 16, 96), (2, 8, 8, 240),
+                                   (2, 256, 256, 4), (8, 128, 128, 64)])      # > 256 chunk partials per channel
 @pytest.mark.parametrize("training", [True, False])
 def test_batch_norm_relu_chain(hip, training, shape):
     B, H, W, C = shape
     z = (rnd(B, C, H, W, seed=1) * 1.5 + 40.0).requires_grad_(True)      # |mean| >> std: the cancellation-prone regime
-    gam, bet = (rnd(C, seed=2) * 0.3 + 1).requires_grad_(True), (rnd(C, seed=3) * 0.5).requires_grad_(True)
+    # (the two large maps: all pre-activations positive -- among millions of elements some lie within fp32 rounding of zero,
+    #  and their ReLU mask bit then differs between any two evaluations, torch's own fp32 and fp64 included)
+    shift = 8.0 if B * H * W > 10000 else 0.0
+    gam, bet = (rnd(C, seed=2) * 0.3 + 1).requires_grad_(True), (rnd(C, seed=3) * 0.5 + shift).requires_grad_(True)
     rm, rv = rnd(C, seed=4) * 0.1, rnd(C, seed=5, kind="uniform") + 0.5
     rm0, rv0 = rm.clone(), rv.clone()
     y = torch.relu(F.batch_norm(z, rm, rv, gam, bet, training, 0.03, 1e-3))
@@ -862,41 +875,84 @@ X6_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", X6_CASES)
-def test_x6_conv_matches_fp32_mfma_path(hip, case):
+def _conv_suite_inputs(case):
     B, H, W, Ci, Co, k, s, p, d = case
     OH, OW = (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
-    x = nhwc(rnd(B, Ci, H, W, seed=1))
-    w = rnd(Co, Ci, k, k, seed=2) / np.sqrt(Ci * k * k)
-    wp, b, ls = pack(hip, w), rnd(Co, seed=3).cuda(), rnd(Co, seed=4).cuda()
-    res = nhwc(rnd(B, Co, OH, OW, seed=5))
-    outs = {}
-    for prec in (0, 2):
-        y, ypre = torch.empty(B, OH, OW, Co, device="cuda"), torch.empty(B, OH, OW, Co, device="cuda")
-        st, per = hip.conv_stats_buffer(B, OH * OW, Co, x.device)
-        hip.conv2d(x, Ci, wp, b, y, Co, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, act=2, ypre=ypre, ldypre=Co, res=res, ldres=Co,
-                   res_scale=ls, stats=st, precision=prec)
-        fam_f = hip.last_kernel()
-        g, aux = nhwc(rnd(B, Co, OH, OW, seed=6)), nhwc(rnd(B, Ci, H, W, seed=7))
-        dx = nhwc(rnd(B, Ci, H, W, seed=8))                       # accumulate into existing contents
-        hip.conv2d(g, Co, wp, None, dx, Ci, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, mode=1, kscale=ls, aux=aux, ldaux=Ci,
-                   accumulate=1, precision=prec)
-        fam_d = hip.last_kernel()
-        dw, db, dl = torch.empty(Co, Ci, k, k, device="cuda"), torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
-        kw = dict(w=w.cuda().contiguous(), bias=b, dls=dl) if k == 1 else {}
-        hip.conv2d_wgrad(x, Ci, g, Co, dw, db, ls, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, precision=prec, **kw)
-        fam_w = hip.last_kernel()
-        dw_nb = torch.full((Co, Ci, k, k), 7.0, device="cuda")     # without a bias gradient (BaseConv), accumulating
-        guard = torch.zeros(4096, device="cuda")
-        hip.conv2d_wgrad(x, Ci, g, Co, dw_nb, None, None, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, accumulate=1, precision=prec)
-        outs[prec] = (y, ypre, st.view(B, -1, 2).sum(1) if st is not None else None, dx, dw, db, dl if k == 1 else None,
-                      (fam_f, fam_d, fam_w), dw_nb)
+    return dict(x=rnd(B, Ci, H, W, seed=1), w=rnd(Co, Ci, k, k, seed=2) / np.sqrt(Ci * k * k), b=rnd(Co, seed=3), ls=rnd(Co, seed=4),
+                res=rnd(B, Co, OH, OW, seed=5), g=rnd(B, Co, OH, OW, seed=6), aux=rnd(B, Ci, H, W, seed=7), dx0=rnd(B, Ci, H, W, seed=8),
+                OH=OH, OW=OW)
+
+
+def _conv_suite(hip, case, prec):
+    """Every way the network launches a dense conv, at one precision: forward with bias + pre-activation copy + GELU +
+    layer-scale residual + output statistics; data gradient with contraction scale, GELU' epilogue and accumulation; weight
+    / bias gradient with row scale and (1x1) the layer-scale gradient; weight gradient without bias, accumulating.
+    Returns (y, ypre, per-sample (sum, sumsq), dx, dw, db, dls, kernel families, dw_nb)."""
+    B, H, W, Ci, Co, k, s, p, d = case
+    t = _conv_suite_inputs(case)
+    OH, OW = t["OH"], t["OW"]
+    x, wp, b, ls, res = nhwc(t["x"]), pack(hip, t["w"]), t["b"].cuda(), t["ls"].cuda(), nhwc(t["res"])
+    y, ypre = torch.empty(B, OH, OW, Co, device="cuda"), torch.empty(B, OH, OW, Co, device="cuda")
+    st, per = hip.conv_stats_buffer(B, OH * OW, Co, x.device)
+    hip.conv2d(x, Ci, wp, b, y, Co, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, act=2, ypre=ypre, ldypre=Co, res=res, ldres=Co,
+               res_scale=ls, stats=st, precision=prec)
+    fam_f = hip.last_kernel()
+    g, aux, dx = nhwc(t["g"]), nhwc(t["aux"]), nhwc(t["dx0"])     # dx: accumulate into existing contents
+    hip.conv2d(g, Co, wp, None, dx, Ci, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, mode=1, kscale=ls, aux=aux, ldaux=Ci,
+               accumulate=1, precision=prec)
+    fam_d = hip.last_kernel()
+    dw, db, dl = torch.empty(Co, Ci, k, k, device="cuda"), torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
+    kw = dict(w=t["w"].cuda().contiguous(), bias=b, dls=dl) if k == 1 else {}
+    hip.conv2d_wgrad(x, Ci, g, Co, dw, db, ls, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, precision=prec, **kw)
+    fam_w = hip.last_kernel()
+    dw_nb = torch.full((Co, Ci, k, k), 7.0, device="cuda")     # without a bias gradient (BaseConv), accumulating
+    hip.conv2d_wgrad(x, Ci, g, Co, dw_nb, None, None, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, accumulate=1, precision=prec)
+    return (y, ypre, st.view(B, -1, 2).sum(1) if st is not None else None, dx, dw, db, dl if k == 1 else None,
+            (fam_f, fam_d, fam_w), dw_nb)
+
+
+@pytest.mark.parametrize("case", X6_CASES)
+def test_x6_conv_matches_fp32_mfma_path(hip, case):
+    outs = {prec: _conv_suite(hip, case, prec) for prec in (0, 2)}
     assert 6 in outs[2][7], outs[2][7]                            # at least one launch ran on an x6 kernel
     assert 6 not in outs[0][7]
     for name, a, b_ in zip(("y", "ypre", "stats", "dx", "dw", "db", "dls"), outs[2], outs[0]):
         if a is not None:
             close(a, b_, 2e-5, what=f"x6 {name} {outs[2][7]}")
     close(outs[2][8], outs[0][8], 2e-5, what="x6 dw without bias, accumulate")
+
+
+@pytest.mark.parametrize("case", X6_CASES)
+def test_x6_conv_against_fp64_aten(hip, case):
+    """The dominant kernels (precision 2: fp32 products as six bf16 x bf16 products) DIRECTLY against fp64 ATen on the CPU --
+    forward, data gradient, weight / bias / layer-scale gradient with every epilogue the network uses, on shapes large
+    enough for the x6 tile kernels to be dispatched (incl. ragged tiles, a contraction that is no multiple of 16, 3x3, stride
+    2 with parity-major rows, dilation).  2e-5 of each tensor's largest magnitude."""
+    B, H, W, Ci, Co, k, s, p, d = case
+    t = _conv_suite_inputs(case)
+    out = _conv_suite(hip, case, 2)
+    assert 6 in out[7], out[7]
+    D = lambda a: a.double()
+    x, w, b = D(t["x"]).requires_grad_(True), D(t["w"]).requires_grad_(True), D(t["b"]).requires_grad_(True)
+    ls, g = D(t["ls"])[None, :, None, None], D(t["g"])
+    z = F.conv2d(x, w, b, s, p, d)
+    y = D(t["res"]) + ls * F.gelu(z)
+    (z * (g * ls)).sum().backward()          # x.grad = conv^T(g * ls), w.grad = ls * sum g x, b.grad = ls * sum g
+    a = D(t["aux"])
+    gp = 0.5 * (1 + torch.erf(a / np.sqrt(2.0))) + a * torch.exp(-0.5 * a * a) / np.sqrt(2 * np.pi)
+    dx = D(t["dx0"]) + x.grad * gp
+    close(nchw(out[1]), z, 2e-5, what=f"ypre {out[7]}")
+    close(nchw(out[0]), y, 2e-5, what="y")
+    if out[2] is not None:
+        yd = y.detach()
+        close(out[2], torch.stack([yd.sum((1, 2, 3)), (yd * yd).sum((1, 2, 3))], 1), 2e-5, what="statistics")
+    close(nchw(out[3]), dx, 2e-5, what="dx")
+    close(out[4], w.grad, 2e-5, what="dw")
+    close(out[5], b.grad, 2e-5, what="db")
+    if out[6] is not None:
+        dw_raw, db_raw = w.grad / ls.view(-1, 1, 1, 1), b.grad / ls.flatten()
+        close(out[6], (w.detach() * dw_raw).sum((1, 2, 3)) + b.detach() * db_raw, 2e-5, what="dls")
+    close(out[8], 7.0 + w.grad / ls.view(-1, 1, 1, 1), 2e-5, what="dw without bias, accumulate")
 
 
 @pytest.mark.parametrize("precision", [2, 0])
@@ -1033,3 +1089,122 @@ def test_gelu_and_derivative_accuracy(hip):
     ys = torch.empty_like(sp)
     hip.conv2d(sp, C, eye, None, ys, C, 1, 8, 8, C, 8, 8, C, 1, 1, 1, 0, 1, act=2, precision=0)
     assert torch.isnan(ys[0, 0, 0, 2]) and torch.isfinite(ys[0, 1:]).all()
+
+
+def test_narrow_conv_head_layout(hip):
+    """The head's prediction convs as the program issues them (decouplehead.py:74-86): NCHW stores into channel ranges of one
+    (B, 5 + nc, h, w) tensor, data / weight gradients from channel SLICES of the (B, h, w, 5 + nc) gradient (row stride 9,
+    odd offsets), the data gradients of reg and obj accumulated into one buffer."""
+    B, H, W, K, ctot = 2, 16, 16, 256, 9
+    g = rnd(B, K, H, W, seed=1)
+    ws = [rnd(n, K, 1, 1, seed=2 + i) / 16 for i, n in enumerate((4, 1, 4))]
+    bs = [rnd(n, seed=5 + i) for i, n in enumerate((4, 1, 4))]
+    out = torch.zeros(B, ctot, H, W, device="cuda")
+    gg = nhwc(g)
+    for w, b, off in zip(ws, bs, (0, 4, 5)):
+        hip.conv2d(gg, K, w.cuda(), b.cuda(), out, 0, B, H, W, K, H, W, w.shape[0], 1, 1, 1, 0, 1, out_nchw=1, out_ctot=ctot, out_coff=off)
+        assert hip.last_kernel() == 5
+    ref = torch.cat([F.conv2d(g, w, b) for w, b in zip(ws, bs)], 1)
+    close(out.cpu(), ref, what="nchw slices")
+    d = nhwc(rnd(B, ctot, H, W, seed=9))                      # (B, H, W, 9) gradient
+    dx = torch.empty(B, H, W, K, device="cuda")
+    acc = 0
+    for w, off in zip(ws, (0, 4, 5)):
+        hip.conv2d(d[..., off:], ctot, w.cuda(), None, dx, K, B, H, W, K, H, W, w.shape[0], 1, 1, 1, 0, 1, mode=1, accumulate=acc)
+        assert hip.last_kernel() == 5
+        acc = 1
+    dref = sum(F.conv_transpose2d(nchw(d)[:, off:off + w.shape[0]], w) for w, off in zip(ws, (0, 4, 5)))
+    close(nchw(dx), dref, what="dgrad from slices, accumulated")
+    for w, off in zip(ws, (0, 4, 5)):
+        n = w.shape[0]
+        dw, db = torch.empty(n, K, 1, 1, device="cuda"), torch.empty(n, device="cuda")
+        hip.conv2d_wgrad(gg, K, d[..., off:], ctot, dw, db, None, B, H, W, K, H, W, n, 1, 1, 1, 0, 1)
+        assert hip.last_kernel() == 5
+        dn = nchw(d)[:, off:off + n]
+        close(dw, torch.einsum("bnhw,bkhw->nk", dn, g).view(n, K, 1, 1), what="wgrad from a slice")
+        close(db, dn.sum((0, 2, 3)), what="bgrad from a slice")
+
+
+def test_x6_non_finite_and_tiny_operands(hip):
+    """Documented edge semantics of the six-product scheme (include/vrnet_hip.h): an Inf operand splits into (Inf, NaN, NaN)
+    and so yields NaN where fp32 arithmetic would give +-Inf; NaN stays NaN; both stay confined to their own output rows.
+    Operands down to 2^-100 keep full fp32 accuracy; below ~2^-110 the low planes fall into the bf16 denormal range."""
+    B, H, W, Ci, Co = 2, 128, 128, 64, 128
+    x = rnd(B, H, W, Ci, seed=1).cuda()
+    w = (rnd(Co, Ci, 1, 1, seed=2) / 8).cuda()
+    y0 = torch.empty(B, H, W, Co, device="cuda")
+    hip.conv2d(x, Ci, w, None, y0, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=2)
+    assert hip.last_kernel() == 6
+    xi = x.clone()
+    xi[0, 0, 0, 3] = float("inf")
+    xi[1, 5, 7, 9] = float("nan")
+    y = torch.empty_like(y0)
+    hip.conv2d(xi, Ci, w, None, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=2)
+    assert torch.isnan(y[0, 0, 0]).all() and torch.isnan(y[1, 5, 7]).all()          # (fp32 arithmetic: +-Inf resp. NaN)
+    y[0, 0, 0], y[1, 5, 7] = y0[0, 0, 0], y0[1, 5, 7]
+    assert torch.equal(y, y0)                                                        # every other row untouched
+    ref = (x.double().view(-1, Ci) @ w.double().view(Co, Ci).T).view(B, H, W, Co)
+    for e, tol in ((-100, 2e-5), (-120, 1e-2)):
+        sc = 2.0 ** e
+        hip.conv2d(x * sc, Ci, w, None, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=2)
+        err = ((y.double() / sc - ref).abs().max() / ref.abs().max()).item()
+        print(f"operands scaled by 2^{e}: rel err {err:.2e}")
+        assert err < tol, (e, err)
+
+
+def test_torch_library_custom_ops_round3(hip):
+    """The remaining fused ops as torch.ops.vrnet.* (ops.py): values and autograd against ATen, schema / fake kernels by
+    opcheck, and the autocast registration (fp32 inside an autocast region)."""
+    import asy_vrnet_amd.ops  # noqa: F401
+    opcheck = lambda op, args: torch.library.opcheck(op, args, test_utils=("test_schema", "test_faketensor"))
+    # ---- mlp: res + ls * fc2(gelu(fc1(x)))
+    B, H, W, C, hid = 2, 8, 8, 64, 256
+    mk = lambda *s_, seed, sc=1.0: (rnd(*s_, seed=seed) * sc).cuda().requires_grad_(True)
+    x, res = mk(B, H, W, C, seed=1), mk(B, H, W, C, seed=2)
+    w1, b1, w2, b2, ls = mk(hid, C, 1, 1, seed=3, sc=1 / 8), mk(hid, seed=4), mk(C, hid, 1, 1, seed=5, sc=1 / 16), mk(C, seed=6), mk(C, seed=7)
+    y, _ = torch.ops.vrnet.mlp(x, w1, b1, w2, b2, res, ls)
+    ref = res + ls * (F.gelu(x @ w1.view(hid, C).T + b1) @ w2.view(C, hid).T + b2)
+    close(y, ref, what="mlp op")
+    g = rnd(B, H, W, C, seed=8).cuda()
+    mine = torch.autograd.grad(y, (x, w1, b1, w2, b2, res, ls), g)
+    want = torch.autograd.grad(ref, (x, w1, b1, w2, b2, res, ls), g)
+    for a, b_, nm in zip(mine, want, ("dx", "dw1", "db1", "dw2", "db2", "dres", "dls")):
+        close(a, b_, 2e-4, what="mlp op " + nm)
+    opcheck(torch.ops.vrnet.mlp.default, tuple(t.detach() for t in (x, w1, b1, w2, b2, res, ls)))
+    # ---- GroupNorm(1, C)
+    gam, bet = mk(C, seed=9), mk(C, seed=10)
+    y, _ = torch.ops.vrnet.group_norm1(x, gam, bet, 1e-5)
+    ref = F.group_norm(x.permute(0, 3, 1, 2), 1, gam, bet, 1e-5).permute(0, 2, 3, 1)
+    close(y, ref, what="group_norm1")
+    for a, b_, nm in zip(torch.autograd.grad(y, (x, gam, bet), g), torch.autograd.grad(ref, (x, gam, bet), g), ("dx", "dgamma", "dbeta")):
+        close(a, b_, 2e-4, what="group_norm1 " + nm)
+    opcheck(torch.ops.vrnet.group_norm1.default, (x.detach(), gam.detach(), bet.detach(), 1e-5))
+    # ---- BatchNorm + ReLU (train mode), functional running statistics
+    rm, rv = rnd(C, seed=11).cuda() * 0.1, rnd(C, seed=12, kind="uniform").cuda() + 0.5
+    y, _, rm2, rv2 = torch.ops.vrnet.batch_norm_act(x, gam, bet, rm, rv, True, 0.03, 1e-3, True)
+    rmr, rvr = rm.clone(), rv.clone()
+    ref = torch.relu(F.batch_norm(x.permute(0, 3, 1, 2), rmr, rvr, gam, bet, True, 0.03, 1e-3)).permute(0, 2, 3, 1)
+    close(y, ref, what="batch_norm_act")
+    close(rm2, rmr, what="running_mean"); close(rv2, rvr, what="running_var")
+    for a, b_, nm in zip(torch.autograd.grad(y, (x, gam, bet), g), torch.autograd.grad(ref, (x, gam, bet), g), ("dx", "dgamma", "dbeta")):
+        close(a, b_, 5e-4, what="batch_norm_act " + nm)
+    opcheck(torch.ops.vrnet.batch_norm_act.default, (x.detach(), gam.detach(), bet.detach(), rm, rv, True, 0.03, 1e-3, True))
+    # ---- depthwise 3x3 and bilinear upsampling
+    wd = mk(C, 1, 3, 3, seed=13)
+    y = torch.ops.vrnet.dwconv3x3(x, wd)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), wd, None, 1, 1, 1, C).permute(0, 2, 3, 1)
+    close(y, ref, what="dwconv3x3 op")
+    for a, b_, nm in zip(torch.autograd.grad(y, (x, wd), g), torch.autograd.grad(ref, (x, wd), g), ("dx", "dw")):
+        close(a, b_, 2e-4, what="dwconv3x3 op " + nm)
+    opcheck(torch.ops.vrnet.dwconv3x3.default, (x.detach(), wd.detach()))
+    y = torch.ops.vrnet.upsample_bilinear(x, 2)
+    ref = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    close(y, ref, what="upsample op")
+    g2 = rnd(B, 2 * H, 2 * W, C, seed=14).cuda()
+    close(torch.autograd.grad(y, x, g2)[0], torch.autograd.grad(ref, x, g2)[0], 2e-4, what="upsample op dx")
+    opcheck(torch.ops.vrnet.upsample_bilinear.default, (x.detach(), 2))
+    # ---- autocast: half-precision arguments are cast to fp32 on the way in, the result is fp32
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = torch.ops.vrnet.dwconv3x3(x.detach().bfloat16(), wd.detach())
+    assert ya.dtype == torch.float32
+    close(ya, torch.ops.vrnet.dwconv3x3(x.detach().bfloat16().float(), wd.detach()), 1e-6, what="autocast")

@@ -85,9 +85,18 @@ def test_against_reference_golden(A, name, golden_dir):
     from tests.parity import rel_err
     st = meta.get("seg_stride", 1)
     gtol = 5e-3 if meta["size"] <= 128 else 3e-2
+    def same(mine, ref, what):
+        # (512 px, 0.9 M hard assignments: this fixture is tie-free for the kernel set as it stands.  It is not a robust
+        # property: in round 3 a direct kernel for nano's 16-channel patch embedding -- another summation order, 1e-7
+        # apart -- turned ONE tied decision the other way, and through data_normal's batch-wide max (vr_coc.py:59-67) 87 % of
+        # det0 moved by more than 1e-3 (up to 9.5 %) while the teacher-forced comparison of the same configuration,
+        # test_512_bs2_against_oracle, stayed at 2e-6.  That test is the gate; if this one ever fails with a large
+        # `fraction`, look there first.)
+        e = (mine.detach().double().cpu() - torch.from_numpy(ref).double()).abs() / float(np.abs(ref).max())
+        assert float(e.max()) < 1e-3, (what, "max", float(e.max()), "fraction beyond 1e-3", float((e > 1e-3).double().mean()))
     for i in range(3):
-        assert rel_err(det[i], torch.from_numpy(z[f"det{i}"])) < 1e-3
-    assert rel_err(seg[:, :, ::st, ::st], torch.from_numpy(z["seg"])) < 1e-3
+        same(det[i], z[f"det{i}"], f"det{i}")
+    same(seg[:, :, ::st, ::st], z["seg"], "seg")
     if meta["training"]:
         sd = m.state_dict()
         for k in z.files:

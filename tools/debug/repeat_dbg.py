@@ -1,5 +1,5 @@
 """Debug: is one forward+backward bit-repeatable?  Lists the parameters whose gradient differs between runs.
-    python tools/debug/repeat_dbg.py [dtype] [concurrent 0/1] [runs]"""
+    python tools/debug/repeat_dbg.py [dtype] [concurrent 0/1] [runs] [batch] [pair]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -12,6 +12,7 @@ net = A.EfficientVRNet(4, 9, "l", img_size=512).cuda().train()
 A.randomize_state_dict(net.state_dict(), seed=2)
 net.compute_dtype = dtype
 net.concurrent = bool(conc)
+net.pair_streams = len(sys.argv) > 5 and sys.argv[5] == "pair"
 x, r = A.synthetic_inputs(bs, 512, 11, "cuda")
 state = {k: v.clone() for k, v in net.state_dict().items()}
 def cks(t):
@@ -46,8 +47,16 @@ for it in range(runs):
     if bad or it == runs - 1:
         outs = {k: float((cur[k] - ref[k]).abs().max() / ref[k].abs().max()) for k in ("<seg>", "<det0>", "<det1>", "<det2>")}
         print(f"run {it}: {len(bad)} of {len(ref)} tensors differ; output rel diffs: {outs}")
+    if bad and len(bad) <= 6:
+        print("   differing:", [(k.replace("backbone.backbone.", "bb."), f"{e:.1e}") for k, e in bad])
+        for k, _ in bad:
+            dd = (cur[k].double() - ref[k].double()).flatten(1) if cur[k].dim() > 1 else (cur[k].double() - ref[k].double())[None]
+            nz = (dd != 0)
+            print("     ", k, "shape", tuple(cur[k].shape), "differing elements", int(nz.sum()), "per row", nz.sum(1).tolist(),
+                  "cols", nz.any(0).nonzero().flatten().tolist()[:40], "ratio", (dd[nz] / ref[k].double().flatten(1)[nz] if cur[k].dim() > 1 else dd[nz])[:6].tolist())
     if bad and not reported:
         reported = True
+        print("   differing:", [(k.replace("backbone.backbone.", "bb."), f"{e:.1e}") for k, e in bad][:40])
         now = {"x": cks(x), "r": cks(r)}
         now.update({"state." + k: cks(v) for k, v in state.items()})
         print("   persistent tensors that changed:", [k for k in base if base[k] != now[k]])
