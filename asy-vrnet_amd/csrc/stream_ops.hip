@@ -12,11 +12,15 @@
 
 namespace {
 
+__device__ __forceinline__ f32x4 ld4(const float* p);
+__device__ __forceinline__ double block_sum(double v, double* red);
+
 // ------------------------------------------------------------------------------------------ moments
 template <int VEC>
 __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, const float* x2, long ldx2,
                                                       const float* mask, long ldm, long HW, int C, int TPR,
-                                                      long rows_per_chunk, int nchunks, double* partial, int total_only) {
+                                                      long rows_per_chunk, int nchunks, double* partial, int total_only,
+                                                      const float* gamma = nullptr, double* gtot = nullptr) {
   extern __shared__ double sm[];   // [256][2*VEC]
   const int tid = threadIdx.x;
   const int tx = tid % TPR, ty = tid / TPR, RP = 256 / TPR;
@@ -107,6 +111,128 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, 
       out[2 * j] = s1[j];
       out[2 * j + 1] = s2[j];
     }
+  }
+  if (gtot) {
+    // GroupNorm(1, C) backward: the per-SAMPLE coefficients only need sum_c gamma_c * (s1, s2) -- one pair per workgroup,
+    // so that the apply kernel can finish the sample's coefficients itself (vrnet_gn_apply_bwd) without a reduce launch
+    double g1 = 0.0, g2 = 0.0;
+    if (ty == 0 && cv < CV) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const double g = (double)gamma[cv * VEC + j];
+        g1 += g * s1[j];
+        g2 += g * s2[j];
+      }
+    }
+    __syncthreads();                      // the channel partials in sm have been consumed
+    g1 = wave_sum(g1);
+    g2 = wave_sum(g2);
+    if ((tid & 63) == 0) { sm[2 * (tid >> 6)] = g1; sm[2 * (tid >> 6) + 1] = g2; }
+    __syncthreads();
+    if (tid < 2)
+      gtot[(((long)b * nchunks + chunk) * gridDim.z + blockIdx.z) * 2 + tid] = sm[tid] + sm[2 + tid] + sm[4 + tid] + sm[6 + tid];
+  }
+}
+
+// ---- GroupNorm(1, C) with the coefficient step inside the apply kernel (vr_coc.py:105-111) ---------------------------
+// Forward: the producing conv's epilogue left (sum, sum of squares) pairs per 32 x 32 tile; every workgroup adds the pairs
+// of ITS sample (<= a few thousand, fp64, fixed order: all workgroups of a sample get the same bits) and normalises its
+// share of the rows: y = (rstd * gamma) * (x - mean) + beta.  One launch where the coefficient kernel + affine were two.
+__global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const float* x, long ldx, const double* pairs, long per,
+                                                           const float* gamma, const float* beta, float eps, long HW, int C,
+                                                           float* y, long ldy, float* mean_rstd) {
+  __shared__ double red[4];
+  const int b = blockIdx.y;
+  const double* src = pairs + (long)b * per * 2;
+  double s1 = 0, s2 = 0, t1 = 0, t2 = 0;
+  long i = threadIdx.x;
+  for (; i + 256 < per; i += 512) {
+    s1 += src[2 * i]; s2 += src[2 * i + 1];
+    t1 += src[2 * (i + 256)]; t2 += src[2 * (i + 256) + 1];
+  }
+  if (i < per) { s1 += src[2 * i]; s2 += src[2 * i + 1]; }
+  s1 = block_sum(s1 + t1, red);
+  s2 = block_sum(s2 + t2, red);
+  const double n = (double)HW * C;
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0) var = 0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    mean_rstd[2 * b] = (float)mean;
+    mean_rstd[2 * b + 1] = (float)rstd;
+  }
+  const float mu = (float)mean;
+  const int CV = C / 4;
+  const long total = HW * CV, stride = (long)gridDim.x * 256;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+    const long r = e / CV;
+    const int c = (int)(e - r * CV) * 4;
+    const long row = (long)b * HW + r;
+    const f32x4 v = ld4(x + row * ldx + c), g = ld4(gamma + c), be = ld4(beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaf((float)(rstd * (double)g[j]), v[j] - mu, be[j]);
+    *reinterpret_cast<f32x4*>(y + row * ldy + c) = o;
+  }
+}
+
+// Backward: blockIdx.y < B -- dx = A * dy + E * (x - mean) + D (+ add) with the sample's coefficients finished here from
+// the moments kernel's gamma-weighted chunk totals; blockIdx.y == B -- the per-channel parameter gradients (one wave per
+// channel over the [B][nchunks] chunk partials).  One launch where reduce + coefficient kernel + affine were three.
+__global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const float* dy, long lddy, const float* x, long ldx,
+                                                           const double* gtot, int gper, const double* partial, int nchunks,
+                                                           const float* mean_rstd, const float* gamma, int B, long HW, int C,
+                                                           const float* add, long ldadd, float* out, long ldo, float* dgamma,
+                                                           float* dbeta, int accumulate_params) {
+  __shared__ double red[4];
+  if ((int)blockIdx.y == B) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double dg = 0.0, db = 0.0;
+    const int total = B * nchunks;
+    for (int j = lane; j < total; j += 64) {
+      const int bb = j / nchunks;
+      const double mu = mean_rstd[2 * bb], r = mean_rstd[2 * bb + 1];
+      const double* q = partial + ((long)j * C + c) * 2;
+      const double s1 = q[0], s2 = q[1];
+      dg += r * (s2 - mu * s1);
+      db += s1;
+    }
+    dg = wave_sum(dg);
+    db = wave_sum(db);
+    if (lane == 0) {
+      dgamma[c] = (accumulate_params ? dgamma[c] : 0.f) + (float)dg;
+      dbeta[c] = (accumulate_params ? dbeta[c] : 0.f) + (float)db;
+    }
+    return;
+  }
+  const int b = blockIdx.y;
+  const double* src = gtot + (long)b * gper * 2;
+  double t1 = 0, t2 = 0;
+  for (int i = threadIdx.x; i < gper; i += 256) { t1 += src[2 * i]; t2 += src[2 * i + 1]; }
+  t1 = block_sum(t1, red);
+  t2 = block_sum(t2, red);
+  const double mu = mean_rstd[2 * b], r = mean_rstd[2 * b + 1];
+  const double n = (double)HW * C;
+  const double m1 = t1 / n, m2 = r * (t2 - mu * t1) / n;
+  const float e_ = (float)(-r * r * m2), d_ = (float)(-r * m1), muf = (float)mu;
+  const int CV = C / 4;
+  const long total = HW * CV, stride = (long)gridDim.x * 256;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+    const long rr = e / CV;
+    const int c = (int)(e - rr * CV) * 4;
+    const long row = (long)b * HW + rr;
+    const f32x4 g = ld4(dy + row * lddy + c), xv = ld4(x + row * ldx + c), ga = ld4(gamma + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaf((float)(r * (double)ga[j]), g[j], fmaf(e_, xv[j] - muf, d_));
+    if (add) {
+      const f32x4 a = ld4(add + row * ldadd + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] += a[j];
+    }
+    *reinterpret_cast<f32x4*>(out + row * ldo + c) = o;
   }
 }
 
@@ -639,7 +765,7 @@ extern "C" long vrnet_moments_workspace(int B, long HW, int C) {
 
 static int moments_launch(const float* x, long ldx, const float* x2, long ldx2, const float* mask, long ldm, int B,
                           long HW, int C, void* workspace, long workspace_bytes, hipStream_t st, int* nchunks_out,
-                          int total_only = 0) {
+                          int total_only = 0, const float* gamma = nullptr, double* gtot = nullptr, int* ncb_out = nullptr) {
   if (vr_ablated("moments")) { if (nchunks_out) *nchunks_out = 1; return VR_OK; }
   VR_CHECK_ARG(x && workspace, "moments: null tensor");
   VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && ldx >= C, "moments: bad shape");
@@ -657,11 +783,12 @@ static int moments_launch(const float* x, long ldx, const float* x2, long ldx2, 
   dim3 grid(nchunks, B, ncb), block(256);
   if (vec)
     hipLaunchKernelGGL((moments_kernel<4>), grid, block, 256 * 8 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
-                       TPR, rows, nchunks, partial, total_only);
+                       TPR, rows, nchunks, partial, total_only, gamma, gtot);
   else
     hipLaunchKernelGGL((moments_kernel<1>), grid, block, 256 * 2 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
-                       TPR, rows, nchunks, partial, total_only);
+                       TPR, rows, nchunks, partial, total_only, gamma, gtot);
   VR_LAUNCH_CHECK("moments");
+  if (ncb_out) *ncb_out = ncb;
   *nchunks_out = total_only ? nchunks * ncb : nchunks;
   return VR_OK;
 }
@@ -739,6 +866,63 @@ extern "C" int vrnet_gn_coef_fwd(const double* mom, const float* gamma, const fl
   hipLaunchKernelGGL(gn_coef_fwd_kernel, dim3(B), dim3(256), 0, vr_stream(stream), mom, gamma, beta, eps, HW, C, A, D, S,
                      mean_rstd, (const float*)nullptr, (const float*)nullptr);
   VR_LAUNCH_CHECK("gn_coef_fwd");
+  return VR_OK;
+}
+
+/* GroupNorm(1, C) forward from the producer's tile statistics, ONE launch: y = GN(x); mean_rstd [B][2] for the backward
+ * pass.  pairs: `pairs_per_sample` consecutive fp64 (sum, sumsq) pairs per sample (vrnet_conv2d_f32 / vrnet_mlp_fwd_f32
+ * `stats`).  Needs C % 4 == 0 and 16-byte rows. */
+extern "C" int vrnet_gn_apply_fwd(const float* x, long ldx, const double* pairs, long pairs_per_sample, const float* gamma,
+                                  const float* beta, float eps, int B, long HW, int C, float* y, long ldy, float* mean_rstd,
+                                  void* stream) {
+  VR_CHECK_ARG(x && pairs && gamma && beta && y && mean_rstd, "gn_apply_fwd: null tensor");
+  VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && vr_aligned16(x) &&
+                   vr_aligned16(y) && vr_aligned16(gamma) && vr_aligned16(beta),
+               "gn_apply_fwd: needs C %% 4 == 0 and 16-byte aligned rows");
+  if (vr_ablated("affine")) return VR_OK;
+  long bx = vr_cdiv(HW * (C / 4), 256 * 4);            // ~4 float4 per thread: the pair reduction is repeated per workgroup
+  const long cap = vr_cdiv(2048, B);
+  if (bx > cap) bx = cap;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3((unsigned)bx, B), dim3(256), 0, vr_stream(stream), x, ldx, pairs, pairs_per_sample,
+                     gamma, beta, eps, HW, C, y, ldy, mean_rstd);
+  VR_LAUNCH_CHECK("gn_apply_fwd");
+  return VR_OK;
+}
+
+/* GroupNorm(1, C) backward in TWO launches (moments of (dy, dy * x) with gamma-weighted chunk totals; apply + parameter
+ * gradients): out = dx (+ add), dgamma / dbeta (accumulated when accumulate_params).  workspace: vrnet_gn_bwd_workspace. */
+extern "C" long vrnet_gn_bwd_workspace(int B, long HW, int C) {
+  return vrnet_moments_workspace(B, HW, C) + (long)B * 512 * 4 * 2 * 8 + 256;
+}
+extern "C" int vrnet_gn_apply_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean_rstd,
+                                  const float* gamma, int B, long HW, int C, const float* add, long ldadd, float* out, long ldo,
+                                  float* dgamma, float* dbeta, int accumulate_params, void* workspace, long workspace_bytes,
+                                  void* stream) {
+  VR_CHECK_ARG(dy && x && mean_rstd && gamma && out && dgamma && dbeta && workspace, "gn_apply_bwd: null tensor");
+  VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (!add || ldadd % 4 == 0) &&
+                   vr_aligned16(dy) && vr_aligned16(x) && vr_aligned16(out) && vr_aligned16(gamma) && (!add || vr_aligned16(add)),
+               "gn_apply_bwd: needs C %% 4 == 0 and 16-byte aligned rows");
+  if (workspace_bytes < vrnet_gn_bwd_workspace(B, HW, C)) {
+    vr_set_error("gn_apply_bwd: workspace too small");
+    return VR_ERR_WORKSPACE;
+  }
+  hipStream_t st = vr_stream(stream);
+  const long mom_bytes = vrnet_moments_workspace(B, HW, C);
+  double* gtot = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + ((mom_bytes + 255) / 256) * 256);
+  int nchunks = 1, ncb = 1;
+  int rc = moments_launch(dy, lddy, x, ldx, nullptr, 0, B, HW, C, workspace, mom_bytes, st, &nchunks, 0, gamma, gtot, &ncb);
+  if (rc) return rc;
+  if (vr_ablated("affine")) return VR_OK;
+  long bx = vr_cdiv(HW * (C / 4), 256 * 4);
+  const long cap = vr_cdiv(2048, B);
+  if (bx > cap) bx = cap;
+  const long need = vr_cdiv(C, 4);                      // the parameter-gradient row of the grid: one wave per channel
+  if (bx < need) bx = need;
+  hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3((unsigned)bx, B + 1), dim3(256), 0, st, dy, lddy, x, ldx, gtot, nchunks * ncb,
+                     reinterpret_cast<double*>(workspace), nchunks, mean_rstd, gamma, B, HW, C, add, ldadd, out, ldo, dgamma, dbeta,
+                     accumulate_params);
+  VR_LAUNCH_CHECK("gn_apply_bwd");
   return VR_OK;
 }
 

@@ -46,6 +46,9 @@ _SIGS = {
     "vrnet_gn_coef_from_pairs": ([P, L, P, P, F, I, L, I, P, P, P, P, P, P, P], I),
     "vrnet_gn_stats_fwd": ([P, L, P, P, F, I, L, I, P, P, P, P, P, P, P, L, P], I),
     "vrnet_gn_coef_bwd": ([P, P, P, I, L, I, P, P, P, P, P, P, I, P, P, P, P], I),
+    "vrnet_gn_apply_fwd": ([P, L, P, L, P, P, F, I, L, I, P, L, P, P], I),
+    "vrnet_gn_bwd_workspace": ([I, L, I], L),
+    "vrnet_gn_apply_bwd": ([P, L, P, L, P, P, I, L, I, P, L, P, L, P, P, I, P, L, P], I),
     "vrnet_bn_coef_fwd": ([P, P, P, F, F, P, P, P, I, I, L, I, P, P, P, P, P], I),
     "vrnet_bn_coef_bwd": ([P, P, P, I, I, L, I, P, P, P, P, P, P, I, P], I),
     "vrnet_bn_stats_fwd": ([P, L, P, P, F, F, P, P, P, I, L, I, P, P, P, P, P, L, P], I),
@@ -282,6 +285,22 @@ def gn_stats_fwd(x, ldx, gamma, beta, eps, B, HW, C, A, Dc, S, mean_rstd, gamma2
     ws = _ws.get(_lib.vrnet_moments_workspace(B, HW, C), x.device)
     _check(_lib.vrnet_gn_stats_fwd(ptr(x), ldx, ptr(gamma), ptr(beta), eps, B, HW, C, ptr(A), ptr(Dc), ptr(S),
                                    ptr(mean_rstd), ptr(gamma2), ptr(beta2), ptr(ws), ws.numel(), stream()), "gn_stats_fwd")
+
+
+def gn_apply_ok(C, *lds):
+    """Shapes the one-launch GroupNorm kernels accept: C % 4 == 0 and row strides that are multiples of 4."""
+    return C % 4 == 0 and all(ld % 4 == 0 for ld in lds)
+
+
+def gn_apply_fwd(x, ldx, pairs, per_sample, gamma, beta, eps, B, HW, C, y, ldy, mean_rstd):
+    _check(_lib.vrnet_gn_apply_fwd(ptr(x), ldx, ptr(pairs), per_sample, ptr(gamma), ptr(beta), eps, B, HW, C, ptr(y), ldy,
+                                   ptr(mean_rstd), stream()), "gn_apply_fwd")
+
+
+def gn_apply_bwd(dy, lddy, x, ldx, mean_rstd, gamma, B, HW, C, out, ldo, dgamma, dbeta, accumulate_params, add=None, ldadd=0):
+    ws = _ws.get(_lib.vrnet_gn_bwd_workspace(B, HW, C), x.device)
+    _check(_lib.vrnet_gn_apply_bwd(ptr(dy), lddy, ptr(x), ldx, ptr(mean_rstd), ptr(gamma), B, HW, C, ptr(add), ldadd, ptr(out),
+                                   ldo, ptr(dgamma), ptr(dbeta), accumulate_params, ptr(ws), ws.numel(), stream()), "gn_apply_bwd")
 
 
 def gn_coef_bwd(mom2, mean_rstd, gamma, B, HW, C, A, E, Dc, S, dgamma, dbeta, accumulate, gamma2=None, dgamma2=None,

@@ -212,7 +212,8 @@ def group_norm1(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: f
     Returns (y, (B,2) mean / rstd)."""
     x = x.contiguous()
     B, H, W, C, _ = _rows(x)
-    A, D, S, ms = (torch.empty((B, C), device=x.device) for _ in range(3)) + (torch.empty((B, 2), device=x.device),)
+    A, D, S = (torch.empty((B, C), device=x.device) for _ in range(3))
+    ms = torch.empty((B, 2), device=x.device)
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
         hip.gn_stats_fwd(x, C, gamma, beta, eps, B, H * W, C, A, D, S, ms)
@@ -264,7 +265,8 @@ def batch_norm_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, run
     module's buffers.  Returns (y, (C,2) mean / rstd, new running_mean, new running_var)."""
     x = x.contiguous()
     B, H, W, C, _ = _rows(x)
-    A, D, S, ms = (torch.empty(C, device=x.device) for _ in range(3)) + (torch.empty((C, 2), device=x.device),)
+    A, D, S = (torch.empty(C, device=x.device) for _ in range(3))
+    ms = torch.empty((C, 2), device=x.device)
     rm, rv = running_mean.clone(), running_var.clone()
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):

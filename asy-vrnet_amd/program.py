@@ -599,8 +599,14 @@ def gn_forward(rt, x, gn):
     """GroupNorm(1, C); gn may be a pair of modules (two-stream launch: second half of the samples = second module)."""
     g0, g1 = _pair(gn)
     B, HW, C = x.B, x.HW, x.C
-    A, D, S, ms = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C), rt.buf(B, 2)
+    ms = rt.buf(B, 2)
     kw2 = {} if g1 is None else dict(gamma2=g1.weight, beta2=g1.bias)
+    if x.pairs is not None and g1 is None and hip.gn_apply_ok(C, x.ld):
+        # statistics from the producer's epilogue AND the coefficient step inside the apply kernel: ONE launch on the chain
+        y = rt.new(x.B, x.H, x.W, C)
+        hip.gn_apply_fwd(x.t, x.ld, x.pairs[0], x.pairs[1], g0.weight, g0.bias, g0.eps, B, HW, C, y.t, C, ms)
+        return y, ms
+    A, D, S = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C)
     if x.pairs is not None:
         hip.gn_coef_from_pairs(x.pairs[0], x.pairs[1], g0.weight, g0.bias, g0.eps, B, HW, C, A, D, S, ms, **kw2)
     else:
@@ -627,6 +633,15 @@ def gn_backward(rt, gn, x, ms, dy, out, accumulate=0, add=None):
     """out = dx of y = GN(x) given contiguous dy [+ out (accumulate) | + add (another contiguous tensor)]."""
     g0, g1 = _pair(gn)
     B, HW, C = x.B, x.HW, x.C
+    if g1 is None and hip.gn_apply_ok(C, x.ld) and (not accumulate or add is None):
+        # two launches (moments; apply + parameter gradients) where moments, reduce, coefficients and affine were four
+        (gw, gb), accw = _pgrads_or_scratch(rt, (g0.weight, g0.bias), (C, C))
+        hip.gn_apply_bwd(dy, C, x.t, x.ld, ms, g0.weight, B, HW, C, out, C, gw, gb, accw, add=out if accumulate else add,
+                         ldadd=C if (accumulate or add is not None) else 0)
+        if rt.on_param_grad:
+            rt.on_param_grad(g0.weight)
+            rt.on_param_grad(g0.bias)
+        return
     mom2 = hip.moments(dy, C, B, HW, C, x2=x.t, ldx2=x.ld)
     A, E, D, S = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C), rt.buf(B, C)
     (gw, gb), accw = _pgrads_or_scratch(rt, (g0.weight, g0.bias), (C, C))

@@ -170,6 +170,21 @@ int vrnet_gn_stats_fwd(const float* x, long ldx, const float* gamma, const float
 int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int B, long HW, int C,
                       float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,
                       const float* gamma2, float* dgamma2, float* dbeta2, void* stream);
+
+/* GroupNorm(1, C) with the coefficient step INSIDE the apply kernels (vr_coc.py:105-111, 264-271: norm1 / norm2 of every
+ * ClusterBlock sit on the critical chain of the step, so launches count).  C % 4 == 0, 16-byte rows.
+ * vrnet_gn_apply_fwd: y = GN(x) in ONE launch from the (sum, sumsq) tile pairs the producing conv / fused Mlp left
+ *   (`stats` of vrnet_conv2d_f32 / vrnet_mlp_fwd_f32: pairs_per_sample consecutive fp64 pairs per sample); every workgroup
+ *   re-adds its sample's pairs in the same fixed order; mean_rstd [B][2] is written for the backward pass.
+ * vrnet_gn_apply_bwd: TWO launches -- the moments kernel over (dy, dy * x), which also leaves gamma-weighted totals per
+ *   chunk, then one kernel that finishes each sample's coefficients from those totals, writes out = dx (+ add) and, in an
+ *   extra row of its grid, the parameter gradients dgamma / dbeta (+= when accumulate_params). */
+int vrnet_gn_apply_fwd(const float* x, long ldx, const double* pairs, long pairs_per_sample, const float* gamma,
+                       const float* beta, float eps, int B, long HW, int C, float* y, long ldy, float* mean_rstd, void* stream);
+long vrnet_gn_bwd_workspace(int B, long HW, int C);
+int vrnet_gn_apply_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean_rstd, const float* gamma, int B,
+                       long HW, int C, const float* add, long ldadd, float* out, long ldo, float* dgamma, float* dbeta,
+                       int accumulate_params, void* workspace, long workspace_bytes, void* stream);
 /* nn.BatchNorm2d: batch statistics + running-stat update (unbiased var, momentum) + num_batches_tracked += 1
  * when training, running statistics otherwise.  y = A*(z - S) + D with A,D,S [C]; mean_rstd [C][2]. */
 int vrnet_bn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, float momentum,

@@ -1208,3 +1208,40 @@ def test_torch_library_custom_ops_round3(hip):
         ya = torch.ops.vrnet.dwconv3x3(x.detach().bfloat16(), wd.detach())
     assert ya.dtype == torch.float32
     close(ya, torch.ops.vrnet.dwconv3x3(x.detach().bfloat16().float(), wd.detach()), 1e-6, what="autocast")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (3, 8, 8, 320), (8, 128, 128, 64), (2, 32, 32, 128)])
+def test_group_norm_one_and_two_launch_forms(hip, shape):
+    """GroupNorm(1, C) as the network runs it on the block chain: forward in ONE launch from the producer's tile pairs
+    (vrnet_gn_apply_fwd), backward in TWO (moments + apply with in-kernel coefficients and parameter gradients,
+    vrnet_gn_apply_bwd), against ATen in fp64; |mean| >> std on purpose."""
+    B, H, W, C = shape
+    x = (rnd(B, H, W, C, seed=1) * 1.5 + 10.0)
+    gam, bet = rnd(C, seed=2) * 0.3 + 1, rnd(C, seed=3) * 0.5
+    g, addend = rnd(B, H, W, C, seed=4), rnd(B, H, W, C, seed=5)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    ref = F.group_norm(xd.permute(0, 3, 1, 2), 1, gd, bd, 1e-5).permute(0, 2, 3, 1)
+    ref.backward(g.double())
+    # tile pairs as a conv epilogue leaves them: (sum, sumsq) per 32 rows x 32 channels, fp64
+    nb = (C + 31) // 32
+    t = x.double().view(B, H * W // 32, 32, C)
+    pairs = torch.zeros(B, H * W // 32, nb, 2, dtype=torch.float64)
+    for j in range(nb):
+        blk = t[..., 32 * j:32 * (j + 1)]
+        pairs[:, :, j, 0], pairs[:, :, j, 1] = blk.sum((2, 3)), (blk * blk).sum((2, 3))
+    xg, y, ms = x.cuda(), torch.empty(B, H, W, C, device="cuda"), torch.empty(B, 2, device="cuda")
+    hip.gn_apply_fwd(xg, C, pairs.cuda(), (H * W // 32) * nb, gam.cuda(), bet.cuda(), 1e-5, B, H * W, C, y, C, ms)
+    close(y, ref, 2e-5, what="gn forward")
+    mean = x.double().mean((1, 2, 3))
+    close(ms[:, 0], mean, 1e-6, what="mean")
+    close(ms[:, 1], 1 / torch.sqrt(x.double().var((1, 2, 3), unbiased=False) + 1e-5), 1e-5, what="rstd")
+    dx, dg, db = torch.empty(B, H, W, C, device="cuda"), torch.full((C,), 2.0, device="cuda"), torch.full((C,), 2.0, device="cuda")
+    hip.gn_apply_bwd(g.cuda(), C, xg, C, ms, gam.cuda(), B, H * W, C, dx, C, dg, db, 1, add=addend.cuda(), ldadd=C)
+    close(dx, xd.grad + addend.double(), 5e-5, what="gn dx + add")
+    close(dg, gd.grad + 2, 5e-5, what="dgamma (accumulated)")
+    close(db, bd.grad + 2, 5e-5, what="dbeta (accumulated)")
+    dx2 = addend.cuda().clone()                                   # in-place accumulate: add == out
+    hip.gn_apply_bwd(g.cuda(), C, xg, C, ms, gam.cuda(), B, H * W, C, dx2, C, dg, db, 0, add=dx2, ldadd=C)
+    assert torch.equal(dx2, dx)
+    close(dg, gd.grad, 5e-5, what="dgamma")
