@@ -19,6 +19,16 @@
 
 #include <cstdlib>
 
+extern "C" {
+// include/vrnet_hip.h: optional column statistics of a conv's stored outputs
+typedef struct vrnet_conv_colstats {
+  double* partial;              // [ceil(M/32)][N][2]: per output column, (sum v, sum v * f) over each 32-row tile
+  const float* x2; long ldx2;   // f = x2[m, n] (row stride ldx2); NULL: f = v
+  const float* gamma;           // with tile_totals: weights of the columns
+  double* tile_totals;          // [ceil(M/32)][ceil(N/32)][2]: the two sums weighted by gamma, added over a tile's 32 columns
+} vrnet_conv_colstats;
+}
+
 namespace {
 
 template <int BM, int BN, int BK, int TM, int TN, int WM, int WN, int MODE, bool VEC>
@@ -586,6 +596,18 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
         vr_bf16x8 a3[TM][3], b3[TN][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i) vr_split3(af[i][2 * ks], af[i][2 * ks + 1], a3[i]);
+#ifdef VR_TUNING
+        // timing experiment (results garbage): what would weights that arrive pre-split into bf16 planes be worth?
+        // VRNET_X6_FAKE_PRESPLIT=1 takes the B fragments' bits as they are instead of splitting them.
+        if (p.dbg_fake_presplit) {
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            b3[i][0] = __builtin_bit_cast(vr_bf16x8, bq[i][2 * ks]);
+            b3[i][1] = __builtin_bit_cast(vr_bf16x8, bq[i][2 * ks + 1]);
+            b3[i][2] = b3[i][0];
+          }
+        } else
+#endif
 #pragma unroll
         for (int i = 0; i < TN; ++i) vr_split3(bq[i][2 * ks], bq[i][2 * ks + 1], b3[i]);
 #pragma unroll
@@ -1227,7 +1249,8 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                                 long ldres, const float* res_scale, const float* kscale, const float* aux,
                                 long ldaux, int out_nchw, int out_ctot, int out_coff, int accumulate,
                                 double* stats, int precision, int pair_rows, const float* w2, const float* bias2,
-                                const float* res_scale2, const float* kscale2, void* stream) {
+                                const float* res_scale2, const float* kscale2, const vrnet_conv_colstats* colstats,
+                                void* stream) {
   VR_CHECK_ARG(a && w && y, "conv2d: null tensor");
   if (vr_ablated("igemm")) return VR_OK;
   {   // finer timing ablations by output-row class (diagnostic): stage-0/1 maps, stage-2 maps, neck / head maps
@@ -1246,13 +1269,14 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                    (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1 == OW,
                "conv2d: output size %dx%d inconsistent with input %dx%d k%d s%d p%d d%d", OH, OW, H, W, kh,
                stride, pad, dil);
-  const bool plain = !ypre && !res && !kscale && !aux && !out_nchw && act == 0 && !stats && precision != 1 && !pair_rows;
+  const bool plain = !ypre && !res && !kscale && !aux && !out_nchw && act == 0 && !stats && precision != 1 && !pair_rows &&
+                     !colstats;
   if (plain && tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride)) vr_note_kernel(4);
   if (plain && tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride))
     return vr_tiny_conv(mode, a, lda, w, mode == 0 ? bias : nullptr, y, ldy, B, H, W, Cin, Cout, kh, pad, dil, accumulate,
                         vr_stream(stream));
   // narrow outputs over wide inputs (head predictions, seg logits): direct HBM-streaming kernels (narrowconv.hip)
-  if ((vr_tune("VRNET_NARROW", 3) >> mode & 1) && !ypre && !res && !kscale && !aux && act == 0 && !stats && !pair_rows && precision != 1 &&
+  if ((vr_tune("VRNET_NARROW", 3) >> mode & 1) && !colstats && !ypre && !res && !kscale && !aux && act == 0 && !stats && !pair_rows && precision != 1 &&
       precision != 3 && vr_narrow_conv_ok(Cin, Cout, kh, kw, stride, pad) && !tiny_shape(H, W, Cin, OH, OW, Cout, kh, kw, stride) && vr_aligned16(w) &&
       (mode == 0 ? (lda % 4 == 0 && vr_aligned16(a)) : (!out_nchw && ldy % 4 == 0 && vr_aligned16(y)))) {
     VR_CHECK_ARG(lda >= (mode == 0 ? Cin : Cout) && (out_nchw || ldy >= (mode == 0 ? Cout : Cin)),
@@ -1291,6 +1315,13 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
             (!aux || ((ldaux % 4 == 0) && vr_aligned16(aux)));
   p.stats = stats;
   p.stats_nb = (int)vr_cdiv(p.CN, 32);
+  p.dbg_fake_presplit = vr_tune("VRNET_X6_FAKE_PRESPLIT", 0);
+  if (colstats) {
+    VR_CHECK_ARG(colstats->partial && (!colstats->tile_totals || colstats->gamma), "conv2d: column statistics need `partial` (and gamma "
+                                                                                 "with tile_totals)");
+    p.col_part = colstats->partial; p.col_x2 = colstats->x2; p.ld_col_x2 = colstats->ldx2;
+    p.col_gamma = colstats->gamma; p.col_tot = colstats->tile_totals;
+  }
   p.pair_rows = pair_rows; p.w2 = w2; p.bias2 = bias2; p.res_scale2 = res_scale2; p.kscale2 = kscale2;
   VR_CHECK_ARG(!pair_rows || (pair_rows < M && 2L * pair_rows == M), "conv2d: the two streams must have equal row counts");
   if (pair_rows && p.perm2) {
@@ -1301,6 +1332,9 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
     p.b_vec = p.b_vec && vr_aligned16(w2);
     p.e_vec = p.e_vec && (!bias2 || vr_aligned16(bias2)) && (!res_scale2 || vr_aligned16(res_scale2));
   }
+  VR_CHECK_ARG(!colstats || (p.e_vec && !p.perm2 && p.CN > 32 && (!colstats->x2 || (colstats->ldx2 % 4 == 0 && vr_aligned16(colstats->x2)))),
+               "conv2d: column statistics need the vector epilogue (NHWC, channel counts %% 4 == 0, 16-byte rows), > 32 output "
+               "channels and no stride-2 data gradient");
 #ifndef VR_IGEMM_STAMP2
   VR_CHECK_ARG(!stats || (p.e_vec && !p.perm2 && mode == 0 && ((long)p.MH * p.MW) % 32 == 0 && p.CN > 32),
                "conv2d: output statistics need the vector epilogue, a forward conv, > 32 output channels and a map of a "

@@ -28,6 +28,12 @@ struct IgemmArgs {
   // pair_rows is a multiple of every row-tile size, so a workgroup never straddles the two halves.
   int pair_rows;   // 0 = single parameter set
   const float* w2; const float* bias2; const float* res_scale2; const float* kscale2;
+  // Column statistics of the stored outputs per 32-row tile (vector epilogue only): col_part[mb][n] = (sum_m v, sum_m v * f)
+  // with f = col_x2[m, n] or, without col_x2, v itself -- the chunk partials of BatchNorm's batch statistics (forward) and
+  // of GroupNorm's backward moments, which otherwise cost a pass over the tensor each; col_tot[mb][n / 32] = the same two
+  // sums weighted by col_gamma[n] and added over the tile's 32 columns (GroupNorm backward: per-sample coefficients).
+  double* col_part; const float* col_x2; long ld_col_x2; const float* col_gamma; double* col_tot;
+  int dbg_fake_presplit;   // diagnostic build only (timing experiment, igemm.hip)
 };
 
 // The argument block a workgroup whose first row is m0 works with: the second stream's parameters behind pair_rows.
@@ -95,6 +101,7 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
   // The same source built with -fno-slp-vectorize, or this fp64 form, is repeatable; the library is built without the
   // SLP vectoriser for that reason, see the Makefile.)
   double q1 = 0.0, q2 = 0.0;
+  double cs1[4] = {0.0, 0.0, 0.0, 0.0}, cs2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int q = lane + 64 * t;
@@ -133,6 +140,55 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
           q1 += dv;
           q2 = __builtin_fma(dv, dv, q2);
         }
+      }
+      if (p.col_part) {
+        f32x4 f = v;
+        if (p.col_x2) f = *reinterpret_cast<const f32x4*>(p.col_x2 + mo * p.ld_col_x2 + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double dv = (double)v[e];
+          cs1[e] += dv;
+          cs2[e] = __builtin_fma(dv, (double)f[e], cs2[e]);
+        }
+      }
+    }
+  }
+  if (p.col_part) {      // lane (row group lane >> 3, column quad lane & 7): add the 8 row groups, lanes 0-7 report
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        cs1[e] += __shfl_xor(cs1[e], o, 64);
+        cs2[e] += __shfl_xor(cs2[e], o, 64);
+      }
+    }
+    const int mb = (m0 + wm * TM * 32 + ti * 32) >> 5;
+    const int n = n0 + wn * TN * 32 + tj * 32 + (lane & 7) * 4;
+    double g1 = 0.0, g2 = 0.0;
+    if (lane < 8 && mb * 32 < p.M && n < p.CN) {
+      double* d = p.col_part + ((long)mb * p.CN + n) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d[2 * e] = cs1[e];
+        d[2 * e + 1] = cs2[e];
+        if (p.col_tot) {
+          const double g = (double)p.col_gamma[n + e];
+          g1 += g * cs1[e];
+          g2 += g * cs2[e];
+        }
+      }
+    }
+    if (p.col_tot) {
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        g1 += __shfl_xor(g1, o, 64);
+        g2 += __shfl_xor(g2, o, 64);
+      }
+      const int nb = (n0 + wn * TN * 32 + tj * 32) >> 5;
+      if (lane == 0 && mb * 32 < p.M && nb < p.stats_nb) {
+        double* d = p.col_tot + ((long)mb * p.stats_nb + nb) * 2;
+        d[0] = g1;
+        d[1] = g2;
       }
     }
   }

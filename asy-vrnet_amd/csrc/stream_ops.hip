@@ -926,6 +926,45 @@ extern "C" int vrnet_gn_apply_bwd(const float* dy, long lddy, const float* x, lo
   return VR_OK;
 }
 
+/* The apply step alone, for dy whose moments the producing conv already left (vrnet_conv2d_f32 colstats with x2 = x and
+ * gamma): partial [B * HW/32][C][2], tile_totals [B * HW/32][ceil(C/32)][2]; HW % 32 == 0.  ONE launch. */
+extern "C" int vrnet_gn_apply_bwd_from_partials(const float* dy, long lddy, const float* x, long ldx, const double* partial,
+                                                const double* tile_totals, const float* mean_rstd, const float* gamma, int B,
+                                                long HW, int C, const float* add, long ldadd, float* out, long ldo,
+                                                float* dgamma, float* dbeta, int accumulate_params, void* stream) {
+  VR_CHECK_ARG(dy && x && partial && tile_totals && mean_rstd && gamma && out && dgamma && dbeta, "gn_apply_bwd_from_partials: null tensor");
+  VR_CHECK_ARG(B > 0 && HW > 0 && HW % 32 == 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 &&
+                   (!add || ldadd % 4 == 0) && vr_aligned16(dy) && vr_aligned16(x) && vr_aligned16(out) && vr_aligned16(gamma) &&
+                   (!add || vr_aligned16(add)),
+               "gn_apply_bwd_from_partials: needs HW %% 32 == 0, C %% 4 == 0 and 16-byte aligned rows");
+  if (vr_ablated("affine")) return VR_OK;
+  long bx = vr_cdiv(HW * (C / 4), 256 * 4);
+  const long cap = vr_cdiv(2048, B);
+  if (bx > cap) bx = cap;
+  const long need = vr_cdiv(C, 4);
+  if (bx < need) bx = need;
+  const int nchunks = (int)(HW / 32);
+  hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3((unsigned)bx, B + 1), dim3(256), 0, vr_stream(stream), dy, lddy, x, ldx, tile_totals,
+                     nchunks * (int)vr_cdiv(C, 32), partial, nchunks, mean_rstd, gamma, B, HW, C, add, ldadd, out, ldo, dgamma, dbeta,
+                     accumulate_params);
+  VR_LAUNCH_CHECK("gn_apply_bwd_from_partials");
+  return VR_OK;
+}
+
+/* Train-mode BatchNorm coefficients + running statistics from the column partials the producing conv left
+ * (vrnet_conv2d_f32 colstats, x2 = NULL): partial [B * HW/32][C][2]; HW % 32 == 0.  ONE launch, no pass over the tensor. */
+extern "C" int vrnet_bn_coef_fwd_from_partials(const double* partial, const float* gamma, const float* beta, float eps,
+                                               float momentum, float* running_mean, float* running_var,
+                                               long long* num_batches_tracked, int B, long HW, int C, float* A, float* D, float* S,
+                                               float* mean_rstd, void* stream) {
+  VR_CHECK_ARG(partial && gamma && beta && running_mean && running_var && A && D && S && mean_rstd, "bn_coef_fwd_from_partials: null tensor");
+  VR_CHECK_ARG((long)B * HW > 1 && HW % 32 == 0, "bn_coef_fwd_from_partials: needs HW %% 32 == 0 and more than 1 value per channel");
+  hipLaunchKernelGGL(bn_coef_fwd_partial_kernel, dim3(vr_cdiv(C, 4)), dim3(256), 0, vr_stream(stream), partial, (int)(HW / 32), gamma,
+                     beta, eps, momentum, running_mean, running_var, num_batches_tracked, B, HW, C, A, D, S, mean_rstd);
+  VR_LAUNCH_CHECK("bn_coef_fwd_from_partials");
+  return VR_OK;
+}
+
 extern "C" int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int B, long HW, int C,
                                  float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,
                                  const float* gamma2, float* dgamma2, float* dbeta2, void* stream) {

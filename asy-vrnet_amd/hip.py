@@ -28,7 +28,7 @@ _SIGS = {
     "vrnet_tuning_build": ([], I),
     "vrnet_kernel_launches": ([I], L),
     "vrnet_device_arch": ([ctypes.c_char_p, I], I),
-    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P], I),
+    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
     "vrnet_conv2d_dma_tile": ([L, I], I),
     "vrnet_conv2d_wgrad_workspace": ([I] * 8, L),
@@ -48,6 +48,8 @@ _SIGS = {
     "vrnet_gn_coef_bwd": ([P, P, P, I, L, I, P, P, P, P, P, P, I, P, P, P, P], I),
     "vrnet_gn_apply_fwd": ([P, L, P, L, P, P, F, I, L, I, P, L, P, P], I),
     "vrnet_gn_bwd_workspace": ([I, L, I], L),
+    "vrnet_gn_apply_bwd_from_partials": ([P, L, P, L, P, P, P, P, I, L, I, P, L, P, L, P, P, I, P], I),
+    "vrnet_bn_coef_fwd_from_partials": ([P, P, P, F, F, P, P, P, I, L, I, P, P, P, P, P], I),
     "vrnet_gn_apply_bwd": ([P, L, P, L, P, P, I, L, I, P, L, P, L, P, P, I, P, L, P], I),
     "vrnet_bn_coef_fwd": ([P, P, P, F, F, P, P, P, I, I, L, I, P, P, P, P, P], I),
     "vrnet_bn_coef_bwd": ([P, P, P, I, I, L, I, P, P, P, P, P, P, I, P], I),
@@ -106,6 +108,11 @@ EXPORTED = tuple(_SIGS)
 def _check(rc, name):
     if rc != 0:
         raise RuntimeError(f"{name}: {_lib.vrnet_last_error().decode()}")
+
+
+class ConvColStats(ctypes.Structure):
+    """vrnet_conv_colstats (include/vrnet_hip.h): optional column statistics of a conv's stored outputs."""
+    _fields_ = [("partial", P), ("x2", P), ("ldx2", L), ("gamma", P), ("tile_totals", P)]
 
 
 _DTYPES = frozenset((torch.float32, torch.float64, torch.uint8, torch.int64, torch.int32))
@@ -177,12 +184,17 @@ _ws = Workspace()
 def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, mode=0, act=0,
            ypre=None, ldypre=0, res=None, ldres=0, res_scale=None, kscale=None, aux=None, ldaux=0,
            out_nchw=0, out_ctot=0, out_coff=0, accumulate=0, stats=None, precision=0, pair_rows=0, w2=None, bias2=None,
-           res_scale2=None, kscale2=None):
-    """pair_rows > 0: two-stream launch, GEMM rows >= pair_rows use (w2, bias2, res_scale2, kscale2)."""
+           res_scale2=None, kscale2=None, colstats=None):
+    """pair_rows > 0: two-stream launch, GEMM rows >= pair_rows use (w2, bias2, res_scale2, kscale2).
+    colstats = (partial, x2, ldx2, gamma, tile_totals) (None entries allowed): column statistics of the stored outputs."""
+    cs = None
+    if colstats is not None:
+        part, x2, ldx2, gam, tot = colstats
+        cs = ctypes.byref(ConvColStats(ptr(part), ptr(x2), ldx2, ptr(gam), ptr(tot)))
     _check(_lib.vrnet_conv2d_f32(ptr(a), lda, ptr(w), ptr(bias), ptr(y), ldy, B, H, W, Cin, OH, OW, Cout, kh, kw,
                                  stride, pad, dil, mode, act, ptr(ypre), ldypre, ptr(res), ldres, ptr(res_scale),
                                  ptr(kscale), ptr(aux), ldaux, out_nchw, out_ctot, out_coff, accumulate, ptr(stats),
-                                 precision, pair_rows, ptr(w2), ptr(bias2), ptr(res_scale2), ptr(kscale2), stream()),
+                                 precision, pair_rows, ptr(w2), ptr(bias2), ptr(res_scale2), ptr(kscale2), cs, stream()),
            "conv2d")
 
 
@@ -301,6 +313,29 @@ def gn_apply_bwd(dy, lddy, x, ldx, mean_rstd, gamma, B, HW, C, out, ldo, dgamma,
     ws = _ws.get(_lib.vrnet_gn_bwd_workspace(B, HW, C), x.device)
     _check(_lib.vrnet_gn_apply_bwd(ptr(dy), lddy, ptr(x), ldx, ptr(mean_rstd), ptr(gamma), B, HW, C, ptr(add), ldadd, ptr(out),
                                    ldo, ptr(dgamma), ptr(dbeta), accumulate_params, ptr(ws), ws.numel(), stream()), "gn_apply_bwd")
+
+
+def colstats_ok(HW, Cout, *lds):
+    """Shapes for which a conv can leave the column statistics of its output (see conv2d `colstats`)."""
+    return HW % 32 == 0 and Cout > 32 and Cout % 4 == 0 and all(ld % 4 == 0 for ld in lds)
+
+
+def colstats_buffers(B, HW, C, device, totals=False):
+    part = torch.empty((B * HW // 32, C, 2), dtype=torch.float64, device=device)
+    tot = torch.empty((B * HW // 32, (C + 31) // 32, 2), dtype=torch.float64, device=device) if totals else None
+    return part, tot
+
+
+def gn_apply_bwd_from_partials(dy, lddy, x, ldx, partial, tile_totals, mean_rstd, gamma, B, HW, C, out, ldo, dgamma, dbeta,
+                               accumulate_params, add=None, ldadd=0):
+    _check(_lib.vrnet_gn_apply_bwd_from_partials(ptr(dy), lddy, ptr(x), ldx, ptr(partial), ptr(tile_totals), ptr(mean_rstd),
+                                                 ptr(gamma), B, HW, C, ptr(add), ldadd, ptr(out), ldo, ptr(dgamma), ptr(dbeta),
+                                                 accumulate_params, stream()), "gn_apply_bwd_from_partials")
+
+
+def bn_coef_fwd_from_partials(partial, gamma, beta, eps, momentum, rm, rv, nbt, B, HW, C, A, Dc, S, mean_rstd):
+    _check(_lib.vrnet_bn_coef_fwd_from_partials(ptr(partial), ptr(gamma), ptr(beta), eps, momentum, ptr(rm), ptr(rv), ptr(nbt), B,
+                                                HW, C, ptr(A), ptr(Dc), ptr(S), ptr(mean_rstd), stream()), "bn_coef_fwd_from_partials")
 
 
 def gn_coef_bwd(mom2, mean_rstd, gamma, B, HW, C, A, E, Dc, S, dgamma, dbeta, accumulate, gamma2=None, dgamma2=None,

@@ -24,12 +24,13 @@ class Act:
     Two-stream buffers: the image and the radar stream of a backbone stage live in ONE (2B,H,W,C) tensor (image
     samples first) so that a stage's ClusterBlocks run as one launch per layer; `half(k)` is the Act of one stream --
     a view whose gradient is the matching half of the parent's gradient buffer (`written[k]`: that half holds data)."""
-    __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad", "pairs", "parent", "slot", "written", "_halves",
+    __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad", "pairs", "colpart", "parent", "slot", "written", "_halves",
                  "__weakref__")
 
     def __init__(self, t, need_grad=True):
         self.t = t
         self.pairs = None       # (fp64 (sum, sumsq) pairs, pairs per sample) emitted by the conv that produced `t`
+        self.colpart = None     # fp64 per-channel (sum, sumsq) partials per 32-row tile emitted by that conv (BatchNorm)
         self.B, self.H, self.W, self.C = t.shape
         self.ld = t.stride(2)
         self.grad = None
@@ -81,6 +82,10 @@ class RT:
         self.bf16 = False           # dense convs with bf16-rounded operands on the bf16 MFMA (model.compute_dtype)
         self.fp32_precision = 2     # fp32 layers: 2 = six-bf16-product kernels where available, 0 = fp32 MFMA only
         self.fused_mlp = True       # Mlp of a ClusterBlock as one kernel per direction where the library has one
+        self.bn_colstats = True     # BatchNorm batch statistics from the producing conv's epilogue (no pass over z)
+        self.gn_colstats = False    # GroupNorm backward moments from the producing data-gradient conv's epilogue (built and
+                                    # tested; same-box A/B: 29.16 -> 29.16 ms with it, 29.01 without: the epilogue work it adds to
+                                    # the x6 data-gradient kernels costs what the 46 moments launches it removes were worth)
         self.consts = {}
         self.idx_maps = {}
         self.relu_masks = None      # {BatchNorm module: ReLU output Act} when model.record_relu_masks (parity tests)
@@ -440,7 +445,7 @@ def _pair_kw(rt, x, convs, w_of, bias=True, res_scale=None, kscale=None):
     return dict(w2=w_of(c1), bias2=c1.bias if bias else None, res_scale2=rs1, kscale2=ks1)
 
 
-def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw=None, bias=True, stats=False):
+def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw=None, bias=True, stats=False, bn_stats=False):
     """out: Act (NHWC target) or, with nchw=(tensor, ctot, coff), a channel range of an NCHW tensor.
     conv / res_scale may be pairs (two-stream launch over a (2B,...) input: first half of the rows = first module)."""
     c0, c1 = _pair(conv)
@@ -449,6 +454,11 @@ def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw
     if nchw is None:
         pairs, per = hip.conv_stats_buffer(x.B, OH * OW, co, x.t.device) if stats else (None, 0)
         kw2 = {}
+        if bn_stats and rt.bn_colstats and c1 is None and rt.training and hip.colstats_ok(OH * OW, co, out.ld, x.ld) and out.t.data_ptr() % 16 == 0 \
+                and x.t.data_ptr() % 16 == 0 and ci % 4 == 0:
+            # train-mode BatchNorm behind this conv: its per-channel batch sums come out of the epilogue (no pass over z)
+            out.colpart, _ = hip.colstats_buffers(x.B, OH * OW, co, x.t.device)
+            kw2["colstats"] = (out.colpart, None, 0, None, None)
         if c1 is not None:
             kw2 = _pair_kw(rt, x, conv, rt.weight, bias, res_scale)
             kw2["pair_rows"] = (x.B // 2) * OH * OW
@@ -467,7 +477,7 @@ def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw
 
 
 def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, skip_bias=False, dx_to=None,
-                  defer_ok=True, ls_grad=None, no_dx=False):
+                  defer_ok=True, ls_grad=None, no_dx=False, colstats=None):
     """Gradients of y = conv(x): weight/bias into the parameter table, dx accumulated into x.grad
     (or written to the Act `dx_to`).  dy: tensor whose data_ptr is the (0,0) element, row stride lddy.
     conv / kscale / row_scale / ls_grad may be pairs (two-stream launch).  ls_grad: the layer-scale parameter(s) behind
@@ -531,6 +541,8 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
             wd1, ks1, prec1 = rt.dgrad_operands(c1, c1.weight, rt.weight(c1), co, ci, kh, kw, ks1, lddy, rows)
             assert prec1 == prec
             kw2 = dict(pair_rows=(x.B // 2) * x.H * x.W, w2=wd1, kscale2=ks1)
+        if colstats is not None:
+            kw2["colstats"] = colstats
         hip.conv2d(dy, lddy, wd, None, buf, ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=1,
                    kscale=ks, aux=None if aux is None else aux.t, ldaux=0 if aux is None else aux.ld, accumulate=acc,
                    precision=prec, **kw2)
@@ -559,7 +571,11 @@ def bn_forward(rt, z, bn, relu, out=None, residual=None):
     """y = [relu](BN(z)) [+ residual].  Returns (y, ctx) where ctx feeds bn_backward."""
     B, HW, C = z.B, z.HW, z.C
     A, D, S, ms = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C, 2)
-    if rt.training:
+    if rt.training and z.colpart is not None:
+        hip.bn_coef_fwd_from_partials(z.colpart, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                      bn.num_batches_tracked, B, HW, C, A, D, S, ms)
+        z.colpart = None
+    elif rt.training:
         hip.bn_stats_fwd(z.t, z.ld, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
                          bn.num_batches_tracked, B, HW, C, A, D, S, ms)
     else:
@@ -629,10 +645,28 @@ def _pgrads_or_scratch(rt, params, sizes):
     return outs, acc
 
 
-def gn_backward(rt, gn, x, ms, dy, out, accumulate=0, add=None):
-    """out = dx of y = GN(x) given contiguous dy [+ out (accumulate) | + add (another contiguous tensor)]."""
+def gn_colstats(rt, gn, x):
+    """Buffers for the column statistics a data-gradient conv leaves for the backward pass of the GroupNorm `gn` whose
+    input was `x` (conv2d `colstats`), or None when the shape does not qualify."""
+    if not rt.gn_colstats or isinstance(gn, tuple) or not hip.colstats_ok(x.HW, x.C, x.ld) or x.t.data_ptr() % 16:
+        return None
+    part, tot = hip.colstats_buffers(x.B, x.HW, x.C, x.t.device, totals=True)
+    return (part, x.t, x.ld, gn.weight, tot)
+
+
+def gn_backward(rt, gn, x, ms, dy, out, accumulate=0, add=None, partials=None):
+    """out = dx of y = GN(x) given contiguous dy [+ out (accumulate) | + add (another contiguous tensor)].
+    partials: the colstats tuple the conv that produced dy was launched with (its moments are then already there)."""
     g0, g1 = _pair(gn)
     B, HW, C = x.B, x.HW, x.C
+    if partials is not None and (not accumulate or add is None):
+        (gw, gb), accw = _pgrads_or_scratch(rt, (g0.weight, g0.bias), (C, C))
+        hip.gn_apply_bwd_from_partials(dy, C, x.t, x.ld, partials[0], partials[4], ms, g0.weight, B, HW, C, out, C, gw, gb, accw,
+                                       add=out if accumulate else add, ldadd=C if (accumulate or add is not None) else 0)
+        if rt.on_param_grad:
+            rt.on_param_grad(g0.weight)
+            rt.on_param_grad(g0.bias)
+        return
     if g1 is None and hip.gn_apply_ok(C, x.ld) and (not accumulate or add is None):
         # two launches (moments; apply + parameter gradients) where moments, reduce, coefficients and affine were four
         (gw, gb), accw = _pgrads_or_scratch(rt, (g0.weight, g0.bias), (C, C))
@@ -668,7 +702,7 @@ def base_conv(rt, x, m, out=None):
     conv = m.conv
     co, ci, kh, kw, s, p, d, OH, OW = conv_geom(x, conv)
     z = rt.new(x.B, OH, OW, co)
-    conv_call(rt, x, conv, z, bias=False)
+    conv_call(rt, x, conv, z, bias=False, bn_stats=True)
     y, ms = bn_forward(rt, z, m.bn, relu=True, out=out)
 
     def bwd():
@@ -688,7 +722,7 @@ def ds_base_conv(rt, x, m, out=None):
     t = rt.new(x.B, x.H, x.W, C)
     hip.dwconv3x3(x.t, x.ld, dconv.weight, t.t, C, x.B, x.H, x.W, C)
     z = rt.new(x.B, x.H, x.W, pconv.weight.shape[0])
-    conv_call(rt, t, pconv, z, bias=False)
+    conv_call(rt, t, pconv, z, bias=False, bn_stats=True)
     y, ms = bn_forward(rt, z, m.bn, relu=True, out=out)
 
     def bwd():
@@ -776,6 +810,7 @@ def cluster_block(rt, x, m, name=None):
         # ---- MLP branch
         du = rt.new(B, H, W, hid)
         dxn2 = rt.new(B, H, W, C)
+        cs2 = None
         if pmlp:
             # one kernel: d(pre-activation) and the recomputed activation are written once for the two weight gradients,
             # which run beside the rest of the block's backward like every other weight gradient
@@ -785,9 +820,10 @@ def cluster_block(rt, x, m, name=None):
             conv_backward(rt, xn2, mlp0.fc1, du.t, hid, no_dx=True)
         else:
             conv_backward(rt, h, _attr(mlp, "fc2"), dx2, C, kscale=ls2, aux=u, row_scale=ls2, dx_to=du, ls_grad=ls2)
-            conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2)
+            cs2 = None if paired else gn_colstats(rt, m0.norm2, x1)     # d xn2's GroupNorm moments from this conv's epilogue
+            conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2, colstats=cs2)
         dx1 = rt.buf(B, H, W, C)
-        gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx1, add=dx2)               # dx1 = dx2 + d(GN -> Mlp branch)
+        gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx1, add=dx2, partials=cs2)   # dx1 = dx2 + d(GN -> Mlp branch)
         # ---- Cluster branch
         do = rt.new(B, H, W, ED)
         conv_backward(rt, o, _attr(tm, "fc2"), dx1, C, kscale=ls1, row_scale=ls1, dx_to=do, ls_grad=ls1)
@@ -812,9 +848,12 @@ def cluster_block(rt, x, m, name=None):
         if paired:
             wd1, _, _ = rt.dgrad_operands(tm1, tm1._fused_qkv[0], tm1._fused_qkv[0], 2 * ED, C, 1, 1, None, 2 * ED, B * H * W)
             kwd = dict(pair_rows=rows_half, w2=wd1)
+        cs1 = None if paired else gn_colstats(rt, m0.norm1, x)
+        if cs1 is not None:
+            kwd["colstats"] = cs1
         hip.conv2d(dfv.t, 2 * ED, wd, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1, precision=prec, **kwd)
         dx = rt.buf(B, H, W, C)
-        gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx, add=dx1)                   # dx = dx1 + d(GN -> Cluster branch)
+        gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx, add=dx1, partials=cs1)     # dx = dx1 + d(GN -> Cluster branch)
         rt.give_grad(x, dx)
     rt.push(bwd)
     return x2
@@ -879,7 +918,7 @@ def image_enhance(rt, x, r, m, out=None):
     conv, bn1 = m.radar_projection.conv, m.radar_projection.bn
     B, H, W, C = x.B, x.H, x.W, x.C
     z = rt.new(B, H, W, C)
-    conv_call(rt, r, conv, z, bias=False)
+    conv_call(rt, r, conv, z, bias=False, bn_stats=True)
     p, ms1 = bn_forward(rt, z, bn1, relu=True)
     mm = rt.buf(2)
     n = p.t.numel()
@@ -1007,7 +1046,7 @@ def radar_enhance(rt, x, r, m, out=None):
     conv, bn1 = m.inverse_projection.conv, m.inverse_projection.bn
     B, H, W, C = r.B, r.H, r.W, r.C
     z = rt.new(B, H, W, C)
-    conv_call(rt, u, conv, z, bias=False)
+    conv_call(rt, u, conv, z, bias=False, bn_stats=True)
     q, ms1 = bn_forward(rt, z, bn1, relu=True)
     s = rt.new(B, H, W, C)
     hip.affine(s.t, C, B, H * W, C, x1=q.t, ld1=C, x2=r.t, ld2=r.ld)
@@ -1069,7 +1108,7 @@ def aspp(rt, x, m):
     def conv_branch(k, br):
         conv, bn = br[0], br[1]
         z = rt.new(B, H, W, C)
-        conv_call(rt, x, conv, z)
+        conv_call(rt, x, conv, z, bn_stats=True)
         sl = Act(cat.t[..., k * C:(k + 1) * C])
         _, ms = bn_forward(rt, z, bn, relu=True, out=sl)
         return (conv, bn, z, sl, ms)
@@ -1089,7 +1128,7 @@ def aspp(rt, x, m):
     saved, (gm, z5, q5, ms5) = res[:4], res[4]
     convc, bnc = m.conv_cat[0], m.conv_cat[1]
     zc = rt.new(B, H, W, C)
-    conv_call(rt, cat, convc, zc)
+    conv_call(rt, cat, convc, zc, bn_stats=True)
     y, msc = bn_forward(rt, zc, bnc, relu=True)
 
     def bwd():
@@ -1344,6 +1383,8 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         # two-stream chain 31.6 ms/step (and 1 480 instead of 2 070 launches): the default is the faster one
         rt.pair_streams = bool(getattr(model, "pair_streams", False))
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
+        rt.bn_colstats = bool(getattr(model, "bn_colstats", True))
+        rt.gn_colstats = bool(getattr(model, "gn_colstats", False))
         cd = str(os.environ.get("VRNET_COMPUTE_DTYPE") or getattr(model, "compute_dtype", "f32")).lower()   # env: diagnostics
         if cd not in ("f32", "fp32", "float32", "torch.float32", "f32-mfma", "bf16", "bfloat16", "torch.bfloat16"):
             raise RuntimeError(f"compute_dtype {cd!r}: expected 'f32', 'f32-mfma' or 'bf16'")

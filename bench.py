@@ -73,7 +73,7 @@ def pmc_traffic_bytes(phi):
         return None
     n, tot = 0, 0.0
     for row in csv.DictReader(open(files[-1])):
-        if row["kernel"].startswith(("igemm_kernel", "igemm_dma_kernel")):
+        if row["kernel"].startswith(("igemm_kernel", "igemm_dma_kernel", "mlp_fused_kernel")):
             k = int(row["launches"])
             n += k
             tot += k * float(row["avg_HBM_MB"]) * 1024 * 1024
@@ -306,6 +306,11 @@ def main():
                          "instead of two chains on two forked streams")
     ap.add_argument("--no-pair", action="store_true", help="(default) two chains on two forked streams")
     ap.add_argument("--no-fused-mlp", action="store_true", help="Mlp as two conv launches (A/B aid)")
+    ap.add_argument("--no-bn-colstats", action="store_true", help="BatchNorm statistics by a pass over z (A/B aid)")
+    ap.add_argument("--gn-colstats", action="store_true", help="GroupNorm backward moments from the data-gradient conv's epilogue (A/B aid; off by default)")
+    ap.add_argument("--diagnostic", action="store_true",
+                    help="allow VRNET_* environment knobs and the diagnostic library build (tools/sweep_env.sh ablations); the "
+                         "line is then marked `diagnostic`, its metric string says so, and it is not a measurement")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     args = ap.parse_args()
 
@@ -326,7 +331,7 @@ def main():
     # Measurement hygiene: no tuning / diagnostic knob may be active in a benchmark run.  The product library reads no
     # environment at all (the knobs are compiled into the diagnostic build only); the host-side ones are refused here.
     knobs = sorted(k for k in os.environ if k.startswith("VRNET_") and k != "VRNET_BENCH_FORCE_DP")
-    if knobs:
+    if knobs and not args.diagnostic:
         raise SystemExit(f"bench.py: refusing to run with diagnostic environment variables set: {', '.join(knobs)}")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -344,7 +349,7 @@ def main():
     import asy_vrnet_amd as A
     from asy_vrnet_amd import hip
     from asy_vrnet_amd.parallel import DataParallelVRNet
-    if hip.tuning_build():
+    if hip.tuning_build() and not args.diagnostic:
         raise SystemExit("bench.py: the loaded library is the diagnostic build (make tuning); benchmark the product library")
     model = A.EfficientVRNet(4, 9, args.phi, img_size=args.size).to(dev).train()
     A.randomize_state_dict(model.state_dict(), seed=0)
@@ -353,6 +358,8 @@ def main():
         model.concurrent = False
     model.pair_streams = bool(args.pair)
     model.fused_mlp = not args.no_fused_mlp
+    model.bn_colstats = not args.no_bn_colstats
+    model.gn_colstats = bool(args.gn_colstats)
     net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 
@@ -481,6 +488,9 @@ def main():
                            "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"dp{world}", "launch": launch},
                 "roofline": roof, "cpu_baseline": cpu,
                 "env": {k: v for k, v in os.environ.items() if k.startswith("VRNET_")}, "schema": 3}
+        if args.diagnostic:
+            line["diagnostic"] = True
+            line["metric"] = "DIAGNOSTIC RUN (env knobs / tuning build allowed: not a measurement) -- " + line["metric"]
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -71,12 +71,27 @@ int vrnet_device_arch(char* buf, int len);   /* host buffer <- e.g. "gfx950:sram
  * MFMA by itself; precision 3 (bf16-rounded operands with the STANDARD weight layout in both modes, kscale allowed) is only
  * accepted where this returns non-zero. */
 int vrnet_conv2d_dma_tile(long rows, int cols);
+/* Optional column statistics of the STORED outputs (NULL = none; NHWC vector epilogue, > 32 output channels, not for
+ * stride-2 data gradients): what a separate pass over the output tensor would otherwise compute.
+ *   partial[mb][n] = (sum_m v[m,n], sum_m v[m,n] * f[m,n]) over the 32 rows of row tile mb, f = x2 (row stride ldx2) or,
+ *     with x2 == NULL, v itself: the chunk partials of train-mode BatchNorm statistics (vrnet_bn_coef_fwd_partial, forward
+ *     conv of a BaseConv, normal_conv.py:45-49) and of GroupNorm's backward moments (data gradient of the conv behind a
+ *     GroupNorm, x2 = the GroupNorm input; vr_coc.py:264-271), in the layout [row tile][channel][2] of the moments kernel;
+ *   tile_totals[mb][n / 32] = the same two sums weighted by gamma[n] and added over the tile's 32 columns (GroupNorm
+ *     backward: per-sample coefficients, vrnet_gn_apply_bwd_from_partials). */
+typedef struct vrnet_conv_colstats {
+  double* partial;
+  const float* x2; long ldx2;
+  const float* gamma;
+  double* tile_totals;
+} vrnet_conv_colstats;
 int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias, float* y, long ldy,
                      int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride, int pad,
                      int dil, int mode, int act, float* ypre, long ldypre, const float* res, long ldres,
                      const float* res_scale, const float* kscale, const float* aux, long ldaux, int out_nchw,
                      int out_ctot, int out_coff, int accumulate, double* stats, int precision, int pair_rows,
-                     const float* w2, const float* bias2, const float* res_scale2, const float* kscale2, void* stream);
+                     const float* w2, const float* bias2, const float* res_scale2, const float* kscale2,
+                     const vrnet_conv_colstats* colstats, void* stream);
 
 /* Weight (+ bias) gradient of the same convolutions (autograd of nn.Conv2d): dw in OIHW layout
  * [Cout][Cin][kh][kw], dbias[Cout] (NULL = none), both scaled by row_scale[Cout] when given (layer scale).
@@ -182,6 +197,19 @@ int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* g
 int vrnet_gn_apply_fwd(const float* x, long ldx, const double* pairs, long pairs_per_sample, const float* gamma,
                        const float* beta, float eps, int B, long HW, int C, float* y, long ldy, float* mean_rstd, void* stream);
 long vrnet_gn_bwd_workspace(int B, long HW, int C);
+/* The apply step of vrnet_gn_apply_bwd alone (ONE launch) when the conv that produced dy already left its moments
+ * (vrnet_conv_colstats with x2 = the GroupNorm input, gamma = the GroupNorm weight): partial [B*HW/32][C][2],
+ * tile_totals [B*HW/32][ceil(C/32)][2]; HW % 32 == 0. */
+int vrnet_gn_apply_bwd_from_partials(const float* dy, long lddy, const float* x, long ldx, const double* partial,
+                                     const double* tile_totals, const float* mean_rstd, const float* gamma, int B, long HW,
+                                     int C, const float* add, long ldadd, float* out, long ldo, float* dgamma, float* dbeta,
+                                     int accumulate_params, void* stream);
+/* Train-mode BatchNorm2d coefficients (y = A * (z - S) + D), running statistics and mean / rstd from the column partials
+ * the producing conv left (vrnet_conv_colstats, x2 = NULL; partial [B*HW/32][C][2]; HW % 32 == 0): BaseConv's conv -> BN
+ * (normal_conv.py:45-49) without a statistics pass over z. */
+int vrnet_bn_coef_fwd_from_partials(const double* partial, const float* gamma, const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var, long long* num_batches_tracked, int B, long HW,
+                                    int C, float* A, float* D, float* S, float* mean_rstd, void* stream);
 int vrnet_gn_apply_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean_rstd, const float* gamma, int B,
                        long HW, int C, const float* add, long ldadd, float* out, long ldo, float* dgamma, float* dbeta,
                        int accumulate_params, void* workspace, long workspace_bytes, void* stream);

@@ -1245,3 +1245,66 @@ def test_group_norm_one_and_two_launch_forms(hip, shape):
     hip.gn_apply_bwd(g.cuda(), C, xg, C, ms, gam.cuda(), B, H * W, C, dx2, C, dg, db, 0, add=dx2, ldadd=C)
     assert torch.equal(dx2, dx)
     close(dg, gd.grad, 5e-5, what="dgamma")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 96, 1, 1, 0, 1, 0), (8, 32, 32, 320, 128, 1, 1, 0, 1, 2), (2, 128, 128, 64, 128, 1, 1, 0, 1, 2),
+                                  (2, 32, 32, 64, 64, 3, 1, 1, 1, 2), (2, 16, 16, 96, 48, 3, 2, 1, 1, 0), (2, 32, 32, 128, 64, 1, 1, 0, 1, 1)])
+def test_conv_column_statistics(hip, case):
+    """conv2d `colstats`: per-channel (sum, sum of squares) partials of the stored outputs per 32-row tile -- train-mode
+    BatchNorm statistics without a pass over z -- and, on a data gradient, the GroupNorm-backward moments (sum dy, sum dy * x)
+    with gamma-weighted tile totals; both against fp64 ATen, and through the coefficient kernels that consume them."""
+    B, H, W, Ci, Co, k, s, p, d, prec = case
+    OH, OW = (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
+    x = rnd(B, Ci, H, W, seed=1)
+    w, b = rnd(Co, Ci, k, k, seed=2) / np.sqrt(Ci * k * k), rnd(Co, seed=3)
+    if prec == 1:
+        x, w = _bf16r(x), _bf16r(w)
+    z = F.conv2d(x.double(), w.double(), b.double(), s, p, d)
+    xg, wp = nhwc(x), pack(hip, w)
+    y = torch.empty(B, OH, OW, Co, device="cuda")
+    part, _ = hip.colstats_buffers(B, OH * OW, Co, "cuda")
+    hip.conv2d(xg, Ci, wp, b.cuda(), y, Co, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, precision=prec, colstats=(part, None, 0, None, None))
+    yd = y.double().cpu().view(B * OH * OW // 32, 32, Co)
+    close(part[..., 0], yd.sum(1), 1e-9, what="tile column sums")
+    close(part[..., 1], (yd * yd).sum(1), 1e-9, what="tile column sums of squares")
+    close(part[..., 0].sum(0), z.sum((0, 2, 3)), 2e-4 if prec == 1 else 2e-5, what="channel sums vs ATen")
+    # ... and the BatchNorm coefficients from them
+    gam, bet = rnd(Co, seed=4).cuda() * 0.3 + 1, rnd(Co, seed=5).cuda()
+    rm, rv, nbt = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
+    A, D, S, ms = (torch.empty(Co, device="cuda") for _ in range(3)) , None, None, torch.empty(Co, 2, device="cuda")
+    A, D, S = A
+    hip.bn_coef_fwd_from_partials(part, gam, bet, 1e-3, 0.03, rm, rv, nbt, B, OH * OW, Co, A, D, S, ms)
+    yy = y.double().cpu().view(-1, Co)
+    close(S, yy.mean(0), 1e-6, what="bn mean")
+    close(A, gam.double().cpu() / torch.sqrt(yy.var(0, unbiased=False) + 1e-3), 1e-5, what="bn scale")
+    close(rv, 0.97 + 0.03 * yy.var(0, unbiased=True), 1e-5, what="running_var")
+    assert int(nbt) == 1
+    if s != 1:
+        return
+    # ---- data gradient with GroupNorm-backward moments: dxn = conv^T(g); sums of dxn and dxn * xin per channel, gamma totals
+    g = rnd(B, Co, OH, OW, seed=6)
+    xin, gamma = rnd(B, H, W, Ci, seed=7).cuda(), (rnd(Ci, seed=8) * 0.3 + 1).cuda()
+    dx = torch.empty(B, H, W, Ci, device="cuda")
+    part, tot = hip.colstats_buffers(B, H * W, Ci, "cuda", totals=True)
+    hip.conv2d(nhwc(g), Co, wp, None, dx, Ci, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, mode=1, precision=0 if prec == 1 else prec,
+               colstats=(part, xin, Ci, gamma, tot))
+    dd, xx = dx.double().cpu().view(B * H * W // 32, 32, Ci), xin.double().cpu().view(B * H * W // 32, 32, Ci)
+    close(part[..., 0], dd.sum(1), 1e-9, what="dgrad tile column sums")
+    close(part[..., 1], (dd * xx).sum(1), 1e-9, what="dgrad tile column sums of dy * x")
+    gd = gamma.double().cpu()
+    nb = (Ci + 31) // 32
+    pad = torch.zeros(B * H * W // 32, nb * 32, 2, dtype=torch.float64)
+    pad[:, :Ci, 0], pad[:, :Ci, 1] = dd.sum(1) * gd, (dd * xx).sum(1) * gd
+    close(tot, pad.view(-1, nb, 32, 2).sum(2), 1e-9, what="gamma-weighted tile totals")
+    # the one-launch GroupNorm backward that consumes them, against the two-launch form
+    ms = torch.stack([xin.double().mean((1, 2, 3)), 1 / torch.sqrt(xin.double().var((1, 2, 3), unbiased=False) + 1e-5)], 1).float().cuda()
+    outs = []
+    for form in (0, 1):
+        o, dg, db = torch.empty(B, H, W, Ci, device="cuda"), torch.empty(Ci, device="cuda"), torch.empty(Ci, device="cuda")
+        if form == 0:
+            hip.gn_apply_bwd(dx, Ci, xin, Ci, ms, gamma, B, H * W, Ci, o, Ci, dg, db, 0)
+        else:
+            hip.gn_apply_bwd_from_partials(dx, Ci, xin, Ci, part, tot, ms, gamma, B, H * W, Ci, o, Ci, dg, db, 0)
+        outs.append((o, dg, db))
+    for a, b_, nm in zip(outs[1], outs[0], ("dx", "dgamma", "dbeta")):
+        close(a, b_, 1e-5, what="gn backward from partials: " + nm)

@@ -3,12 +3,13 @@
 # profiles/ with the round prefix afterwards):  bash tools/refresh_profiles.sh
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
+R=r03
 out=gpurun_out/refresh
 rm -rf $out; mkdir -p $out
 python3 bench.py > $out/bench_phi-l_bs8_512.json 2> $out/bench_l.err
 python3 bench.py --phi nano --no-cpu-baseline > $out/bench_phi-nano_bs8_512.json 2>/dev/null
-python3 bench.py --no-cpu-baseline --pair > $out/bench_phi-l_bs8_512_pair.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --dtype f32-mfma > $out/bench_phi-l_bs8_512_f32-mfma.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --no-fused-mlp > $out/bench_phi-l_bs8_512_no-fused-mlp.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --dtype bf16 > $out/bench_phi-l_bs8_512_bf16.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --dtype bf16 --batch 16 > $out/bench_phi-l_bs16_512_bf16.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --dtype bf16 --batch 4 --size 1024 > $out/bench_phi-l_bs4_1024_bf16.json 2>/dev/null
@@ -18,9 +19,12 @@ VRNET_BENCH_FORCE_DP=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-n
     bench.py --gpus 1 --no-cpu-baseline --no-roofline 2>/dev/null | grep metric > $out/line_dp1_rccl_3segments_phi-l_bs8_512.json
 python3 tools/x6_probe.py > $out/x6_vs_fp32_mfma_gemm_probe.txt 2>/dev/null
 python3 tools/x6_probe.py wgrad >> $out/x6_vs_fp32_mfma_gemm_probe.txt 2>/dev/null
+# diagnostic build: fused-Mlp store / wait experiments and the launch-skipping ablations
+export VRNET_HIP_LIB=$PWD/asy-vrnet_amd/csrc/libvrnet_hip_tuning.so
+(for d in 0 1 2; do VRNET_MLP_DBG=$d python3 tools/mlp_probe.py 2>&1 | grep "^M"; done) > $out/mlp_fused_probe.txt
 tools/sweep_env.sh "" "VRNET_ABLATE=igemm" "VRNET_ABLATE=wgrad" "VRNET_ABLATE=igemm,wgrad" "VRNET_ABLATE=moments,affine" \
-    "VRNET_ABLATE=igemm,wgrad,moments,affine" "VRNET_ABLATE=igemm_big" "VRNET_ABLATE=igemm_mid" "VRNET_ABLATE=igemm_small" \
-    "VRNET_ABLATE=wgrad_big" "VRNET_ABLATE=wgrad_mid" "VRNET_ABLATE=wgrad_small" > $out/ablation_ms_per_step.txt 2>&1
+    "VRNET_ABLATE=igemm,wgrad,moments,affine" > $out/ablation_ms_per_step.txt 2>&1
+unset VRNET_HIP_LIB
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/graph -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > $out/graph.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --serial --no-graph > $out/serial.log 2>&1
 cp $(ls $out/graph/*/*kernel_stats.csv | head -1) $out/kernel_stats_phi-l_bs8_512_hipgraph.csv
@@ -32,8 +36,10 @@ bash tools/pmc_mfma.sh $out/mfma_util_pmc_phi-l_bs8_512.csv > $out/pmc_mfma.log 
 rm -rf gpurun_out/pmc_mfma
 python3 tools/join_hbm_rate.py $out/hbm_traffic_pmc_phi-l_bs8_512.csv $out/kernel_stats_phi-l_bs8_512_serial.csv > $out/hbm_rate_per_kernel_phi-l_bs8_512.csv 2>/dev/null
 # the headline line last, with the PMC traffic of THIS kernel source in place (bench.py checks the source hash)
-cp $out/hbm_traffic_pmc_phi-l_bs8_512.csv profiles/r02_hbm_traffic_pmc_phi-l_bs8_512.csv
-cp $out/hbm_traffic_pmc_phi-l_bs8_512.csv.meta.json profiles/r02_hbm_traffic_pmc_phi-l_bs8_512.csv.meta.json
+cp $out/hbm_traffic_pmc_phi-l_bs8_512.csv profiles/${R}_hbm_traffic_pmc_phi-l_bs8_512.csv
+cp $out/hbm_traffic_pmc_phi-l_bs8_512.csv.meta.json profiles/${R}_hbm_traffic_pmc_phi-l_bs8_512.csv.meta.json
 python3 bench.py > $out/bench_phi-l_bs8_512.json 2> $out/bench_l.err
+(echo "# tools/micro/x6_overlap.hip: 24 MFMAs + 4 fragment splits per K16 step; clustered / software-pipelined, accumulators free / pinned to AGPRs"; timeout 120 tools/micro/x6_overlap.bin) > $out/x6_overlap_micro.txt 2>&1
+(echo "# tools/micro/mfma_chain.hip: v_mfma_f32_32x32x16_bf16 issue rate vs number of independent accumulator chains"; timeout 120 tools/micro/mfma_chain.bin) > $out/mfma_chain_micro.txt 2>&1
 (echo "# tools/micro/x6_peak.hip: register-resident x6 inner loop, no memory (mfma only / splits only / both)"; timeout 120 tools/micro/x6_peak.bin) > $out/x6_issue_ceiling_micro.txt 2>&1
 ls -la $out
