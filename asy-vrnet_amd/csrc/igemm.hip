@@ -668,6 +668,189 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// x6 implicit GEMM for 1x1 convs with PRE-SPLIT weights (round 3).  The six-product scheme spends its VALU time on splitting
+// fragments into bf16 planes, and the matrix pipe and the VALU do not overlap on gfx950 -- but the B operand is the same
+// weight tile for every row tile of every launch of a step.  vrnet_conv_planes_pack_f32 splits every eligible weight ONCE
+// per step into three bf16 planes laid out as the LDS image of a stage: [k16 step][64-column block][plane][lane half][64
+// columns] x 8 bf16, so a stage's B tile is one contiguous 6 KB (x TN) block that goes global -> LDS by DMA as it is and
+// every B fragment is one conflict-free ds_read_b128 per plane; only the A (activation) fragments are split in the
+// kernel: 2 instead of 3 (128 x 64 tile) resp. 4 (128 x 128) fragment splits per K16 step.  Both directions use this
+// kernel: the forward pack holds w[n][c] (columns n, contraction c), the data-gradient pack the transposed weights with
+// the layer scale folded in (columns c, contraction n).  A operand, ring, XCD-aware tile map and epilogue as in
+// igemm_dma_kernel.  Measured bound of the idea (diagnostic build, B splits skipped): 27.8 -> 26.6 ms per step.
+template <int TN, int NST>
+__global__ __launch_bounds__(256, (NST * (8192 + TN * 6144) <= 49152) ? 3 : 2) void igemm_planes_kernel(const IgemmArgs p,
+                                                                                                      const unsigned char* planes,
+                                                                                                      int JB, int MT, int NT) {
+  // Wave layout 4 x 1: a wave owns 32 of the tile's 128 rows and ALL its columns, so every A fragment is split by exactly
+  // one wave (with the 2 x 2 layout of igemm_dma_kernel the two waves of a row pair split the same rows) -- with B free, the
+  // A splits are the whole VALU cost: 1 split per 12 (128 x 64 tile) resp. 24 (128 x 128) MFMAs.
+  constexpr int TM = 1, TNW = 2 * TN, BM = 128, BN = 64 * TN, BK = 16;
+  constexpr int A_BYTES = BM * BK * 4, B_BYTES = TN * 6144, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int NA = A_BYTES / 1024 / 4;                  // A pieces per wave and stage (2)
+  constexpr int NBT = B_BYTES / 1024;                     // B pieces per stage: 6 (waves 0-1 issue 2, waves 2-3 one) or 12 (3 each)
+  static_assert(NST * ST_BYTES >= 4 * 32 * STAGE_LD * 4, "epilogue staging must fit the ring");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NST * ST_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float* zero_page = vr_zero_page;
+  asm volatile("" : "+s"(zero_page));
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = blockIdx.x, jj = L >> 3;
+  const int nt = jj % NT, mt = (jj / NT) * 8 + (L & 7);
+  if (mt >= MT) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nsteps = p.CK / BK;
+  const int NBW = TN == 2 ? 3 : (wave < 2 ? 2 : 1);      // this wave's B pieces per stage (wave-uniform)
+
+  // ---- A loader roles (as igemm_dma_kernel with QPR = 4): slot (row, quad) of a 128 x 16 fp32 image, XOR-swizzled
+  const float* a_run[NA];
+  int a_inc[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int sl = (wave * NA + i) * 64 + lane, r = sl >> 2;
+    const int q = (sl & 3) ^ ((r >> 2) & 3);
+    const int m = m0 + r;
+    const bool ok = m < p.M;
+    a_run[i] = ok ? p.a + (long)m * p.lda + 4 * q : zero_page;
+    a_inc[i] = ok ? BK : 0;
+  }
+  const unsigned char* b_src = planes + ((long)(n0 >> 6)) * 6144 + (long)lane * 16;       // + kb * JB * 6144
+  const long b_step = (long)JB * 6144;
+  int ld_buf = 0;
+  // one DMA piece of the stage being issued: 0 .. NA - 1 = A, then this wave's B pieces
+  auto issue_piece = [&](int i) {
+    unsigned char* stage = smem + ld_buf * ST_BYTES;
+    if (i < NA) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_run[i],
+                                       (__attribute__((address_space(3))) void*)(stage + (wave * NA + i) * 1024), 16, 0, 0);
+      a_run[i] += a_inc[i];
+    } else if (i - NA < NBW) {
+      const int j = i - NA;
+      const int piece = TN == 2 ? wave * 3 + j : (wave < 2 ? wave * 2 + j : 2 + wave);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + piece * 1024),
+                                       (__attribute__((address_space(3))) void*)(stage + A_BYTES + piece * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_end = [&]() {
+    b_src += b_step;
+    if (++ld_buf == NST) ld_buf = 0;
+  };
+  constexpr int NPMAX = NA + (TN == 2 ? 3 : 2);
+  auto issue = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPMAX; ++i) issue_piece(i);
+    issue_end();
+  };
+
+  f32x16 acc[TM][TNW];
+#pragma unroll
+  for (int j = 0; j < TNW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+  const int h = lane >> 5;
+  const int ra = wave * 32 + (lane & 31);
+  const int a_off = ra * BK * 4, a_swz = (ra >> 2) & 3;
+  int b_off[TNW];
+#pragma unroll
+  for (int i = 0; i < TNW; ++i) {
+    const int rb = 32 * i + (lane & 31);
+    b_off[i] = ((rb >> 6) * 6 + h) * 1024 + (rb & 63) * 16;       // + plane * 2048
+  }
+
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < nsteps) issue();
+  int cur = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    if (NST >= 3 && nsteps - 1 - s >= 1) {       // one younger stage stays in flight
+      if (TN == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (wave < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool more = s + NST - 1 < nsteps;      // the next stage goes into the slot every wave finished reading before this barrier
+    const unsigned char* As = smem + cur * ST_BYTES;
+    const unsigned char* Bs = As + A_BYTES;
+    vr_bf16x8 a3[3], b3[TNW][3];
+#pragma unroll
+    for (int i = 0; i < TNW; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b3[i][pl] = *reinterpret_cast<const vr_bf16x8*>(Bs + b_off[i] + pl * 2048);
+    {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(As + a_off + 16 * ((2 * h) ^ a_swz));
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(As + a_off + 16 * ((2 * h + 1) ^ a_swz));
+      vr_split3(lo, hi, a3);
+    }
+    // each DMA instruction of the next stage goes behind a group of six MFMAs, whose execution hides its issue cost
+#pragma unroll
+    for (int jn = 0; jn < TNW; ++jn) {
+      acc[0][jn] = vr_mfma_x6(a3, b3[jn], acc[0][jn]);
+      if (more) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NPMAX; ++q)
+          if (q % TNW == jn) issue_piece(q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (more) issue_end();
+    if (++cur == NST) cur = 0;
+  }
+  __syncthreads();
+  igemm_epilogue<TM, TNW, 4, 1>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
+}
+
+// Multi-tensor weight split: one launch for every eligible weight of a step.  Table entry e (8 longs): source address,
+// columns J, contraction K, element strides (column, contraction), contraction-scale address or 0, destination address,
+// first block.  Block = (entry, k16 step, 64-column block); thread = (lane half, column): 8 values -> 3 x 8 bf16.
+__global__ __launch_bounds__(128) void planes_pack_kernel(const long* table, int nentries) {
+  int e = 0;
+  {   // the entry this block belongs to: first-block offsets ascend
+    int lo = 0, hi = nentries - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (table[8 * mid + 7] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    e = lo;
+  }
+  const long* t = table + 8 * e;
+  const float* src = reinterpret_cast<const float*>(t[0]);
+  const int J = (int)t[1], K = (int)t[2];
+  const long sj = t[3], sk = t[4];
+  const float* ksc = reinterpret_cast<const float*>(t[5]);
+  unsigned short* dst = reinterpret_cast<unsigned short*>(t[6]);
+  const int JB = ((J + 127) >> 7) << 1;       // 64-column blocks, padded to whole 128-column tiles
+  const int blk = blockIdx.x - (int)t[7];
+  const int kb = blk / JB, jb = blk - kb * JB;
+  const int hh = threadIdx.x >> 6, col = threadIdx.x & 63;
+  const int j = jb * 64 + col;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = kb * 16 + 8 * hh + i;
+    float x = (j < J && k < K) ? src[(long)j * sj + (long)k * sk] : 0.f;
+    if (ksc && k < K) x *= ksc[k];
+    v[i] = x;
+  }
+  unsigned short* d = dst + ((long)(kb * JB + jb) * 6144 + hh * 1024 + col * 16) / 2;      // plane stride 2048 B
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 p0 = (__bf16)v[i];
+    const float r1 = v[i] - (float)p0;
+    const __bf16 p1 = (__bf16)r1;
+    const float r2 = r1 - (float)p1;
+    const __bf16 p2 = (__bf16)r2;
+    d[i] = __builtin_bit_cast(unsigned short, p0);
+    d[1024 + i] = __builtin_bit_cast(unsigned short, p1);
+    d[2048 + i] = __builtin_bit_cast(unsigned short, p2);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Weight gradient: dW[t][n][c] = sum_m dy[m, n] * x[src(m, t), c], contraction over output pixels,
 // split over `S` row ranges into fp32 slabs (deterministic; reduced by wgrad_reduce_kernel).
@@ -1249,8 +1432,8 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                                 long ldres, const float* res_scale, const float* kscale, const float* aux,
                                 long ldaux, int out_nchw, int out_ctot, int out_coff, int accumulate,
                                 double* stats, int precision, int pair_rows, const float* w2, const float* bias2,
-                                const float* res_scale2, const float* kscale2, const vrnet_conv_colstats* colstats,
-                                void* stream) {
+                                const float* res_scale2, const float* kscale2, const void* w_planes,
+                                const vrnet_conv_colstats* colstats, void* stream) {
   VR_CHECK_ARG(a && w && y, "conv2d: null tensor");
   if (vr_ablated("igemm")) return VR_OK;
   {   // finer timing ablations by output-row class (diagnostic): stage-0/1 maps, stage-2 maps, neck / head maps
@@ -1417,6 +1600,30 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
       else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 2, 1, PR>), grid, block, 0, st, p, (int)mt, (int)nt21);           \
     }                                                                                                                   \
   } while (0)
+    if (tile && precision == 2 && w_planes && kh == 1 && kw == 1 && stride == 1 && pad == 0 && !pair_rows && p.CK % 16 == 0 &&
+        vr_tune("VRNET_X6_PLANES", 1)) {
+      // pre-split weights (vrnet_conv_planes_pack_f32; in mode 1 the pack holds the transposed weights with kscale folded in)
+      IgemmArgs q = p;
+      q.kscale = nullptr;
+      const int JB = (int)(((p.CN + 127) >> 7) << 1);
+      if (tile == 22) {
+        dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt22));
+        // 128 x 128 tile: two stages (40 KB, 3 workgroups per CU) measured 0.2 ms per step ahead of three (60 KB, 2 per CU)
+        if (vr_tune("VRNET_PLANES_NST2", 1))
+          hipLaunchKernelGGL((igemm_planes_kernel<2, 2>), grid, block, 0, st, q, reinterpret_cast<const unsigned char*>(w_planes), JB,
+                             (int)mt, (int)nt22);
+        else
+          hipLaunchKernelGGL((igemm_planes_kernel<2, 3>), grid, block, 0, st, q, reinterpret_cast<const unsigned char*>(w_planes), JB,
+                             (int)mt, (int)nt22);
+      } else {
+        dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt21));
+        hipLaunchKernelGGL((igemm_planes_kernel<1, 3>), grid, block, 0, st, q, reinterpret_cast<const unsigned char*>(w_planes), JB,
+                           (int)mt, (int)nt21);
+      }
+      vr_note_kernel(9);
+      VR_LAUNCH_CHECK("conv2d(x6, pre-split weights)");
+      return VR_OK;
+    }
     if (tile) {
       if (precision == 2) VR_TILE_LAUNCH(6);
       else VR_TILE_LAUNCH(1);
@@ -1708,6 +1915,20 @@ extern "C" int vrnet_conv2d_wgrad_f32(const float* x, long ldx, const float* dy,
   VR_LAUNCH_CHECK("conv2d_wgrad");
   return wgrad_reduce_launch(p.slab, p.bslab, ls_part, ls_stride, S, T, Cout, Cin, streams, row_scale, dw, dbias, accumulate,
                              row_scale2, dw2, dbias2, w, w2, bias, bias2, dls, dls2, st);
+}
+
+/* Size in bytes of the bf16 planes of a [J columns] x [K contraction] weight (K % 16 == 0). */
+extern "C" long vrnet_conv_planes_bytes(int J, int K) { return (long)(K / 16) * (((J + 127) >> 7) << 1) * 6144; }
+
+/* One launch that splits every weight of `table` (device array, 8 longs per entry: source address, J, K, element stride
+ * between columns, element stride along the contraction, address of a per-contraction-index scale or 0, destination
+ * address, index of the entry's first block; an entry has (K / 16) * 2 * ceil(J / 128) blocks) into three bf16 planes in the
+ * stage-image order of igemm_planes_kernel.  total_blocks = sum of the entries' blocks. */
+extern "C" int vrnet_conv_planes_pack_f32(const long* table, int nentries, long total_blocks, void* stream) {
+  VR_CHECK_ARG(table && nentries > 0 && total_blocks > 0 && total_blocks < (1L << 31), "conv_planes_pack: bad table");
+  hipLaunchKernelGGL(planes_pack_kernel, dim3((unsigned)total_blocks), dim3(128), 0, vr_stream(stream), table, nentries);
+  VR_LAUNCH_CHECK("conv_planes_pack");
+  return VR_OK;
 }
 
 extern "C" int vrnet_pack_weight_f32(const float* w_oihw, float* w_tnc, int Cout, int Cin, int kh, int kw,

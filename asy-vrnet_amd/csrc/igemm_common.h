@@ -242,10 +242,14 @@ __device__ __forceinline__ void igemm_epilogue_scalar(const IgemmArgs& p, const 
 // still be reading operand images from it (callers end their main loop with a barrier).
 template <int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0) {
-  static_assert(TM <= 2 && TN <= 2, "accumulator tiles are named explicitly");
+  static_assert((TM <= 2 && TN <= 2) || (TM == 1 && TN == 4), "accumulator tiles are named explicitly");
   if (p.e_vec) {
     igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[0][0], smem, m0, n0, 0, 0);
     if constexpr (TN > 1) igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[0][1], smem, m0, n0, 0, 1);
+    if constexpr (TN > 2) {
+      igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[0][2], smem, m0, n0, 0, 2);
+      igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[0][3], smem, m0, n0, 0, 3);
+    }
     if constexpr (TM > 1) {
       igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[1][0], smem, m0, n0, 1, 0);
       if constexpr (TN > 1) igemm_epilogue_vec<TM, TN, WM, WN>(p, acc[1][1], smem, m0, n0, 1, 1);
@@ -254,6 +258,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
   }
   igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[0][0], m0, n0, 0, 0);
   if constexpr (TN > 1) igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[0][1], m0, n0, 0, 1);
+  if constexpr (TN > 2) {
+    igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[0][2], m0, n0, 0, 2);
+    igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[0][3], m0, n0, 0, 3);
+  }
   if constexpr (TM > 1) {
     igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[1][0], m0, n0, 1, 0);
     if constexpr (TN > 1) igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[1][1], m0, n0, 1, 1);

@@ -28,7 +28,9 @@ _SIGS = {
     "vrnet_tuning_build": ([], I),
     "vrnet_kernel_launches": ([I], L),
     "vrnet_device_arch": ([ctypes.c_char_p, I], I),
-    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P, P], I),
+    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P, P, P], I),
+    "vrnet_conv_planes_bytes": ([I, I], L),
+    "vrnet_conv_planes_pack_f32": ([P, I, L, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
     "vrnet_conv2d_dma_tile": ([L, I], I),
     "vrnet_conv2d_wgrad_workspace": ([I] * 8, L),
@@ -184,7 +186,7 @@ _ws = Workspace()
 def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, mode=0, act=0,
            ypre=None, ldypre=0, res=None, ldres=0, res_scale=None, kscale=None, aux=None, ldaux=0,
            out_nchw=0, out_ctot=0, out_coff=0, accumulate=0, stats=None, precision=0, pair_rows=0, w2=None, bias2=None,
-           res_scale2=None, kscale2=None, colstats=None):
+           res_scale2=None, kscale2=None, colstats=None, w_planes=None):
     """pair_rows > 0: two-stream launch, GEMM rows >= pair_rows use (w2, bias2, res_scale2, kscale2).
     colstats = (partial, x2, ldx2, gamma, tile_totals) (None entries allowed): column statistics of the stored outputs."""
     cs = None
@@ -194,8 +196,17 @@ def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, 
     _check(_lib.vrnet_conv2d_f32(ptr(a), lda, ptr(w), ptr(bias), ptr(y), ldy, B, H, W, Cin, OH, OW, Cout, kh, kw,
                                  stride, pad, dil, mode, act, ptr(ypre), ldypre, ptr(res), ldres, ptr(res_scale),
                                  ptr(kscale), ptr(aux), ldaux, out_nchw, out_ctot, out_coff, accumulate, ptr(stats),
-                                 precision, pair_rows, ptr(w2), ptr(bias2), ptr(res_scale2), ptr(kscale2), cs, stream()),
+                                 precision, pair_rows, ptr(w2), ptr(bias2), ptr(res_scale2), ptr(kscale2), ptr(w_planes), cs, stream()),
            "conv2d")
+
+
+def conv_planes_bytes(J, K):
+    return _lib.vrnet_conv_planes_bytes(J, K)
+
+
+def conv_planes_pack(table, nentries, total_blocks):
+    """table: int64 device tensor, 8 values per entry (vrnet_conv_planes_pack_f32)."""
+    _check(_lib.vrnet_conv_planes_pack_f32(ptr(table), nentries, total_blocks, stream()), "conv_planes_pack")
 
 
 def bf16_conv_ok(lda, Cin, Cout, mode):

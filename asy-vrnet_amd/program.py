@@ -82,6 +82,7 @@ class RT:
         self.bf16 = False           # dense convs with bf16-rounded operands on the bf16 MFMA (model.compute_dtype)
         self.fp32_precision = 2     # fp32 layers: 2 = six-bf16-product kernels where available, 0 = fp32 MFMA only
         self.fused_mlp = True       # Mlp of a ClusterBlock as one kernel per direction where the library has one
+        self.wplanes = None         # WeightPlanes: pre-split weights for the x6 kernels (model.weight_planes, default on)
         self.bn_colstats = True     # BatchNorm batch statistics from the producing conv's epilogue (no pass over z)
         self.gn_colstats = False    # GroupNorm backward moments from the producing data-gradient conv's epilogue (built and
                                     # tested; same-box A/B: 29.16 -> 29.16 ms with it, 29.01 without: the epilogue work it adds to
@@ -307,6 +308,14 @@ class RT:
             return 1
         return 2 if self.fp32_precision == 2 else 0
 
+    def planes(self, w, mode, J, K, rows, kscale=None):
+        """bf16 planes of a 1x1 weight for a launch of `rows` GEMM rows and J columns (None: the launch does not run on
+        an x6 tile kernel, or the planes are switched off).  mode 0: w is [J = Cout][K = Cin]; mode 1: [K = Cout][J = Cin]."""
+        if self.wplanes is None or self.bf16 or self.fp32_precision != 2 or K % 16 or not hip.conv2d_dma_tile(rows, J):
+            return None
+        sj, sk = (K, 1) if mode == 0 else (1, J)
+        return self.wplanes.get((id(w), mode), w, J, K, sj, sk, kscale)
+
     def prec_wgrad(self, ldx, lddy, ci, co):
         if self.bf16 and hip.bf16_wgrad_ok(ldx, lddy, ci, co):
             return 1
@@ -462,6 +471,8 @@ def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw
         if c1 is not None:
             kw2 = _pair_kw(rt, x, conv, rt.weight, bias, res_scale)
             kw2["pair_rows"] = (x.B // 2) * OH * OW
+        if c1 is None and kh == 1 and kw == 1 and s == 1 and p == 0:
+            kw2["w_planes"] = rt.planes(c0.weight, 0, co, ci, x.B * OH * OW)
         hip.conv2d(x.t, x.ld, rt.weight(c0), b, out.t, out.ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
                    mode=0, act=act, ypre=None if ypre is None else ypre.t, ldypre=0 if ypre is None else ypre.ld,
                    res=None if res is None else res.t, ldres=0 if res is None else res.ld,
@@ -543,6 +554,8 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
             kw2 = dict(pair_rows=(x.B // 2) * x.H * x.W, w2=wd1, kscale2=ks1)
         if colstats is not None:
             kw2["colstats"] = colstats
+        if c1 is None and kh == 1 and kw == 1 and s == 1 and p == 0 and prec == 2:
+            kw2["w_planes"] = rt.planes(c0.weight, 1, ci, co, x.B * x.H * x.W, kscale=ks)
         hip.conv2d(dy, lddy, wd, None, buf, ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=1,
                    kscale=ks, aux=None if aux is None else aux.t, ldaux=0 if aux is None else aux.ld, accumulate=acc,
                    precision=prec, **kw2)
@@ -762,6 +775,8 @@ def cluster_block(rt, x, m, name=None):
     wcat, bcat = tm0._fused_qkv                                  # [fc1 ; fc_v]: one GEMM, f | v side by side
     kwq = dict(pair_rows=rows_half, w2=tm1._fused_qkv[0], bias2=tm1._fused_qkv[1]) if paired else {}
     fv = rt.new(B, H, W, 2 * ED)
+    if not paired:
+        kwq["w_planes"] = rt.planes(wcat, 0, 2 * ED, C, B * H * W)
     hip.conv2d(xn.t, xn.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0,
                precision=rt.prec_fwd(xn.ld, C, 2 * ED), **kwq)
     f_t, v_t = fv.t, fv.t[..., ED:]
@@ -851,6 +866,8 @@ def cluster_block(rt, x, m, name=None):
         cs1 = None if paired else gn_colstats(rt, m0.norm1, x)
         if cs1 is not None:
             kwd["colstats"] = cs1
+        if not paired and prec == 2:
+            kwd["w_planes"] = rt.planes(wcat, 1, C, 2 * ED, B * H * W)
         hip.conv2d(dfv.t, 2 * ED, wd, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1, precision=prec, **kwd)
         dx = rt.buf(B, H, W, C)
         gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx, add=dx1, partials=cs1)     # dx = dx1 + d(GN -> Cluster branch)
@@ -1316,6 +1333,49 @@ def head_forward(rt, hd, feats, det_outs):
     rt.parallel([(lambda k=k, x=x: level(k, x)) for k, x in enumerate(feats)], site=5)
 
 
+class WeightPlanes:
+    """Pre-split weights for the x6 kernels (hip.conv2d `w_planes`): the six-product scheme spends its VALU time on
+    splitting fragments into bf16 planes, and a weight tile is the same for every row tile of a step -- so every 1x1 weight
+    whose launch runs on an x6 tile kernel is split ONCE per forward, all of them in ONE launch (hip.conv_planes_pack), into
+    the kernel's LDS stage image.  Derived caches like FusedQKV: the first forward that needs a pack builds it on the spot
+    and registers it; from then on `refresh()` re-splits the whole table at the start of every forward (the parameters may
+    have been updated in place)."""
+
+    def __init__(self, model, device):
+        self.owner, self.device = id(model), device
+        self.entries = {}          # key -> [source tensor, J, K, sj, sk, kscale tensor or None, planes buffer]
+        self.table, self.nblocks, self.dirty = None, 0, False
+
+    def get(self, key, w, J, K, sj, sk, kscale):
+        ent = self.entries.get(key)
+        ids = (w.data_ptr(), None if kscale is None else kscale.data_ptr())
+        if ent is not None and ent[7] == ids:
+            return ent[6]
+        buf = torch.empty((hip.conv_planes_bytes(J, K),), dtype=torch.uint8, device=self.device)
+        ent = [w, J, K, sj, sk, kscale, buf, ids]
+        self.entries[key] = ent
+        self.dirty = True
+        tab, nb = self._table([ent])
+        hip.conv_planes_pack(tab, 1, nb)          # first use: split now (later forwards: refresh())
+        return buf
+
+    def _table(self, ents):
+        rows, first = [], 0
+        for w, J, K, sj, sk, kscale, buf, _ in ents:
+            rows += [w.data_ptr(), J, K, sj, sk, 0 if kscale is None else kscale.data_ptr(), buf.data_ptr(), first]
+            first += (K // 16) * 2 * ((J + 127) // 128)
+        return torch.tensor(rows, dtype=torch.int64, device=self.device), first
+
+    def refresh(self):
+        if not self.entries:
+            return
+        if self.dirty:
+            self.ents = list(self.entries.values())
+            self.table, self.nblocks = self._table(self.ents)
+            self.dirty = False
+        hip.conv_planes_pack(self.table, len(self.ents), self.nblocks)
+
+
 class FusedQKV:
     """Concatenated [fc1 ; fc_v] weights and biases of every Cluster module (vr_coc.py:145-147): both 1x1 convs read
     the same normalised input, so each block runs them as ONE GEMM with 2*E*D output channels (twice the tiles of the
@@ -1405,6 +1465,12 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         if fq is None or fq.owner != id(model) or fq.dst[0].device != x.device:
             fq = model._fused_qkv = FusedQKV(model, x.device)
         fq.refresh()
+        if getattr(model, "weight_planes", True) and not rt.bf16 and rt.fp32_precision == 2:
+            wp = getattr(model, "_weight_planes", None)
+            if wp is None or wp.owner != id(model) or wp.device != x.device:
+                wp = model._weight_planes = WeightPlanes(model, x.device)
+            wp.refresh()                       # after fq.refresh(): the concatenated fc1 | fc_v weights are sources too
+            rt.wplanes = wp
         xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=need_dx)
         ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=need_dr)
         hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)

@@ -34,11 +34,12 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense bf16 MFMA (no sp
 X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # fp32-equivalent FLOP/s of the x6 kernels: six bf16 MFMAs per fp32 product block
 # matrix-pipe ceiling per kernel family (hip.last_kernel()): fp32-equivalent TFLOP/s
 FAMILY_PEAK = {1: FP32_MFMA_PEAK_TFLOPS, 2: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS, 4: None, 5: None, 6: X6_PEAK_TFLOPS,
-               7: X6_PEAK_TFLOPS, 8: BF16_MFMA_PEAK_TFLOPS}
+               7: X6_PEAK_TFLOPS, 8: BF16_MFMA_PEAK_TFLOPS, 9: X6_PEAK_TFLOPS}
 FAMILY_NAME = {1: "fp32 MFMA, register-staged", 2: "fp32 MFMA, LDS-DMA ring", 3: "bf16-rounded operands",
                4: "direct (tiny channel counts, no MFMA)", 5: "direct (narrow outputs over wide inputs, HBM streams, no MFMA)", 6: "x6: six exact bf16 x bf16 products per fp32 product",
                7: "fused Mlp (fc1 -> GELU -> fc2 in one kernel), x6, weights pre-split into bf16 planes",
-               8: "fused Mlp, bf16-rounded operands"}
+               8: "fused Mlp, bf16-rounded operands",
+               9: "x6 with weights pre-split into bf16 planes once per step (1x1 convs)"}
 
 
 def kernel_source_hash():
@@ -306,6 +307,7 @@ def main():
                          "instead of two chains on two forked streams")
     ap.add_argument("--no-pair", action="store_true", help="(default) two chains on two forked streams")
     ap.add_argument("--no-fused-mlp", action="store_true", help="Mlp as two conv launches (A/B aid)")
+    ap.add_argument("--no-weight-planes", action="store_true", help="x6 kernels split the weights themselves (A/B aid)")
     ap.add_argument("--no-bn-colstats", action="store_true", help="BatchNorm statistics by a pass over z (A/B aid)")
     ap.add_argument("--gn-colstats", action="store_true", help="GroupNorm backward moments from the data-gradient conv's epilogue (A/B aid; off by default)")
     ap.add_argument("--diagnostic", action="store_true",
@@ -358,6 +360,7 @@ def main():
         model.concurrent = False
     model.pair_streams = bool(args.pair)
     model.fused_mlp = not args.no_fused_mlp
+    model.weight_planes = not args.no_weight_planes
     model.bn_colstats = not args.no_bn_colstats
     model.gn_colstats = bool(args.gn_colstats)
     net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model

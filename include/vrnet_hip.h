@@ -27,6 +27,7 @@ int vrnet_abi_version(void);                 /* == 4 */
  * (register-staged), 2 fp32 MFMA (LDS-DMA ring), 3 bf16-rounded operands, 4 direct kernels for tiny channel counts,
  * 5 direct HBM-streaming kernels for 1x1 convs with <= 16 output channels over wide inputs (head predictions, seg logits),
  * 6 "x6": every fp32 product as six exact bf16 x bf16 products on the bf16 MFMA, fp32 accumulate;
+ * 9: x6 with pre-split weights (vrnet_conv2d_f32 `w_planes`);
  * 7 / 8: the fused Mlp kernels (vrnet_mlp_fwd_f32 / vrnet_mlp_bwd_f32) at precision 2 (x6) / 1 (bf16-rounded operands). */
 int vrnet_last_kernel(void);
 /* Launches of kernel family `family` (same codes) issued by the calling thread since the library was loaded. */
@@ -91,7 +92,17 @@ int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias
                      const float* res_scale, const float* kscale, const float* aux, long ldaux, int out_nchw,
                      int out_ctot, int out_coff, int accumulate, double* stats, int precision, int pair_rows,
                      const float* w2, const float* bias2, const float* res_scale2, const float* kscale2,
-                     const vrnet_conv_colstats* colstats, void* stream);
+                     const void* w_planes, const vrnet_conv_colstats* colstats, void* stream);
+/* Pre-split weights for the x6 kernels (precision 2, 1x1 convs, contraction % 16 == 0): the six-product scheme spends its
+ * VALU time on splitting fragments into bf16 planes; weights are the same for every row tile of a step, so they can be
+ * split ONCE per step.  vrnet_conv_planes_pack_f32 does that for a whole table of weights in one launch (round-to-nearest-
+ * even: w = p0 + p1 + p2 exactly), writing each as the LDS stage image of the kernel ([k16 step][64-column block][plane]
+ * [lane half][64 columns] x 8 bf16); `w_planes` of vrnet_conv2d_f32 passes one such pack (NULL = split in the kernel).
+ * mode 0: columns J = Cout, contraction K = Cin (source strides Cin, 1 for an OIHW 1x1 weight); mode 1: J = Cin, K = Cout
+ * (strides 1, Cin) with kscale folded in through the table's scale address (the kscale argument is then ignored).
+ * `w` is still required: shapes without a tile kernel (vrnet_conv2d_dma_tile == 0) use it.  Kernel family 9. */
+long vrnet_conv_planes_bytes(int J, int K);
+int vrnet_conv_planes_pack_f32(const long* table, int nentries, long total_blocks, void* stream);
 
 /* Weight (+ bias) gradient of the same convolutions (autograd of nn.Conv2d): dw in OIHW layout
  * [Cout][Cin][kh][kw], dbias[Cout] (NULL = none), both scaled by row_scale[Cout] when given (layer scale).

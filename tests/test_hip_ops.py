@@ -1308,3 +1308,46 @@ def test_conv_column_statistics(hip, case):
         outs.append((o, dg, db))
     for a, b_, nm in zip(outs[1], outs[0], ("dx", "dgamma", "dbeta")):
         close(a, b_, 1e-5, what="gn backward from partials: " + nm)
+
+
+def _planes(hip, w2d, J, K, sj, sk, kscale=None):
+    """bf16 planes of one weight through the multi-tensor pack entry point (a one-entry table)."""
+    buf = torch.empty((hip.conv_planes_bytes(J, K),), dtype=torch.uint8, device="cuda")
+    nb = (K // 16) * 2 * ((J + 127) // 128)
+    tab = torch.tensor([w2d.data_ptr(), J, K, sj, sk, 0 if kscale is None else kscale.data_ptr(), buf.data_ptr(), 0], dtype=torch.int64,
+                       device="cuda")
+    hip.conv_planes_pack(tab, 1, nb)
+    return buf
+
+
+@pytest.mark.parametrize("case", [(2, 128, 128, 64, 128), (2, 128, 128, 64, 512), (2, 128, 128, 512, 64), (8, 32, 32, 320, 1280),
+                                  (8, 32, 32, 1280, 320), (4, 64, 64, 128, 96), (8, 64, 64, 256, 192), (2, 128, 128, 80, 64)])
+def test_x6_conv_with_presplit_weights(hip, case):
+    """precision 2 with `w_planes` (weights split once into bf16 planes by vrnet_conv_planes_pack_f32, kernel family 9):
+    forward with the full epilogue and data gradient with the layer scale folded into the pack, against fp64 ATen."""
+    B, H, W, Ci, Co = case
+    t = _conv_suite_inputs((B, H, W, Ci, Co, 1, 1, 0, 1))
+    x, w, b, ls, res = nhwc(t["x"]), t["w"].cuda().contiguous(), t["b"].cuda(), t["ls"].cuda(), nhwc(t["res"])
+    pf = _planes(hip, w, Co, Ci, Ci, 1)
+    y, ypre = torch.empty(B, H, W, Co, device="cuda"), torch.empty(B, H, W, Co, device="cuda")
+    st, per = hip.conv_stats_buffer(B, H * W, Co, x.device)
+    hip.conv2d(x, Ci, w, b, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, act=2, ypre=ypre, ldypre=Co, res=res, ldres=Co, res_scale=ls,
+               stats=st, precision=2, w_planes=pf)
+    fam_f = hip.last_kernel()
+    D = lambda a: a.double()
+    z = F.conv2d(D(t["x"]), D(t["w"]), D(t["b"]))
+    close(nchw(ypre), z, 2e-5, what="ypre")
+    close(nchw(y), D(t["res"]) + D(t["ls"])[None, :, None, None] * F.gelu(z), 2e-5, what="y")
+    yd = y.double().cpu()
+    close(st.view(B, -1, 2).sum(1), torch.stack([yd.sum((1, 2, 3)), (yd * yd).sum((1, 2, 3))], 1), 1e-9, what="statistics of the stored outputs")
+    # data gradient: the pack holds w^T with the contraction scale folded in
+    pb = _planes(hip, w, Ci, Co, 1, Ci, kscale=ls)
+    g, aux, dx = nhwc(t["g"]), nhwc(t["aux"]), nhwc(t["dx0"])
+    hip.conv2d(g, Co, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, kscale=ls, aux=aux, ldaux=Ci, accumulate=1, precision=2,
+               w_planes=pb)
+    fam_d = hip.last_kernel()
+    a = D(t["aux"])
+    gp = 0.5 * (1 + torch.erf(a / np.sqrt(2.0))) + a * torch.exp(-0.5 * a * a) / np.sqrt(2 * np.pi)
+    ref = D(t["dx0"]) + F.conv_transpose2d(D(t["g"]) * D(t["ls"])[None, :, None, None], D(t["w"])) * gp
+    close(nchw(dx), ref, 2e-5, what="dx")
+    assert 9 in (fam_f, fam_d), (fam_f, fam_d)        # at least one of the two launches had a tile kernel and used the planes
