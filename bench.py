@@ -74,7 +74,8 @@ def pmc_traffic_bytes(phi):
         return None
     n, tot = 0, 0.0
     for row in csv.DictReader(open(files[-1])):
-        if row["kernel"].startswith(("igemm_kernel", "igemm_dma_kernel", "mlp_fused_kernel")):
+        if row["kernel"].startswith(("igemm_kernel", "igemm_dma_kernel", "igemm_planes_kernel", "mlp_fused_kernel", "tiny::conv_kernel",
+                                     "narrow::fwd_kernel", "narrow::dgrad_kernel")):
             k = int(row["launches"])
             n += k
             tot += k * float(row["avg_HBM_MB"]) * 1024 * 1024

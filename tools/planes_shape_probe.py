@@ -1,0 +1,48 @@
+"""Times single conv launches (forward / data gradient, with and without pre-split weights) at given shapes, back to back in a
+loop so that host latency does not enter.   usage: python tools/planes_shape_probe.py B H W Cin Cout [B H W Cin Cout ...]"""
+import importlib, sys, torch
+sys.path.insert(0, ".")
+hip = importlib.import_module("asy-vrnet_amd.hip")
+
+
+def planes(w2d, J, K, sj, sk, kscale=None):
+    buf = torch.empty((hip.conv_planes_bytes(J, K),), dtype=torch.uint8, device="cuda")
+    nb = (K // 16) * 2 * ((J + 127) // 128)
+    tab = torch.tensor([w2d.data_ptr(), J, K, sj, sk, 0 if kscale is None else kscale.data_ptr(), buf.data_ptr(), 0], dtype=torch.int64, device="cuda")
+    hip.conv_planes_pack(tab, 1, nb)
+    return buf
+
+
+def timeit(fn, n=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+a = [int(v) for v in sys.argv[1:]]
+for i in range(0, len(a), 5):
+    B, H, W, Ci, Co = a[i:i + 5]
+    M = B * H * W
+    x, g = torch.randn(M, Ci, device="cuda"), torch.randn(M, Co, device="cuda")
+    w, ls = torch.randn(Co, Ci, device="cuda") * 0.05, torch.randn(Co, device="cuda")
+    y, dx, aux = torch.empty(M, Co, device="cuda"), torch.empty(M, Ci, device="cuda"), torch.randn(M, Ci, device="cuda")
+    pf, pb = planes(w, Co, Ci, Ci, 1), planes(w, Ci, Co, 1, Ci)
+    fl = 2.0 * M * Ci * Co
+    for name, fn in (
+        ("fwd  fp32", lambda: hip.conv2d(x, Ci, w, None, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=0)),
+        ("fwd  x6", lambda: hip.conv2d(x, Ci, w, None, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=2)),
+        ("fwd  x6 planes", lambda: hip.conv2d(x, Ci, w, None, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=2, w_planes=pf)),
+        ("dgrad fp32", lambda: hip.conv2d(g, Co, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, precision=0)),
+        ("dgrad x6", lambda: hip.conv2d(g, Co, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, precision=2)),
+        ("dgrad x6 planes", lambda: hip.conv2d(g, Co, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, precision=2, w_planes=pb)),
+        ("dgrad x6 planes gelu'", lambda: hip.conv2d(g, Co, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, aux=aux, ldaux=Ci, precision=2, w_planes=pb)),
+    ):
+        us = timeit(fn)
+        print(f"M{M} Cin{Ci} Cout{Co} {name:22s} k{hip.last_kernel()} {us:8.1f} us {fl / us * 1e-6:7.1f} TFLOP/s", flush=True)
