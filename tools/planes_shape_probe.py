@@ -1,5 +1,5 @@
 """Times single conv launches (forward / data gradient, with and without pre-split weights) at given shapes, back to back in a
-loop so that host latency does not enter.   usage: python tools/planes_shape_probe.py B H W Cin Cout [B H W Cin Cout ...]"""
+loop so that host latency does not enter.   usage: python tools/planes_shape_probe.py [--only "fwd  x6 planes"] B H W Cin Cout [B H W Cin Cout ...]"""
 import importlib, sys, torch
 sys.path.insert(0, ".")
 hip = importlib.import_module("asy-vrnet_amd.hip")
@@ -26,7 +26,11 @@ def timeit(fn, n=50):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-a = [int(v) for v in sys.argv[1:]]
+only = None
+argv = sys.argv[1:]
+if argv and argv[0] == "--only":      # --only "<substring of the row name>"
+    only, argv = argv[1], argv[2:]
+a = [int(v) for v in argv]
 for i in range(0, len(a), 5):
     B, H, W, Ci, Co = a[i:i + 5]
     M = B * H * W
@@ -44,5 +48,7 @@ for i in range(0, len(a), 5):
         ("dgrad x6 planes", lambda: hip.conv2d(g, Co, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, precision=2, w_planes=pb)),
         ("dgrad x6 planes gelu'", lambda: hip.conv2d(g, Co, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, aux=aux, ldaux=Ci, precision=2, w_planes=pb)),
     ):
+        if only and only not in name:
+            continue
         us = timeit(fn)
         print(f"M{M} Cin{Ci} Cout{Co} {name:22s} k{hip.last_kernel()} {us:8.1f} us {fl / us * 1e-6:7.1f} TFLOP/s", flush=True)
