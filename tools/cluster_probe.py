@@ -1,39 +1,38 @@
-"""Diagnostic: Cluster core forward / backward launch time and HBM rate at the four stage shapes of phi-l (bs 8).
-    python tools/cluster_probe.py"""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from asy_vrnet_amd import hip
-
-SHAPES = [(8, 128, 128, 4, 32, 8), (8, 64, 64, 4, 32, 4), (8, 32, 32, 8, 32, 2), (8, 16, 16, 8, 32, 1)]   # B H W E D fold
+"""Times the Cluster kernels alone at the benchmark's shapes (phi = l, bs 8, 512 px): us per launch and TB/s on the
+algorithmic bytes (3 P E D 4 forward, 5 P E D 4 backward).   usage: python tools/cluster_probe.py"""
+import importlib, sys, torch
+sys.path.insert(0, ".")
+hip = importlib.import_module("asy-vrnet_amd.hip")
 
 
-def timeit(fn, reps=30):
-    for _ in range(3):
+def timeit(fn, n=50):
+    for _ in range(5):
         fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
+    for _ in range(n):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
+    return e0.elapsed_time(e1) / n * 1e3
 
 
-for B, H, W, E, D, fold in SHAPES:
-    g = torch.Generator(device="cuda").manual_seed(0)
-    ld = 2 * E * D
-    fv = torch.randn(B, H, W, ld, device="cuda", generator=g)
-    f, v = fv[..., :E * D], fv[..., E * D:]
-    out = torch.empty(B, H, W, E * D, device="cuda")
+tf = tb = 0.0
+# (B, H, W, E, D, fold, launches per step)
+for B, H, W, E, D, fold, cnt in ((8, 128, 128, 4, 32, 8, 4), (8, 64, 64, 4, 32, 4, 4), (8, 32, 32, 8, 32, 2, 12), (8, 16, 16, 8, 32, 1, 4),
+                                 (8, 64, 64, 4, 24, 2, 1), (8, 32, 32, 4, 24, 2, 1), (8, 16, 16, 4, 24, 2, 1)):
+    C = E * D
+    f, v, g = (torch.randn(B, H, W, C, device="cuda") for _ in range(3))
+    out, df, dv = (torch.empty(B, H, W, C, device="cuda") for _ in range(3))
     idx = torch.empty(B, H, W, E, dtype=torch.uint8, device="cuda")
     wgt = torch.empty(B, H, W, E, device="cuda")
-    al, be = torch.ones(1, device="cuda"), torch.zeros(1, device="cuda")
-    dout = torch.randn(B, H, W, E * D, device="cuda", generator=g)
-    dfv = torch.empty_like(fv)
-    da, db = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
-    tf = timeit(lambda: hip.cluster_fwd(f, v, ld, al, be, out, E * D, idx, wgt, B, H, W, E, D, fold))
-    tb = timeit(lambda: hip.cluster_bwd(f, v, ld, al, be, idx, dout, E * D, dfv[..., :E * D], dfv[..., E * D:], ld, da, db, 0,
-                                        B, H, W, E, D, fold))
-    pts = B * H * W * E * D * 4
-    print(f"B{B} {H}x{W} E{E} D{D} fold{fold}: fwd {tf:7.1f} us {3 * pts / tf / 1e6:6.2f} TB/s | bwd {tb:7.1f} us {5 * pts / tb / 1e6:6.2f} TB/s")
+    al, be = torch.tensor([1.3], device="cuda"), torch.tensor([-0.2], device="cuda")
+    dab = torch.zeros(2, device="cuda")
+    fw = timeit(lambda: hip.cluster_fwd(f, v, C, al, be, out, C, idx, wgt, B, H, W, E, D, fold))
+    bw = timeit(lambda: hip.cluster_bwd(f, v, C, al, be, idx, g, C, df, dv, C, dab[0:1], dab[1:2], 0, B, H, W, E, D, fold))
+    byt = B * H * W * C * 4
+    print(f"{H}x{W} E{E} D{D} fold{fold} x{cnt}: fwd {fw:7.1f} us {3 * byt / fw * 1e-6:6.2f} TB/s   bwd (+ab reduce) {bw:7.1f} us {5 * byt / bw * 1e-6:6.2f} TB/s", flush=True)
+    tf += cnt * fw
+    tb += cnt * bw
+print(f"per step: forward {tf * 1e-3:.3f} ms, backward {tb * 1e-3:.3f} ms")
