@@ -1,6 +1,6 @@
 """Times single conv launches (forward / data gradient, with and without pre-split weights) at given shapes, back to back in a
 loop so that host latency does not enter.   usage: python tools/planes_shape_probe.py [--only "fwd  x6 planes"] B H W Cin Cout [B H W Cin Cout ...]"""
-import importlib, sys, torch
+import importlib, os, sys, torch
 sys.path.insert(0, ".")
 hip = importlib.import_module("asy-vrnet_amd.hip")
 
@@ -34,19 +34,20 @@ a = [int(v) for v in argv]
 for i in range(0, len(a), 5):
     B, H, W, Ci, Co = a[i:i + 5]
     M = B * H * W
-    x, g = torch.randn(M, Ci, device="cuda"), torch.randn(M, Co, device="cuda")
+    pad = int(os.environ.get("PROBE_LD_PAD", "0"))      # extra floats per row of the input operands (row-stride experiments)
+    x, g = torch.randn(M, Ci + pad, device="cuda"), torch.randn(M, Co + pad, device="cuda")
     w, ls = torch.randn(Co, Ci, device="cuda") * 0.05, torch.randn(Co, device="cuda")
     y, dx, aux = torch.empty(M, Co, device="cuda"), torch.empty(M, Ci, device="cuda"), torch.randn(M, Ci, device="cuda")
     pf, pb = planes(w, Co, Ci, Ci, 1), planes(w, Ci, Co, 1, Ci)
     fl = 2.0 * M * Ci * Co
     for name, fn in (
-        ("fwd  fp32", lambda: hip.conv2d(x, Ci, w, None, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=0)),
-        ("fwd  x6", lambda: hip.conv2d(x, Ci, w, None, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=2)),
-        ("fwd  x6 planes", lambda: hip.conv2d(x, Ci, w, None, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=2, w_planes=pf)),
-        ("dgrad fp32", lambda: hip.conv2d(g, Co, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, precision=0)),
-        ("dgrad x6", lambda: hip.conv2d(g, Co, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, precision=2)),
-        ("dgrad x6 planes", lambda: hip.conv2d(g, Co, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, precision=2, w_planes=pb)),
-        ("dgrad x6 planes gelu'", lambda: hip.conv2d(g, Co, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, aux=aux, ldaux=Ci, precision=2, w_planes=pb)),
+        ("fwd  fp32", lambda: hip.conv2d(x, Ci + pad, w, None, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=0)),
+        ("fwd  x6", lambda: hip.conv2d(x, Ci + pad, w, None, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=2)),
+        ("fwd  x6 planes", lambda: hip.conv2d(x, Ci + pad, w, None, y, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=2, w_planes=pf)),
+        ("dgrad fp32", lambda: hip.conv2d(g, Co + pad, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, precision=0)),
+        ("dgrad x6", lambda: hip.conv2d(g, Co + pad, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, precision=2)),
+        ("dgrad x6 planes", lambda: hip.conv2d(g, Co + pad, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, precision=2, w_planes=pb)),
+        ("dgrad x6 planes gelu'", lambda: hip.conv2d(g, Co + pad, w, None, dx, Ci, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, mode=1, aux=aux, ldaux=Ci, precision=2, w_planes=pb)),
     ):
         if only and only not in name:
             continue
