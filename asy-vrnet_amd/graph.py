@@ -47,6 +47,9 @@ class GraphedStep:
         self.net, self.loss_fn = net, loss_fn
         self.model = getattr(net, "module", net)
         self.bucketer = getattr(self.model, "_grad_bucketer", None)
+        if getattr(self.model, "_sync_bn", None) is not None:
+            raise RuntimeError("GraphedStep: synchronised BatchNorm issues collectives inside the forward / backward program; "
+                               "capture is for rank-local BatchNorm statistics (the default) -- run sync_bn steps eagerly")
         self.device = torch.device(device)
         self.x = torch.zeros((batch, 3, size, size), device=device)
         self.r = torch.zeros((batch, 4, size, size), device=device)

@@ -254,11 +254,34 @@ def backward_param_order(model):
     return list(reversed(list(model.parameters())))
 
 
+class SyncBatchNormStats:
+    """The collective step of synchronised BatchNorm (the reference's `sync_bn` option, train.py:356-357:
+    torch.nn.SyncBatchNorm.convert_sync_batchnorm): per-channel sums over the samples of ALL ranks.  program.bn_forward /
+    bn_backward hand their per-sample fp64 moments (B, C, 2) to `total()`; what comes back is the (1, C, 2) sum over
+    samples and ranks, from which the usual coefficient kernels take mean / variance (forward) and the two gradient sums
+    (backward) with the GLOBAL element count `count(B * HW)`.  The parameter gradients keep the LOCAL sums, as
+    SyncBatchNorm does (the gradient all-reduce averages them afterwards).  Every rank issues the same sequence of
+    collectives: the program's launch order is a function of the model only."""
+
+    def __init__(self, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if _dist_on(process_group) else 1
+
+    def count(self, n_local):
+        return n_local * self.world
+
+    def total(self, mom):
+        tot = mom.sum(0, keepdim=True)
+        if self.world > 1:
+            dist.all_reduce(tot, group=self.group)
+        return tot
+
+
 class DataParallelVRNet(torch.nn.Module):
     """Drop-in for DistributedDataParallel(EfficientVRNet) on one node (one process per GPU)."""
 
     def __init__(self, module, bucket_bytes=32 << 20, process_group=None, force_collective=False, segments=3,
-                 broadcast_buffers=False):
+                 broadcast_buffers=False, sync_bn=False):
         """broadcast_buffers: the reference's DDP default (train.py:367-368 leaves broadcast_buffers=True): rank 0's
         BatchNorm running statistics overwrite the other ranks' before every training forward.  Off by default here:
         rank-0 checkpoints (the only ones the reference writes, utils_fit.py:213-225) are identical either way, ranks
@@ -271,6 +294,10 @@ class DataParallelVRNet(torch.nn.Module):
         self.bucketer = GradBucketer(backward_param_order(module), bucket_bytes, process_group, segments=segments)
         self.bucketer.force_collective = force_collective   # collectives even with one rank (single-GPU RCCL rehearsal)
         module._grad_bucketer = self.bucketer
+        # sync_bn: BatchNorm batch statistics over the samples of all ranks (the reference's opt-in `sync_bn`; its default and
+        # this wrapper's is rank-local statistics).  Two small all-reduces per BatchNorm and direction inside the forward /
+        # backward program: eager steps only -- graph.GraphedStep refuses a model with it (no collective inside a capture).
+        module._sync_bn = SyncBatchNormStats(process_group) if sync_bn else None
         if _dist_on(process_group) and (dist.get_world_size(process_group) > 1 or force_collective):
             with torch.no_grad():                       # replicas start identical (DDP broadcasts at wrap time)
                 for t in list(module.parameters()) + list(module.buffers()):

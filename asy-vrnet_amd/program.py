@@ -87,6 +87,7 @@ class RT:
         self.gn_colstats = False    # GroupNorm backward moments from the producing data-gradient conv's epilogue (built and
                                     # tested; same-box A/B: 29.16 -> 29.16 ms with it, 29.01 without: the epilogue work it adds to
                                     # the x6 data-gradient kernels costs what the 46 moments launches it removes were worth)
+        self.sync_bn = None         # parallel.SyncBatchNormStats: BatchNorm statistics over all ranks (model._sync_bn)
         self.consts = {}
         self.idx_maps = {}
         self.relu_masks = None      # {BatchNorm module: ReLU output Act} when model.record_relu_masks (parity tests)
@@ -584,7 +585,13 @@ def bn_forward(rt, z, bn, relu, out=None, residual=None):
     """y = [relu](BN(z)) [+ residual].  Returns (y, ctx) where ctx feeds bn_backward."""
     B, HW, C = z.B, z.HW, z.C
     A, D, S, ms = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C, 2)
-    if rt.training and z.colpart is not None:
+    if rt.training and rt.sync_bn is not None:
+        # synchronised BatchNorm: per-sample moments -> sum over samples and ranks -> coefficients with the global count
+        tot = rt.sync_bn.total(hip.moments(z.t, z.ld, B, HW, C))
+        hip.bn_coef_fwd(tot, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                        bn.num_batches_tracked, True, 1, rt.sync_bn.count(B * HW), C, A, D, S, ms)
+        z.colpart = None
+    elif rt.training and z.colpart is not None:
         hip.bn_coef_fwd_from_partials(z.colpart, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
                                       bn.num_batches_tracked, B, HW, C, A, D, S, ms)
         z.colpart = None
@@ -612,8 +619,17 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
         gw, accw = rt.buf(C), 0
     if gb is None:
         gb = rt.buf(C)
-    hip.bn_stats_bwd(dy, lddy, z.t, z.ld, None if mask is None else mask.t, 0 if mask is None else mask.ld, ms, bn.weight,
-                     rt.training, B, HW, C, A, E, D, S, gw, gb, accw)
+    if rt.training and rt.sync_bn is not None:
+        # the two gradient sums over all ranks for dz; d gamma / d beta from the LOCAL sums (as SyncBatchNorm: the gradient
+        # all-reduce averages them afterwards)
+        mom2 = hip.moments(dy, lddy, B, HW, C, x2=z.t, ldx2=z.ld, mask=None if mask is None else mask.t,
+                           ldm=0 if mask is None else mask.ld)
+        tot2 = rt.sync_bn.total(mom2)
+        hip.bn_coef_bwd(tot2, ms, bn.weight, True, 1, rt.sync_bn.count(B * HW), C, A, E, D, S, rt.buf(C), rt.buf(C), 0)
+        hip.bn_coef_bwd(mom2, ms, bn.weight, True, B, HW, C, rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C), gw, gb, accw)
+    else:
+        hip.bn_stats_bwd(dy, lddy, z.t, z.ld, None if mask is None else mask.t, 0 if mask is None else mask.ld, ms, bn.weight,
+                         rt.training, B, HW, C, A, E, D, S, gw, gb, accw)
     if rt.on_param_grad:
         rt.on_param_grad(bn.weight)
         rt.on_param_grad(bn.bias)
@@ -1445,6 +1461,9 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
         rt.bn_colstats = bool(getattr(model, "bn_colstats", True))
         rt.gn_colstats = bool(getattr(model, "gn_colstats", False))
+        rt.sync_bn = getattr(model, "_sync_bn", None)
+        if rt.sync_bn is not None:
+            rt.bn_colstats = False          # the statistics come from the per-sample moments pass that feeds the collective
         cd = str(os.environ.get("VRNET_COMPUTE_DTYPE") or getattr(model, "compute_dtype", "f32")).lower()   # env: diagnostics
         if cd not in ("f32", "fp32", "float32", "torch.float32", "f32-mfma", "bf16", "bfloat16", "torch.bfloat16"):
             raise RuntimeError(f"compute_dtype {cd!r}: expected 'f32', 'f32-mfma' or 'bf16'")

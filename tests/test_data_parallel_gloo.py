@@ -234,3 +234,51 @@ def test_data_parallel_hardening_two_ranks():
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+def _worker_sync_bn(rank, world, port, q):
+    """parallel.SyncBatchNormStats (the reference's `sync_bn` option): the (1, C, 2) totals every rank gets back are the sums
+    over the samples of ALL ranks, and mean / variance taken from them with the global count equal the statistics of the
+    concatenated batch (what torch.nn.SyncBatchNorm normalises with)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from asy_vrnet_amd.parallel import SyncBatchNormStats, DataParallelVRNet
+    import asy_vrnet_amd as A
+    B, C, HW = 3, 5, 7
+    xs = [torch.randn(B, HW, C, dtype=torch.float64, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    x = xs[rank]
+    mom = torch.stack([x.sum(1), (x * x).sum(1)], -1)                      # (B, C, 2): what hip.moments hands over
+    sb = SyncBatchNormStats()
+    tot = sb.total(mom)
+    full = torch.cat(xs, 0)
+    n = sb.count(B * HW)
+    ok = tot.shape == (1, C, 2) and n == world * B * HW
+    mean = tot[0, :, 0] / n
+    var = tot[0, :, 1] / n - mean * mean
+    ok = ok and torch.allclose(mean, full.mean((0, 1)), atol=1e-12) and torch.allclose(var, full.var((0, 1), unbiased=False), atol=1e-12)
+    # the wrapper option: sets the stats object on the module; the captured step refuses it
+    model = A.EfficientVRNet(4, 9, "nano", img_size=64)
+    net = DataParallelVRNet(model, sync_bn=True)
+    ok = ok and isinstance(model._sync_bn, SyncBatchNormStats) and model._sync_bn.world == world
+    ok = ok and DataParallelVRNet(A.EfficientVRNet(4, 9, "nano", img_size=64))._modules["module"]._sync_bn is None
+    try:
+        from asy_vrnet_amd.graph import GraphedStep
+        GraphedStep(net, lambda det, seg: seg.sum(), 1, 64, "cpu")
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "synchronised BatchNorm" in str(e)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sync_batch_norm_statistics_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sync_bn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res), res
