@@ -1,8 +1,11 @@
-"""Input formats of the training pipeline, host side, restated from the reference's dataloader
-(utils/dataloader.py is not importable here: cv2 / albumentations).  Only the deterministic evaluation path
-(`random=False`) and the format conversions are covered; the random augmentations (mosaic, mixup, HSV jitter,
-:217-437) are a training-recipe concern outside the hot path.  Parity of this row is unpinned by the reference (it has
-no tests and no fixtures for it); tests/test_data.py checks every function against hand-worked values."""
+"""Input formats of the training pipeline, restated from the reference's dataloader (utils/dataloader.py is
+not importable here: cv2 / albumentations).  Only the deterministic evaluation path (`random=False`) and the format
+conversions are covered; the random augmentations (mosaic, mixup, HSV jitter, :217-437) are a training-recipe concern
+outside the hot path.  Host side (numpy / PIL): parsing, letterbox, box mapping.  Device side (`device_batch`,
+csrc/formats.hip): the per-pixel conversions of a letterboxed batch -- image normalisation + CHW, label clamp, one-hot --
+from bytes.  Pins: the functions the reference keeps in importable modules (`preprocess_input`, `preprocess_input_radar`,
+`resize_image`) produced tests/golden/formats_small.npz (tools/make_golden_formats.py); the rest of the row is checked
+against hand-worked values (tests/test_data.py) -- the reference has no tests or fixtures for it."""
 import os
 import re
 
@@ -104,6 +107,35 @@ def letterbox_sample(image, seg_label, box, input_shape):
     new_label = Image.new("L", [w, h], (0))
     new_label.paste(Image.fromarray(np.array(seg_label)).resize((nw, nh), Image.NEAREST), (dx, dy))
     return new_image, adjust_boxes(box, iw, ih, w, h), new_label
+
+
+def resize_image(image, size):
+    """utils_seg/utils.py:20-31 (the letterbox of the prediction scripts): bicubic resize onto a grey canvas.
+    Returns (canvas, nw, nh)."""
+    from PIL import Image
+    iw, ih = image.size
+    w, h = size
+    nw, nh, dx, dy = letterbox_geometry(iw, ih, w, h)
+    canvas = Image.new("RGB", size, (128, 128, 128))
+    canvas.paste(image.resize((nw, nh), Image.BICUBIC), (dx, dy))
+    return canvas, nw, nh
+
+
+def device_batch(images_u8, pngs_u8, num_classes_seg, device="cuda"):
+    """The tensors `yolo_dataset_collate` ships for a letterboxed batch, made ON THE DEVICE from bytes
+    (vrnet_batch_formats_u8): images_u8 (B,H,W,3) uint8 RGB -> images (B,3,H,W) float32 normalised as preprocess_input does
+    (bit-identical); pngs_u8 (B,H,W) uint8 -> png (B,H,W) int64 with the ignore class, seg_labels (B,H,W,nc+1) float32.
+    numpy arrays or tensors; either input may be None.  4 B per pixel cross PCIe instead of 12 + 8 + 4 (nc + 1)."""
+    from . import hip
+
+    def dev(a):
+        if a is None:
+            return None
+        t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+        if t.dtype != torch.uint8:
+            raise RuntimeError(f"device_batch: expected uint8 bytes, got {t.dtype}")
+        return t.to(device, non_blocking=True).contiguous()
+    return hip.batch_formats(dev(images_u8), dev(pngs_u8), num_classes_seg)
 
 
 def make_sample(image, box, radar, png, num_classes_seg):

@@ -86,6 +86,7 @@ _SIGS = {
     "vrnet_sa_apply_f32": ([P, L, P, P, P, P, L, I, L, I, P], I),
     "vrnet_sa_bwd_workspace": ([I, L, I], L),
     "vrnet_decode_outputs_f32": ([P, P, P, I, I, I, F, F, P, P], I),
+    "vrnet_batch_formats_u8": ([P, P, I, I, I, I, P, P, P, P], I),
     "vrnet_yolo_loss_workspace": ([I, L, I, I], L),
     "vrnet_yolo_loss_f32": ([P, P, P, P, P, I, I, I, P, P, I, F, P, P, P, P, P, L, P], I),
     "vrnet_seg_loss_workspace": ([I, I, L], L),
@@ -531,6 +532,26 @@ def decode_outputs(levels, input_h, input_w, out):
     ws = (ctypes.c_int * n)(*[t.shape[3] for t in levels])
     _check(_lib.vrnet_decode_outputs_f32(ptrs, hs, ws, n, levels[0].shape[0], levels[0].shape[1], float(input_h),
                                          float(input_w), ptr(out), stream()), "decode_outputs")
+
+
+def batch_formats(img_u8, png_u8, num_classes_seg, images=None, png_out=None, onehot=None):
+    """Letterboxed batch as bytes -> the tensors the reference's collate function ships (vrnet_batch_formats_u8):
+    img_u8 (B,H,W,3) uint8 -> images (B,3,H,W) f32; png_u8 (B,H,W) uint8 -> png (B,H,W) int64, onehot (B,H,W,ns+1) f32."""
+    src = img_u8 if img_u8 is not None else png_u8
+    B, H, W = src.shape[:3]
+    for t, sh in ((img_u8, (B, H, W, 3)), (png_u8, (B, H, W))):
+        if t is not None and (t.dtype != torch.uint8 or tuple(t.shape) != sh or not t.is_contiguous() or not t.is_cuda):
+            raise RuntimeError(f"batch_formats: expected a contiguous uint8 GPU tensor of shape {sh}, got {t.dtype} {tuple(t.shape)}")
+    if img_u8 is not None and images is None:
+        images = torch.empty((B, 3, H, W), dtype=torch.float32, device=src.device)
+    if png_u8 is not None:
+        if png_out is None:
+            png_out = torch.empty((B, H, W), dtype=torch.int64, device=src.device)
+        if onehot is None:
+            onehot = torch.empty((B, H, W, num_classes_seg + 1), dtype=torch.float32, device=src.device)
+    _check(_lib.vrnet_batch_formats_u8(ptr(img_u8), ptr(png_u8), B, H, W, int(num_classes_seg), ptr(images), ptr(png_out),
+                                       ptr(onehot), stream()), "batch_formats")
+    return images, png_out, onehot
 
 
 def yolo_loss(levels, grads, strides, labels, counts, max_gt, grad_scale, out, fg=None, matched=None, piou=None):

@@ -366,6 +366,16 @@ int vrnet_mt_copy_f32(const long long* addrs, const long* sizes, const int* chun
 int vrnet_decode_outputs_f32(const float* const* levels, const int* hs, const int* ws, int n_levels, int B, int C,
                              float input_h, float input_w, float* out, void* stream);
 
+/* ---- input formats -----------------------------------------------------------------------------
+ * What YoloDataset.__getitem__ / yolo_dataset_collate (utils/dataloader.py:88-107, 440-457) do to a letterboxed batch,
+ * from BYTES: img (B, H, W, 3) u8 RGB -> images (B, 3, H, W) f32 = ((v / 255) - mean) / std evaluated in double and rounded
+ * once (utils_seg/utils.py:43-47 preprocess_input on a float64 array, then FloatTensor: bit-identical); png (B, H, W) u8
+ * labels -> png_out (B, H, W) int64 with labels >= num_classes_seg set to the ignore class num_classes_seg (:96-97) and
+ * onehot (B, H, W, num_classes_seg + 1) f32 (:103-105).  img or png may be NULL (that half is skipped), as may png_out or
+ * onehot. */
+int vrnet_batch_formats_u8(const unsigned char* img, const unsigned char* png, int B, int H, int W, int num_classes_seg,
+                           float* images, long long* png_out, float* onehot, void* stream);
+
 /* ---- training losses on the path's outputs: value + gradient w.r.t. the head outputs ------------
  * vrnet_yolo_loss_f32: YOLOLoss (nets/yolo_training.py:60-427): decode (:99-111), SimOTA assignment per image
  *   (get_assignments :200-264, get_in_boxes_info :291-368, dynamic_k_matching :370-427), IoU / objectness / class

@@ -87,3 +87,56 @@ def test_reference_annotation_file_sample():
         assert b.shape[1] == 5 and (b[:, 2] > b[:, 0]).all() and (b[:, 3] > b[:, 1]).all() and data.frame_id(ln) in p
         cx = data.boxes_xyxy_to_cxcywh(data.adjust_boxes(b, 1920, 1080, 512, 512))
         assert (cx[:, 2:4] > 1).all() and (cx[:, :2] >= 0).all() and (cx[:, :2] <= 512).all()
+
+
+# ---- pinned by the reference's own importable functions (tools/make_golden_formats.py -> formats_small.npz) ----------
+def _golden():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "formats_small.npz"))
+
+
+def test_host_formats_match_reference_vectors():
+    z = _golden()
+    ns = int(z["num_classes_seg"])
+    imgs = np.stack([np.transpose(data.preprocess_input(im), [2, 0, 1]) for im in z["img"]]).astype(np.float32)
+    assert np.array_equal(imgs, z["images"])                       # preprocess_input, utils_seg/utils.py:43-47
+    for b in range(z["png"].shape[0]):
+        png, onehot = data.seg_targets(z["png"][b], ns)
+        assert np.array_equal(png, z["png_clamped"][b]) and np.array_equal(onehot.astype(np.float32), z["onehot"][b])
+    assert np.array_equal(data.preprocess_input_radar(z["radar"]), z["radar_norm"])      # utils/utils.py:50-53
+    from PIL import Image
+    boxed, nw, nh = data.resize_image(Image.fromarray(z["letterbox_src"]), (32, 32))     # utils_seg/utils.py:20-31
+    assert [nw, nh] == z["letterbox_nw_nh"].tolist() and np.array_equal(np.array(boxed), z["letterbox_out"])
+
+
+@pytest.mark.gpu
+def test_device_batch_formats_bit_identical():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    z = _golden()
+    ns = int(z["num_classes_seg"])
+    images, png, onehot = data.device_batch(z["img"], z["png"], ns)
+    assert images.dtype == torch.float32 and png.dtype == torch.int64 and onehot.dtype == torch.float32
+    assert torch.equal(images.cpu(), torch.from_numpy(z["images"]))
+    assert torch.equal(png.cpu(), torch.from_numpy(z["png_clamped"]))
+    assert torch.equal(onehot.cpu(), torch.from_numpy(z["onehot"]))
+    # either half alone; what the collate function of the host path produces for the same samples
+    im2, p2, o2 = data.device_batch(z["img"], None, ns)
+    assert p2 is None and o2 is None and torch.equal(im2, images)
+    _, p3, o3 = data.device_batch(None, z["png"], ns)
+    assert torch.equal(p3, png) and torch.equal(o3, onehot)
+    batch = [data.make_sample(z["img"][b], np.zeros((0, 5)), z["radar"], z["png"][b], ns) for b in range(2)]
+    h_images, _, _, h_png, h_onehot = data.yolo_dataset_collate(batch)
+    assert torch.equal(h_images, images.cpu()) and torch.equal(h_png, png.cpu()) and torch.equal(h_onehot, onehot.cpu())
+    # a full-size batch: every pixel value class through the kernel, against the 256-entry table of the host function
+    rng = np.random.default_rng(3)
+    big = rng.integers(0, 256, (8, 512, 512, 3), dtype=np.uint8)
+    lab = rng.integers(0, 256, (8, 512, 512), dtype=np.uint8)
+    bi, bp, bo = data.device_batch(big, lab, ns)
+    lut = np.stack([data.preprocess_input(np.full((1, 1, 3), v))[0, 0] for v in range(256)]).astype(np.float32)      # (256, 3)
+    want = np.stack([lut[big[..., c], c] for c in range(3)], 1)
+    assert np.array_equal(bi.cpu().numpy(), want)
+    want_p = np.minimum(lab, ns).astype(np.int64)
+    assert np.array_equal(bp.cpu().numpy(), want_p)
+    assert np.array_equal(bo.cpu().numpy().argmax(-1), want_p) and float(bo.sum()) == lab.size
+    with pytest.raises(RuntimeError, match="uint8"):
+        data.device_batch(big.astype(np.float32), None, ns)
