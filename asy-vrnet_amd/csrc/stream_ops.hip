@@ -879,7 +879,7 @@ extern "C" int vrnet_gn_apply_fwd(const float* x, long ldx, const double* pairs,
   VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && vr_aligned16(x) &&
                    vr_aligned16(y) && vr_aligned16(gamma) && vr_aligned16(beta),
                "gn_apply_fwd: needs C %% 4 == 0 and 16-byte aligned rows");
-  if (vr_ablated("affine")) return VR_OK;
+  if (vr_ablated("affine") || vr_ablated("gnfwd")) return VR_OK;
   long bx = vr_cdiv(HW * (C / 4), 256 * 4);            // ~4 float4 per thread: the pair reduction is repeated per workgroup
   const long cap = vr_cdiv(2048, B);
   if (bx > cap) bx = cap;

@@ -38,7 +38,7 @@ class GraphedStep:
     """step(x, x_radar) -> loss tensor; parameter .grad tensors are static and rewritten by each replay.
 
     `net` is EfficientVRNet or parallel.DataParallelVRNet; loss_fn(det list, seg) -> scalar tensor.
-    Construction runs `warmup` eager passes on zero inputs (workspaces, caches, with data parallelism the recording pass
+    Construction runs `warmup` (at least two) eager passes on zero inputs (workspaces, caches, with data parallelism the recording pass
     and its collectives -- so every rank must construct it) and then captures; the module's buffers (BatchNorm running
     statistics, num_batches_tracked) are restored afterwards, so building a GraphedStep on a loaded checkpoint leaves
     the checkpoint's statistics untouched."""
@@ -58,7 +58,9 @@ class GraphedStep:
         self.stream = torch.cuda.Stream(device)          # warm-up AND capture run here: scratch arenas (hip.Workspace is
         self.stream.wait_stream(cur)                     # keyed by stream) exist before the capture and belong to no graph pool
         with torch.cuda.stream(self.stream):
-            for _ in range(max(1, warmup)):              # allocates workspaces / caches outside the capture
+            # at least two passes: the first one's BACKWARD registers derived caches (the data-gradient weight planes) whose
+            # table is rebuilt -- a host-to-device copy -- by the next forward; that must not be the captured one
+            for _ in range(max(2, warmup)):              # allocates workspaces / caches outside the capture
                 self._eager()
                 if self.bucketer is not None and self.bucketer.recording:
                     self.bucketer.rebuild_from_recording()      # arena in execution order before anything is captured

@@ -87,6 +87,10 @@ class RT:
         self.gn_colstats = False    # GroupNorm backward moments from the producing data-gradient conv's epilogue (built and
                                     # tested; same-box A/B: 29.16 -> 29.16 ms with it, 29.01 without: the epilogue work it adds to
                                     # the x6 data-gradient kernels costs what the 46 moments launches it removes were worth)
+        self.gn_fold = False        # GroupNorm in front of a 1x1 conv folded into that conv's A operand (model.gn_fold; built, bit-
+                                    # identical, tested; same-call A/B: 27.0-27.3 ms with it at any K threshold, 26.8-27.1 without --
+                                    # the per-workgroup statistics prologue, the 16 extra VALU operations per K16 step and the
+                                    # re-made tensor for the weight gradient cost what the 32 launches it removes were worth)
         self.sync_bn = None         # parallel.SyncBatchNormStats: BatchNorm statistics over all ranks (model._sync_bn)
         self.consts = {}
         self.idx_maps = {}
@@ -455,7 +459,8 @@ def _pair_kw(rt, x, convs, w_of, bias=True, res_scale=None, kscale=None):
     return dict(w2=w_of(c1), bias2=c1.bias if bias else None, res_scale2=rs1, kscale2=ks1)
 
 
-def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw=None, bias=True, stats=False, bn_stats=False):
+def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw=None, bias=True, stats=False, bn_stats=False,
+              gn_input=None):
     """out: Act (NHWC target) or, with nchw=(tensor, ctot, coff), a channel range of an NCHW tensor.
     conv / res_scale may be pairs (two-stream launch over a (2B,...) input: first half of the rows = first module)."""
     c0, c1 = _pair(conv)
@@ -474,6 +479,8 @@ def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw
             kw2["pair_rows"] = (x.B // 2) * OH * OW
         if c1 is None and kh == 1 and kw == 1 and s == 1 and p == 0:
             kw2["w_planes"] = rt.planes(c0.weight, 0, co, ci, x.B * OH * OW)
+        if gn_input is not None:      # x is the un-normalised input of the GroupNorm in front of this conv (gn_folded said yes)
+            kw2["gn_input"] = gn_input
         hip.conv2d(x.t, x.ld, rt.weight(c0), b, out.t, out.ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
                    mode=0, act=act, ypre=None if ypre is None else ypre.t, ldypre=0 if ypre is None else ypre.ld,
                    res=None if res is None else res.t, ldres=0 if res is None else res.ld,
@@ -535,7 +542,7 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
                         if l is not None and kwl:
                             rt.on_param_grad(l)
         if defer_ok:
-            rt.aside(wgrad, (x.t, dy))
+            rt.aside(wgrad, (x.keep if isinstance(x, FoldedGN) else x.t, dy))
         else:                    # dy is updated in place later in this closure: the weight gradient must read it now
             wgrad()
     target = dx_to if dx_to is not None else (x if x.need_grad else None)
@@ -638,6 +645,45 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
                masky=None if mask is None else mask.t, ldm=0 if mask is None else mask.ld, x2=z.t, ld2=z.ld, E=E, D2=D,
                S2=S)
     return dz
+
+
+class FoldedGN:
+    """Output of a GroupNorm(1, C) that was never written: its consumer -- a forward 1x1 conv on the pre-split-weight x6
+    kernel -- read the un-normalised tensor `src` and normalised every A fragment in registers (hip.conv2d `gn_input`, the
+    same expression hip.gn_apply_fwd stores: the conv saw identical bits).  The only other reader is the conv's weight
+    gradient, which runs on an auxiliary stream during the backward pass: `.t` makes the tensor THERE, when that closure
+    runs (one gn_apply launch beside the data gradients instead of one on the forward chain), so it is not held from the
+    forward to the backward pass either.  `ms` (B, 2): (mean, rstd), written by the conv."""
+    __slots__ = ("rt", "src", "gn", "pairs", "ms", "B", "H", "W", "C", "ld")
+
+    def __init__(self, rt, src, gn, ms):
+        self.rt, self.src, self.gn, self.pairs, self.ms = rt, src, gn, src.pairs, ms
+        self.B, self.H, self.W, self.C, self.ld = src.B, src.H, src.W, src.C, src.C
+
+    def gn_input(self):
+        return (self.pairs[0], self.pairs[1], self.gn.weight, self.gn.bias, self.gn.eps, self.H * self.W, self.ms)
+
+    @property
+    def keep(self):
+        return self.src.t
+
+    @property
+    def t(self):
+        y = self.rt.buf(self.B, self.H, self.W, self.C)
+        hip.gn_apply_fwd(self.src.t, self.src.ld, self.pairs[0], self.pairs[1], self.gn.weight, self.gn.bias, self.gn.eps,
+                         self.B, self.H * self.W, self.C, y, self.C, self.rt.buf(self.B, 2))
+        return y
+
+
+def gn_folded(rt, x, gn, cols):
+    """FoldedGN for y = GN(x) feeding a forward 1x1 conv with `cols` output channels, or None when that launch cannot take
+    it (then gn_forward runs the GroupNorm as its own launch)."""
+    if not rt.gn_fold or isinstance(gn, tuple) or x.pairs is None or rt.wplanes is None or rt.bf16 or rt.fp32_precision != 2:
+        return None
+    rows = x.B * x.H * x.W
+    if not (hip.gn_apply_ok(x.C, x.ld) and x.t.data_ptr() % 16 == 0 and hip.conv2d_gn_fold_ok(rows, cols, x.C, x.H * x.W)):
+        return None
+    return FoldedGN(rt, x, gn, rt.buf(x.B, 2))
 
 
 def gn_forward(rt, x, gn):
@@ -787,14 +833,20 @@ def cluster_block(rt, x, m, name=None):
     E, Dh, fold = tm0.heads, tm0.head_dim, tm0.fold
     ED = E * Dh
     rows_half = (B // 2) * H * W
-    xn, ms1 = gn_forward(rt, x, _attr(m, "norm1"))
     wcat, bcat = tm0._fused_qkv                                  # [fc1 ; fc_v]: one GEMM, f | v side by side
     kwq = dict(pair_rows=rows_half, w2=tm1._fused_qkv[0], bias2=tm1._fused_qkv[1]) if paired else {}
     fv = rt.new(B, H, W, 2 * ED)
     if not paired:
         kwq["w_planes"] = rt.planes(wcat, 0, 2 * ED, C, B * H * W)
-    hip.conv2d(xn.t, xn.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0,
-               precision=rt.prec_fwd(xn.ld, C, 2 * ED), **kwq)
+    xn = gn_folded(rt, x, m0.norm1, 2 * ED) if kwq.get("w_planes") is not None else None
+    if xn is not None:       # the GroupNorm rides in the conv's A operand: no launch, no normalised tensor on the forward chain
+        ms1 = xn.ms
+        hip.conv2d(x.t, x.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0, precision=2,
+                   gn_input=xn.gn_input(), **kwq)
+    else:
+        xn, ms1 = gn_forward(rt, x, _attr(m, "norm1"))
+        hip.conv2d(xn.t, xn.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0,
+                   precision=rt.prec_fwd(xn.ld, C, 2 * ED), **kwq)
     f_t, v_t = fv.t, fv.t[..., ED:]
     o = rt.new(B, H, W, ED)
     idx = rt.buf(B, H, W, E, dtype=torch.uint8)
@@ -811,11 +863,17 @@ def cluster_block(rt, x, m, name=None):
     ls1, ls2 = _attr(m, "layer_scale_1"), _attr(m, "layer_scale_2")
     x1 = rt.new(B, H, W, C)
     conv_call(rt, o, _attr(tm, "fc2"), x1, res=x, res_scale=ls1, stats=True)
-    xn2, ms2 = gn_forward(rt, x1, _attr(m, "norm2"))
     hid = mlp0.fc1.weight.shape[0]
     u = rt.new(B, H, W, hid, need_grad=False) if rt.record else None
     x2 = rt.new(B, H, W, C)
     pmlp = 0 if paired else rt.prec_mlp(C, hid, B * H * W, H * W)
+    xn2 = None
+    if not pmlp and not paired and rt.planes(mlp0.fc1.weight, 0, hid, C, B * H * W) is not None:
+        xn2 = gn_folded(rt, x1, m0.norm2, hid)
+    if xn2 is not None:
+        ms2 = xn2.ms
+    else:
+        xn2, ms2 = gn_forward(rt, x1, _attr(m, "norm2"))
     if pmlp:
         # fc1 -> GELU -> fc2 (+ layer-scale residual, + GroupNorm statistics of the output) as ONE kernel: the hidden
         # activation never reaches HBM; only the pre-activation is stored, for the backward pass
@@ -828,7 +886,10 @@ def cluster_block(rt, x, m, name=None):
         h = None
     else:
         h = rt.new(B, H, W, hid)
-        conv_call(rt, xn2, _attr(mlp, "fc1"), h, act=2, ypre=u)
+        if isinstance(xn2, FoldedGN):
+            conv_call(rt, x1, mlp0.fc1, h, act=2, ypre=u, gn_input=xn2.gn_input())
+        else:
+            conv_call(rt, xn2, _attr(mlp, "fc1"), h, act=2, ypre=u)
         conv_call(rt, h, _attr(mlp, "fc2"), x2, res=x1, res_scale=ls2, stats=True)
 
     def bwd():
@@ -941,7 +1002,7 @@ def _fused_qkv_wgrad(rt, tm, xn, dfv):
             if rt.on_param_grad:
                 for prm in (t.fc1.weight, t.fc_v.weight, t.fc1.bias, t.fc_v.bias):     # back to back: adjacent in the arena
                     rt.on_param_grad(prm)
-    rt.aside(wgrad, (xn.t, dfv.t))
+    rt.aside(wgrad, (xn.keep if isinstance(xn, FoldedGN) else xn.t, dfv.t))
 
 
 # ----------------------------------------------------------------------------------------- fusion blocks
@@ -1461,6 +1522,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
         rt.bn_colstats = bool(getattr(model, "bn_colstats", True))
         rt.gn_colstats = bool(getattr(model, "gn_colstats", False))
+        rt.gn_fold = bool(getattr(model, "gn_fold", False))
         rt.sync_bn = getattr(model, "_sync_bn", None)
         if rt.sync_bn is not None:
             rt.bn_colstats = False          # the statistics come from the per-sample moments pass that feeds the collective

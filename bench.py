@@ -310,6 +310,7 @@ def main():
     ap.add_argument("--no-fused-mlp", action="store_true", help="Mlp as two conv launches (A/B aid)")
     ap.add_argument("--no-weight-planes", action="store_true", help="x6 kernels split the weights themselves (A/B aid)")
     ap.add_argument("--no-bn-colstats", action="store_true", help="BatchNorm statistics by a pass over z (A/B aid)")
+    ap.add_argument("--gn-fold", action="store_true", help="GroupNorm folded into the consuming 1x1 conv's A operand (A/B aid; off by default)")
     ap.add_argument("--gn-colstats", action="store_true", help="GroupNorm backward moments from the data-gradient conv's epilogue (A/B aid; off by default)")
     ap.add_argument("--diagnostic", action="store_true",
                     help="allow VRNET_* environment knobs and the diagnostic library build (tools/sweep_env.sh ablations); the "
@@ -364,6 +365,7 @@ def main():
     model.weight_planes = not args.no_weight_planes
     model.bn_colstats = not args.no_bn_colstats
     model.gn_colstats = bool(args.gn_colstats)
+    model.gn_fold = bool(args.gn_fold)
     net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 

@@ -4,7 +4,6 @@ RadarEnhanceByImage, ShuffleAttention, eca_block, ASPP, CoCUpsample, BaseConv(ds
 program's own block functions (asy-vrnet_amd/program.py, i.e. the C-ABI kernels) on the fixture's seeded inputs and
 parameters: output, input gradients and every parameter gradient.  tests/test_oracle_golden.py holds the CPU oracle to the
 same vectors; here the HIP path itself meets them, without the oracle in between."""
-import importlib
 import json
 import os
 
@@ -23,8 +22,8 @@ def env():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import asy_vrnet_amd as A
-    program = importlib.import_module("asy-vrnet_amd.program")
-    modules = importlib.import_module("asy-vrnet_amd.modules")
+    import asy_vrnet_amd.modules as modules
+    import asy_vrnet_amd.program as program
     return A, program, modules
 
 
