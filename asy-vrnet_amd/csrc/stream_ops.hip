@@ -685,6 +685,30 @@ __global__ void copy_channels_kernel(const float* src, long lds, int scs, float*
   }
 }
 
+// torch.cat([a, b], 1) (+ the 2-group channel shuffle when `interleave`: channel 2 j = a_j, 2 j + 1 = b_j) in ONE launch, and
+// its adjoint: dir 0: cat[r][c] = a / b;  dir 1: a[r][j] (+)= cat[r][..], b[r][j] (+)= cat[r][..] (per-source accumulate flags;
+// a source pointer may be null: that half is skipped).  Consecutive threads walk consecutive channels of the wide tensor.
+__global__ void cat2_kernel(float* a, long lda, int Ca, float* b, long ldb, int Cb, float* cat, long ldc, long rows,
+                            int interleave, int dir, int acc_a, int acc_b) {
+  const int Ct = Ca + Cb;
+  const long total = rows * Ct;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / Ct;
+    const int c = e - r * Ct;
+    const bool second = interleave ? (c & 1) : (c >= Ca);
+    const int j = interleave ? (c >> 1) : (second ? c - Ca : c);
+    float* s = second ? (b ? b + r * ldb + j : nullptr) : (a ? a + r * lda + j : nullptr);
+    if (!s) continue;
+    float* w = cat + r * ldc + c;
+    if (dir == 0) {
+      *w = *s;
+    } else {
+      const int acc = second ? acc_b : acc_a;
+      *s = acc ? *s + *w : *w;
+    }
+  }
+}
+
 // 32x32 LDS-tiled transpose between [B][C][HW] and [B][HW][ld]
 __global__ void nchw_to_nhwc_kernel(const float* src, float* dst, long ldd, int C, long HW) {
   __shared__ float tile[32][33];
@@ -1083,6 +1107,20 @@ extern "C" int vrnet_copy_channels_f32(const float* src, long lds, int scs, floa
   hipLaunchKernelGGL(copy_channels_kernel, dim3(blocks), dim3(256), 0, vr_stream(stream), src, lds, scs, dst, ldd, dcs,
                      rows, C, accumulate);
   VR_LAUNCH_CHECK("copy_channels");
+  return VR_OK;
+}
+
+extern "C" int vrnet_cat2_f32(float* a, long lda, int Ca, float* b, long ldb, int Cb, float* cat, long ldc, long rows,
+                              int interleave, int dir, int accumulate_a, int accumulate_b, void* stream) {
+  VR_CHECK_ARG(cat && rows > 0 && Ca > 0 && Cb > 0 && (a || b) && (dir == 0 || dir == 1), "cat2: bad arguments");
+  VR_CHECK_ARG(dir == 1 || (a && b), "cat2: the forward direction needs both sources");
+  VR_CHECK_ARG(!interleave || Ca == Cb, "cat2: the channel shuffle needs halves of equal width");
+  VR_CHECK_ARG((!a || lda >= Ca) && (!b || ldb >= Cb) && ldc >= Ca + Cb, "cat2: row strides");
+  long blocks = vr_cdiv(rows * (Ca + Cb), 1024);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cat2_kernel, dim3(blocks), dim3(256), 0, vr_stream(stream), a, lda, Ca, b, ldb, Cb, cat, ldc, rows,
+                     interleave, dir, accumulate_a, accumulate_b);
+  VR_LAUNCH_CHECK("cat2");
   return VR_OK;
 }
 

@@ -63,6 +63,7 @@ _SIGS = {
     "vrnet_ls_coef_bwd": ([P, P, I, I, P, P, I, I, P, P, P, P], I),
     "vrnet_moments_to_float": ([P, P, L, D, I, P], I),
     "vrnet_copy_channels_f32": ([P, L, I, P, L, I, L, I, I, P], I),
+    "vrnet_cat2_f32": ([P, L, I, P, L, I, P, L, L, I, I, I, I, P], I),
     "vrnet_patch_gather_f32": ([P, L, P, P, I, I, I, I, I, I, P], I),
     "vrnet_patch_scatter_f32": ([P, P, L, I, I, I, I, I, I, I, P], I),
     "vrnet_weight_ohwi_f32": ([P, P, I, I, I, I, I, I, P], I),
@@ -432,6 +433,12 @@ def weight_ohwi(src, dst, Cout, Cin, kh, kw, direction, accumulate=0):
 def copy_channels(src, lds, scs, dst, ldd, dcs, rows, C, accumulate=0):
     _check(_lib.vrnet_copy_channels_f32(ptr(src), lds, scs, ptr(dst), ldd, dcs, rows, C, accumulate, stream()),
            "copy_channels")
+
+
+def cat2(a, lda, Ca, b, ldb, Cb, cat, ldc, rows, interleave, dir=0, accumulate_a=0, accumulate_b=0):
+    """dir 0: cat = torch.cat([a, b], channels) (+ 2-group shuffle when interleave); dir 1: the adjoint (a / b may be None)."""
+    _check(_lib.vrnet_cat2_f32(ptr(a), lda, Ca, ptr(b), ldb, Cb, ptr(cat), ldc, rows, int(interleave), dir, accumulate_a,
+                               accumulate_b, stream()), "cat2")
 
 
 def nchw_to_nhwc(src, dst, ldd, B, C, HW):

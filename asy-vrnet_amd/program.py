@@ -1075,30 +1075,24 @@ def shuffle_attention(rt, x, m):
 
 def cat2(rt, a, b, interleave):
     """torch.cat([a, b], 1) [+ 2-group channel shuffle when both halves have equal width]
-    (vr_coc.py:70-80, coc_fpn_dual.py:120-130): strided copies into one buffer."""
+    (vr_coc.py:70-80, coc_fpn_dual.py:120-130): one launch into one buffer, one for the adjoint."""
     B, H, W = a.B, a.H, a.W
     Ct = a.C + b.C
     out = rt.new(B, H, W, Ct)
     rows = a.rows
-    if interleave and Ct % 2 == 0:
+    il = bool(interleave and Ct % 2 == 0)
+    if il:
         assert a.C == b.C
-        hip.copy_channels(a.t, a.ld, 1, out.t, Ct, 2, rows, a.C)
-        hip.copy_channels(b.t, b.ld, 1, out.t[..., 1:], Ct, 2, rows, b.C)
-        sa, sb, cs = out.t, out.t[..., 1:], 2
-    else:
-        hip.copy_channels(a.t, a.ld, 1, out.t, Ct, 1, rows, a.C)
-        hip.copy_channels(b.t, b.ld, 1, out.t[..., a.C:], Ct, 1, rows, b.C)
-        sa, sb, cs = out.t, out.t[..., a.C:], 1
+    hip.cat2(a.t, a.ld, a.C, b.t, b.ld, b.C, out.t, Ct, rows, il)           # one launch (two strided copies before)
 
     def bwd():
         g = take_grad(out)
         if g is None:
             return
-        ga, gb = g, (g[..., 1:] if cs == 2 else g[..., a.C:])
-        for src, act in ((ga, a), (gb, b)):
-            if act.need_grad:
-                buf, acc = rt.grad_target(act)
-                hip.copy_channels(src, Ct, cs, buf, act.C, 1, rows, act.C, accumulate=acc)
+        ba, acca = rt.grad_target(a) if a.need_grad else (None, 0)
+        bb, accb = rt.grad_target(b) if b.need_grad else (None, 0)
+        if ba is not None or bb is not None:
+            hip.cat2(ba, a.C, a.C, bb, b.C, b.C, g, Ct, rows, il, dir=1, accumulate_a=acca, accumulate_b=accb)
     rt.push(bwd)
     return out
 

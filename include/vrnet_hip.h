@@ -287,6 +287,11 @@ int vrnet_weight_ohwi_f32(const float* src, float* dst, int Cout, int Cin, int k
 /* ---- layout ---------------------------------------------------------------------------------------- */
 /* dst[r*ldd + c*dcs] (+)= src[r*lds + c*scs]: torch.cat + shuffle_channels(groups=2) (vr_coc.py:70-80,
  * coc_fpn_dual.py:120-130) written straight into the consumer's buffer, and their adjoints. */
+/* torch.cat([a, b], 1) (+ shuffle_channels(groups = 2) when interleave: channel 2 j = a_j, 2 j + 1 = b_j; vr_coc.py:70-80,
+ * coc_fpn_dual.py:120-130) in ONE launch -- dir 0: cat (rows, Ca + Cb) = a | b -- and its adjoint -- dir 1: a (+)= its
+ * channels of cat, b (+)= its channels (accumulate_a / accumulate_b; a or b NULL: that half is skipped). */
+int vrnet_cat2_f32(float* a, long lda, int Ca, float* b, long ldb, int Cb, float* cat, long ldc, long rows, int interleave,
+                   int dir, int accumulate_a, int accumulate_b, void* stream);
 int vrnet_copy_channels_f32(const float* src, long lds, int scs, float* dst, long ldd, int dcs, long rows, int C,
                             int accumulate, void* stream);
 int vrnet_nchw_to_nhwc_f32(const float* src, float* dst, long ldd, int B, int C, long HW, void* stream);

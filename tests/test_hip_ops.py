@@ -1394,3 +1394,33 @@ def test_conv_with_group_norm_folded_input(hip, case):
     with pytest.raises(RuntimeError, match="GroupNorm-folded"):
         hip.conv2d(x, Ci, w, b, y1, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=0, w_planes=pf,
                    gn_input=(pairs, per, gamma, beta, 1e-5, HW, ms1))
+
+
+@pytest.mark.parametrize("interleave", [False, True])
+@pytest.mark.parametrize("case", [(37, 8, 8), (1024, 64, 64), (200, 12, 20)])
+def test_cat2_and_adjoint(hip, case, interleave):
+    """torch.cat([a, b], channels) (+ shuffle_channels(groups=2)) in one launch, and its adjoint with per-source accumulate
+    flags and an absent source (vr_coc.py:70-80, coc_fpn_dual.py:120-130)."""
+    rows, Ca, Cb = case
+    if interleave and Ca != Cb:
+        with pytest.raises(RuntimeError, match="equal width"):
+            hip.cat2(torch.zeros(rows, Ca, device="cuda"), Ca, Ca, torch.zeros(rows, Cb, device="cuda"), Cb, Cb,
+                     torch.zeros(rows, Ca + Cb, device="cuda"), Ca + Cb, rows, True)
+        return
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(rows, Ca + 4, generator=g).cuda(), torch.randn(rows, Cb, generator=g).cuda()      # a: row stride > width
+    out = torch.empty(rows, Ca + Cb, device="cuda")
+    hip.cat2(a, Ca + 4, Ca, b, Cb, Cb, out, Ca + Cb, rows, interleave)
+    ref = torch.cat([a[:, :Ca], b], 1)
+    if interleave:
+        ref = ref.view(rows, 2, Ca).transpose(1, 2).reshape(rows, 2 * Ca)          # shuffle_channels(groups=2)
+    assert torch.equal(out, ref)
+    gr = torch.randn(rows, Ca + Cb, generator=g).cuda()
+    ga0, gb0 = torch.randn(rows, Ca, generator=g).cuda(), torch.randn(rows, Cb, generator=g).cuda()
+    ga, gb = ga0.clone(), gb0.clone()
+    hip.cat2(ga, Ca, Ca, gb, Cb, Cb, gr, Ca + Cb, rows, interleave, dir=1, accumulate_a=1, accumulate_b=0)
+    ra, rb = (gr[:, 0::2], gr[:, 1::2]) if interleave else (gr[:, :Ca], gr[:, Ca:])
+    assert torch.equal(ga, ga0 + ra) and torch.equal(gb, rb)
+    gb2 = gb0.clone()
+    hip.cat2(None, Ca, Ca, gb2, Cb, Cb, gr, Ca + Cb, rows, interleave, dir=1, accumulate_b=1)
+    assert torch.equal(gb2, gb0 + rb)
