@@ -394,7 +394,66 @@ def _up_setup(ctx, inputs, output):
 upsample_bilinear.register_autograd(lambda ctx, g: (torch.ops.vrnet.upsample_bilinear_backward(g, ctx.scale), None),
                                     setup_context=_up_setup)
 
+
+
+@torch.library.custom_op("vrnet::cat_shuffle", mutates_args=(), device_types="cuda")
+def cat_shuffle(a: torch.Tensor, b: torch.Tensor, interleave: bool) -> torch.Tensor:
+    """torch.cat([a, b], channels) of two NHWC maps, followed by shuffle_channels(groups=2) when `interleave` (equal widths:
+    channel 2 j = a_j, 2 j + 1 = b_j) -- vr_coc.py:70-80, coc_fpn_dual.py:120-130 -- in one launch."""
+    a, b = a.contiguous(), b.contiguous()
+    rows = a.numel() // a.shape[-1]
+    out = a.new_empty(a.shape[:-1] + (a.shape[-1] + b.shape[-1],))
+    with torch.cuda.device(a.device):
+        hip.cat2(a, a.shape[-1], a.shape[-1], b, b.shape[-1], b.shape[-1], out, out.shape[-1], rows, interleave)
+    return out
+
+
+@cat_shuffle.register_fake
+def _(a, b, interleave):
+    return a.new_empty(a.shape[:-1] + (a.shape[-1] + b.shape[-1],))
+
+
+@torch.library.custom_op("vrnet::cat_shuffle_backward", mutates_args=(), device_types="cuda")
+def cat_shuffle_backward(g: torch.Tensor, ca: int, interleave: bool) -> tuple[torch.Tensor, torch.Tensor]:
+    g = g.contiguous()
+    ct = g.shape[-1]
+    rows = g.numel() // ct
+    ga, gb = g.new_empty(g.shape[:-1] + (ca,)), g.new_empty(g.shape[:-1] + (ct - ca,))
+    with torch.cuda.device(g.device):
+        hip.cat2(ga, ca, ca, gb, ct - ca, ct - ca, g, ct, rows, interleave, dir=1)
+    return ga, gb
+
+
+@cat_shuffle_backward.register_fake
+def _(g, ca, interleave):
+    return g.new_empty(g.shape[:-1] + (ca,)), g.new_empty(g.shape[:-1] + (g.shape[-1] - ca,))
+
+
+def _cat_setup(ctx, inputs, output):
+    ctx.ca, ctx.interleave = inputs[0].shape[-1], inputs[2]
+
+
+cat_shuffle.register_autograd(lambda ctx, g: (*torch.ops.vrnet.cat_shuffle_backward(g, ctx.ca, ctx.interleave), None),
+                              setup_context=_cat_setup)
+
+
+@torch.library.custom_op("vrnet::batch_formats", mutates_args=(), device_types="cuda")
+def batch_formats(images_u8: torch.Tensor, pngs_u8: torch.Tensor, num_classes_seg: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """A letterboxed batch from bytes (utils/dataloader.py:88-107, 440-457): images (B,H,W,3) uint8 -> (B,3,H,W) float32
+    normalised as preprocess_input does; labels (B,H,W) uint8 -> (B,H,W) int64 with the ignore class and the
+    (B,H,W,nc+1) float32 one-hot."""
+    with torch.cuda.device(images_u8.device):
+        return hip.batch_formats(images_u8.contiguous(), pngs_u8.contiguous(), num_classes_seg)
+
+
+@batch_formats.register_fake
+def _(images_u8, pngs_u8, num_classes_seg):
+    B, H, W, _ = images_u8.shape
+    return (images_u8.new_empty((B, 3, H, W), dtype=torch.float32), pngs_u8.new_empty((B, H, W), dtype=torch.int64),
+            pngs_u8.new_empty((B, H, W, num_classes_seg + 1), dtype=torch.float32))
+
+
 # Autocast policy (the reference trains under torch.cuda.amp.autocast, utils/utils_fit.py:86-88): these ops compute in fp32
 # whatever the autocast dtype, i.e. floating-point arguments are cast to fp32 on the way in.
-for _op in ("cluster", "conv2d_nhwc", "mlp", "group_norm1", "batch_norm_act", "dwconv3x3", "upsample_bilinear"):
+for _op in ("cluster", "conv2d_nhwc", "mlp", "group_norm1", "batch_norm_act", "dwconv3x3", "upsample_bilinear", "cat_shuffle"):
     torch.library.register_autocast(f"vrnet::{_op}", "cuda", torch.float32)

@@ -1424,3 +1424,32 @@ def test_cat2_and_adjoint(hip, case, interleave):
     gb2 = gb0.clone()
     hip.cat2(None, Ca, Ca, gb2, Cb, Cb, gr, Ca + Cb, rows, interleave, dir=1, accumulate_b=1)
     assert torch.equal(gb2, gb0 + rb)
+
+
+def test_torch_library_cat_shuffle_and_batch_formats(hip):
+    """torch.ops.vrnet.cat_shuffle (cat + 2-group channel shuffle, autograd) and torch.ops.vrnet.batch_formats (input formats
+    from bytes) against ATen / the host functions; schemas and fake kernels by opcheck."""
+    import asy_vrnet_amd.ops  # noqa: F401
+    from asy_vrnet_amd import data
+    opcheck = lambda op, args: torch.library.opcheck(op, args, test_utils=("test_schema", "test_faketensor"))
+    a = rnd(2, 6, 5, 16, seed=1).cuda().requires_grad_(True)
+    b = rnd(2, 6, 5, 16, seed=2).cuda().requires_grad_(True)
+    for il in (False, True):
+        y = torch.ops.vrnet.cat_shuffle(a, b, il)
+        ref = torch.cat([a, b], -1)
+        if il:
+            ref = ref.view(2, 6, 5, 2, 16).transpose(3, 4).reshape(2, 6, 5, 32)
+        assert torch.equal(y, ref)
+        g = rnd(2, 6, 5, 32, seed=3).cuda()
+        for m_, w_ in zip(torch.autograd.grad(y, (a, b), g), torch.autograd.grad(ref, (a, b), g)):
+            assert torch.equal(m_, w_)
+        opcheck(torch.ops.vrnet.cat_shuffle.default, (a.detach(), b.detach(), il))
+    rng = np.random.default_rng(0)
+    img = torch.from_numpy(rng.integers(0, 256, (2, 8, 12, 3), dtype=np.uint8)).cuda()
+    png = torch.from_numpy(rng.integers(0, 256, (2, 8, 12), dtype=np.uint8)).cuda()
+    images, lab, onehot = torch.ops.vrnet.batch_formats(img, png, 9)
+    want = np.stack([np.transpose(data.preprocess_input(im), [2, 0, 1]) for im in img.cpu().numpy()]).astype(np.float32)
+    assert np.array_equal(images.cpu().numpy(), want)
+    assert np.array_equal(lab.cpu().numpy(), np.minimum(png.cpu().numpy(), 9).astype(np.int64))
+    assert np.array_equal(onehot.cpu().numpy().argmax(-1), lab.cpu().numpy())
+    opcheck(torch.ops.vrnet.batch_formats.default, (img, png, 9))
