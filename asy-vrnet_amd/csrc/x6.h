@@ -8,9 +8,15 @@ namespace {
 // ---- fp32 products on the bf16 matrix pipe ("x6"): every fp32 operand is split EXACTLY into three bf16 values
 // a = a0 + a1 + a2 (truncation: a0 = top 16 bits of a, a1 = top 16 bits of a - a0, a2 = a - a0 - a1, which has at most
 // 8 significant bits left), and a*b is accumulated in fp32 as the six bf16 x bf16 products (exact in fp32) with
-// i + j <= 2: a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1.  The three dropped products are <= 2^-24 |ab| each, i.e. the
-// result carries fp32 rounding-level error like the fp32 MFMA, at 6 x 32 instead of 8 x 64 matrix-pipe cycles per
-// 32 x 32 x 16 block (v_mfma_f32_32x32x16_bf16 vs eight v_mfma_f32_32x32x2_f32).
+// i + j <= 2: a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1.  Every plane keeps 8 significant bits, so with truncation
+// |a1| < 2^-7 |a| and |a2| < 2^-14 |a|: the dropped products a1b2 and a2b1 are each below 2^-21 |ab| (a2b2 below 2^-28)
+// and, the planes of a truncated operand all having its sign, carry the sign of ab -- a bias towards zero of at most
+// 2^-20 |ab| per product, about 2^-23 typically (the planes' leading bits are spread evenly), not zero-mean rounding noise.
+// The weights that are split once per step (planes_pack_kernel, mlp_pack_kernel) are split round-to-nearest-even, which
+// halves their side of it and makes it zero-mean; the activations are truncated in the kernels (2 VALU operations per
+// plane instead of the 5 of an RNE split).  Measured against an fp64 matmul over the net's GEMM shapes the result is as
+// close as the fp32 MFMA's (profiles/r03_x6_vs_fp32_mfma_gemm_probe.txt), at 6 x 32 instead of 8 x 64 matrix-pipe cycles
+// per 32 x 32 x 16 block (v_mfma_f32_32x32x16_bf16 vs eight v_mfma_f32_32x32x2_f32).
 typedef __bf16 vr_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned vr_u32x4 __attribute__((ext_vector_type(4)));
 

@@ -161,7 +161,11 @@ int vrnet_pack_weight_t_f32(const float* w_oihw, const float* kscale, float* w_t
  * x6 on non-finite / tiny operands (both here and in vrnet_conv2d_f32 precision 2): an operand of +-Inf splits into
  *   (Inf, NaN, NaN), so an Inf in the data yields NaN where fp32 arithmetic yields Inf; NaN stays NaN.  The low planes of an
  *   operand below 2^-110 in magnitude fall into the bf16 denormal range, which the matrix pipe flushes: such operands
- *   carry 8-16 instead of 24 significant bits (the product is below 2^-110 |other operand|). */
+ *   carry 8-16 instead of 24 significant bits (the product is below 2^-110 |other operand|).
+ * x6 error: the three dropped products are each below 2^-21 |ab| (typically 2^-23); the activation operands are split by
+ *   truncation in the kernels, so their share is a bias towards zero rather than zero-mean rounding; the pre-split
+ *   weights round to nearest even.  Against an fp64 matmul the results are as close as the fp32 MFMA's
+ *   (profiles/r03_x6_vs_fp32_mfma_gemm_probe.txt; tests hold 2e-5 of the output scale). */
 int vrnet_mlp_fused_ok(int C, int HID, long M);
 long vrnet_mlp_pack_bytes(int C, int HID, int precision);
 int vrnet_mlp_pack_f32(const float* w1, const float* w2, int C, int HID, int precision, void* pack_fwd, void* pack_bwd,
