@@ -42,4 +42,13 @@ python3 bench.py > $out/bench_phi-l_bs8_512.json 2> $out/bench_l.err
 (echo "# tools/micro/x6_overlap.hip: 24 MFMAs + 4 fragment splits per K16 step; clustered / software-pipelined, accumulators free / pinned to AGPRs"; timeout 120 tools/micro/x6_overlap.bin) > $out/x6_overlap_micro.txt 2>&1
 (echo "# tools/micro/mfma_chain.hip: v_mfma_f32_32x32x16_bf16 issue rate vs number of independent accumulator chains"; timeout 120 tools/micro/mfma_chain.bin) > $out/mfma_chain_micro.txt 2>&1
 (echo "# tools/micro/x6_peak.hip: register-resident x6 inner loop, no memory (mfma only / splits only / both)"; timeout 120 tools/micro/x6_peak.bin) > $out/x6_issue_ceiling_micro.txt 2>&1
+# isolated probes and micro-benchmarks behind DESIGN 3.4 / 3.5
+(echo "# python tools/cluster_probe.py  (Cluster kernels alone, phi = l, bs 8, 512 px)"; timeout 300 python3 tools/cluster_probe.py 2>&1 | grep -v amdgpu.ids) > $out/cluster_probe.txt
+(echo "# python tools/planes_shape_probe.py B H W Cin Cout ...  (single conv launches alone: fp32 MFMA / x6 / x6 with pre-split weights)"; timeout 600 python3 tools/planes_shape_probe.py 8 32 32 320 1280 8 32 32 1280 320 8 32 32 256 320 8 32 32 320 512 8 16 16 512 2048 8 16 16 2048 512 8 16 16 512 512 8 64 64 128 256 8 64 64 256 1024 8 128 128 64 256 2>&1 | grep -v amdgpu.ids) > $out/planes_shape_probe.txt
+(echo "# tools/micro/lds_fill.hip: per-CU rate of bringing L2-resident data into LDS (LDS-DMA / load + ds_write / load only)"; timeout 120 tools/micro/lds_fill.bin) > $out/lds_fill_micro.txt 2>&1
+(echo "# tools/micro/wg_placement.hip: where the dispatcher puts the workgroups of an under-filled grid"; timeout 60 tools/micro/wg_placement.bin) > $out/wg_placement_micro.txt 2>&1
+(echo "# tools/micro/dma_stream.hip: streaming a row-major fp32 matrix into LDS by LDS-DMA, by chunk size per row"; timeout 60 tools/micro/dma_stream.bin) > $out/dma_stream_micro.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bf16 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --serial --no-graph --dtype bf16 --batch 16 > $out/bf16.log 2>&1
+cp $(ls $out/bf16/*/*kernel_stats.csv | head -1) $out/kernel_stats_phi-l_bs16_512_bf16_serial.csv
+rm -rf $out/bf16
 ls -la $out
