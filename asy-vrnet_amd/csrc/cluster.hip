@@ -23,6 +23,7 @@ struct ClusterArgs {
   float* df; float* dv; long lddf;
   float* ab_partial;   // [blocks][2]
   int B, H, W, E, D, fold;
+  int forced;          // forward: idx is an INPUT (teacher-forced assignment: parity tests), not computed here
 };
 
 constexpr int MAXW = 16;   // waves per workgroup
@@ -235,8 +236,8 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
     fn[s] = inv_nf;   // 1/max(|f_n|, eps); the clamp is active iff inv_nf >= 1e12
     float best, bc;
     int k;
-    if (BWD) {
-      k = ok[s] ? (int)p.idx[row[s] * p.E + e] : 0;     // replay the forward's assignment
+    if (BWD || p.forced) {
+      k = ok[s] ? (int)p.idx[row[s] * p.E + e] : 0;     // replay the forward's (or a given) assignment
       sim_of(dt, k, inv_nf, inv_cn, alpha, beta, best, bc);
     } else {
       k = assign4(dt, inv_nf, inv_cn, alpha, beta, sub, best, bc);
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
     nf = inv_nf;   // callers get 1/max(|f_n|, eps)
     float best, bc;
     int k;
-    if (BWD) {
+    if (BWD || p.forced) {
       k = ok ? (int)p.idx[row * p.E + e] : 0;
       sim_of(dt, k, inv_nf, inv_cn, alpha, beta, best, bc);
     } else {
@@ -762,9 +763,29 @@ int cluster_check(const char* name, const void* f, const void* v, long ld, int B
 
 }  // namespace
 
+static int cluster_fwd_impl(const float* f, const float* v, long ld, const float* alpha, const float* beta, float* out, long ldo,
+                            unsigned char* idx, float* wgt, int B, int H, int W, int E, int D, int fold, const float* alpha2,
+                            const float* beta2, int forced, void* stream);
+
 extern "C" int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                                      float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E,
                                      int D, int fold, const float* alpha2, const float* beta2, void* stream) {
+  return cluster_fwd_impl(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, D, fold, alpha2, beta2, 0, stream);
+}
+
+/* The same forward with the hard assignment GIVEN (idx is read, not written): every point goes to the centre idx names,
+ * with that centre's similarity.  For parity work: two arithmetic paths can only be compared to rounding level when the
+ * numerically tied points of the arg-max (vr_coc.py:173-176) are decided the same way in both. */
+extern "C" int vrnet_cluster_fwd_forced_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
+                                            float* out, long ldo, const unsigned char* idx, float* wgt, int B, int H, int W,
+                                            int E, int D, int fold, const float* alpha2, const float* beta2, void* stream) {
+  return cluster_fwd_impl(f, v, ld, alpha, beta, out, ldo, const_cast<unsigned char*>(idx), wgt, B, H, W, E, D, fold, alpha2,
+                          beta2, 1, stream);
+}
+
+static int cluster_fwd_impl(const float* f, const float* v, long ld, const float* alpha, const float* beta, float* out, long ldo,
+                            unsigned char* idx, float* wgt, int B, int H, int W, int E, int D, int fold, const float* alpha2,
+                            const float* beta2, int forced, void* stream) {
   int T, npt;
   int rc = cluster_check("cluster_fwd", f, v, ld, B, H, W, E, D, fold, &T, &npt, 0);
   if (rc) return rc;
@@ -775,6 +796,7 @@ extern "C" int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, co
   p.alpha2 = alpha2; p.beta2 = beta2;
   p.f = f; p.v = v; p.ld = ld; p.alpha = alpha; p.beta = beta; p.out = out; p.ldo = ldo; p.idx = idx; p.wgt = wgt;
   p.B = B; p.H = H; p.W = W; p.E = E; p.D = D; p.fold = fold;
+  p.forced = forced;
   cluster_launch<false>(p, T, npt, (long)B * E * fold * fold, vr_stream(stream));
   VR_LAUNCH_CHECK("cluster_fwd");
   return VR_OK;

@@ -72,6 +72,7 @@ _SIGS = {
     "vrnet_add_f32": ([P, P, L, P], I),
     "vrnet_fill_f32": ([P, F, L, P], I),
     "vrnet_cluster_fwd_f32": ([P, P, L, P, P, P, L, P, P, I, I, I, I, I, I, P, P, P], I),
+    "vrnet_cluster_fwd_forced_f32": ([P, P, L, P, P, P, L, P, P, I, I, I, I, I, I, P, P, P], I),
     "vrnet_cluster_bwd_workspace": ([I, I, I], L),
     "vrnet_cluster_bwd_workspace2": ([I, I, I, I, I], L),
     "vrnet_cluster_bwd_f32": ([P, P, L, P, P, P, P, L, P, P, L, P, P, I, I, I, I, I, I, I, P, P, P, P, P, L, P], I),
@@ -457,8 +458,10 @@ def fill_(dst, value):
     _check(_lib.vrnet_fill_f32(ptr(dst), float(value), dst.numel(), stream()), "fill")
 
 
-def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold, alpha2=None, beta2=None):
-    _check(_lib.vrnet_cluster_fwd_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(out), ldo, ptr(idx), ptr(wgt), B, H,
+def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold, alpha2=None, beta2=None, forced=False):
+    """forced: idx is given (read), not computed (teacher-forced assignment for parity comparisons)."""
+    fn = _lib.vrnet_cluster_fwd_forced_f32 if forced else _lib.vrnet_cluster_fwd_f32
+    _check(fn(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(out), ldo, ptr(idx), ptr(wgt), B, H,
                                       W, E, Dh, fold, ptr(alpha2), ptr(beta2), stream()), "cluster_fwd")
 
 

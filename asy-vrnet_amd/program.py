@@ -91,6 +91,7 @@ class RT:
                                     # identical, tested; same-call A/B: 27.0-27.3 ms with it at any K threshold, 26.8-27.1 without --
                                     # the per-workgroup statistics prologue, the 16 extra VALU operations per K16 step and the
                                     # re-made tensor for the weight gradient cost what the 32 launches it removes were worth)
+        self.forced_idx = None      # {block name: (B,H,W,E) uint8}: Cluster assignments to replay instead of the arg-max (model.forced_idx_maps)
         self.sync_bn = None         # parallel.SyncBatchNormStats: BatchNorm statistics over all ranks (model._sync_bn)
         self.consts = {}
         self.idx_maps = {}
@@ -852,6 +853,9 @@ def cluster_block(rt, x, m, name=None):
     idx = rt.buf(B, H, W, E, dtype=torch.uint8)
     big = (H // max(fold, 1)) * (W // max(fold, 1)) > 256       # streaming kernel keeps the similarity map
     kwc = dict(alpha2=tm1.sim_alpha, beta2=tm1.sim_beta) if paired else {}
+    if rt.forced_idx is not None and not paired and name is not None and name in rt.forced_idx:
+        idx.copy_(rt.forced_idx[name])                          # teacher-forced assignment (model.forced_idx_maps: parity tests)
+        kwc["forced"] = True
     hip.cluster_fwd(f_t, v_t, 2 * ED, tm0.sim_alpha, tm0.sim_beta, o.t, ED, idx, rt.buf(B, H, W, E) if big else None,
                     B, H, W, E, Dh, fold, **kwc)
     if name is not None:
@@ -1517,6 +1521,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         rt.bn_colstats = bool(getattr(model, "bn_colstats", True))
         rt.gn_colstats = bool(getattr(model, "gn_colstats", False))
         rt.gn_fold = bool(getattr(model, "gn_fold", False))
+        rt.forced_idx = getattr(model, "forced_idx_maps", None)
         rt.sync_bn = getattr(model, "_sync_bn", None)
         if rt.sync_bn is not None:
             rt.bn_colstats = False          # the statistics come from the per-sample moments pass that feeds the collective

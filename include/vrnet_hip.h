@@ -314,6 +314,11 @@ int vrnet_fill_f32(float* dst, float value, long n, void* stream);
 int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                           float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E, int D,
                           int fold, const float* alpha2, const float* beta2, void* stream);
+/* the same forward with the assignment GIVEN (idx is read): parity work, where the numerically tied points of the arg-max
+ * (vr_coc.py:173-176) must be decided the same way on both sides of a comparison */
+int vrnet_cluster_fwd_forced_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
+                                 float* out, long ldo, const unsigned char* idx, float* wgt, int B, int H, int W, int E, int D,
+                                 int fold, const float* alpha2, const float* beta2, void* stream);
 long vrnet_cluster_bwd_workspace(int B, int E, int fold);                          /* regions of <= 256 points */
 long vrnet_cluster_bwd_workspace2(int B, int H, int W, int E, int fold);            /* any region size */
 /* Recomputes the forward from f, v with the saved assignment idx; df, dv share row stride lddf. */

@@ -319,6 +319,19 @@ def test_cluster_core(hip, case):
     out2 = torch.empty_like(out)
     hip.cluster_fwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), out2, E * D, idx, wgt, B, H, W, E, D, fold)
     assert torch.equal(out, out2)
+    # teacher-forced forward (vrnet_cluster_fwd_forced_f32): its own assignment gives the same output; a different one (every
+    # point to the next centre) gives what the oracle computes for that assignment
+    out3 = torch.empty_like(out)
+    hip.cluster_fwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), out3, E * D, idx, wgt, B, H, W, E, D, fold, forced=True)
+    assert torch.equal(out, out3)
+    idx_rot = ((idx.long() + 1) % 4).to(torch.uint8)
+    keep = idx_rot.clone()
+    hip.cluster_fwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), out3, E * D, idx_rot, wgt, B, H, W, E, D, fold, forced=True)
+    assert torch.equal(idx_rot, keep)                       # read, not written
+    with torch.no_grad():
+        ref_rot, _ = O.cluster_core(f.detach(), v.detach(), alpha.detach(), beta.detach(), E, fold,
+                                    forced_idx=idx_rot.permute(0, 3, 1, 2).contiguous().cpu().long())
+    close(nchw(out3), ref_rot, what="cluster fwd, forced assignment")
 
 
 def test_cluster_rejects_bad_shapes(hip):
