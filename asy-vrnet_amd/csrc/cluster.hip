@@ -24,7 +24,12 @@ struct ClusterArgs {
   float* ab_partial;   // [blocks][2]
   int B, H, W, E, D, fold;
   int forced;          // forward: idx is an INPUT (teacher-forced assignment: parity tests), not computed here
+  // optional bf16-plane copies (csrc/pgemm.hip): forward `out`; backward [df | dv] as ONE tensor of 2 E D columns (df first)
+  vrnet_planes_out outp, dfvp;
 };
+__device__ __forceinline__ void cl_planes(const vrnet_planes_out& o, long row, int col, const f32x4 v) {
+  if (o.p) vr_store_planes4(reinterpret_cast<unsigned short*>(o.p) + row * o.ld + col, o.plane, o.np, v);
+}
 
 constexpr int MAXW = 16;   // waves per workgroup
 
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = wg[s] * sm[SM_AFIN + kk[s] * 32 + 4 * sub + q];
         *reinterpret_cast<f32x4*>(p.out + row[s] * p.ldo + e * D + 4 * sub) = o;
+        cl_planes(p.outp, row[s], e * D + 4 * sub, o);
       }
       if (sub == 0) {
         p.idx[row[s] * p.E + e] = (unsigned char)kk[s];
@@ -353,7 +359,10 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) o[q] += pw * atq[m][q];
         }
-        if (ok[s] && dim_ok) *reinterpret_cast<f32x4*>(p.dv + row[s] * p.lddf + e * D + 4 * sub) = o;
+        if (ok[s] && dim_ok) {
+          *reinterpret_cast<f32x4*>(p.dv + row[s] * p.lddf + e * D + 4 * sub) = o;
+          cl_planes(p.dfvp, row[s], p.E * D + e * D + 4 * sub, o);
+        }
       }
       // d c_hat_k += dcos * f_hat_n
       const float dcn = dc * fn[s];
@@ -400,7 +409,10 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q] += pw * dcen[m][q];
     }
-    if (ok[s] && dim_ok) *reinterpret_cast<f32x4*>(p.df + row[s] * p.lddf + e * D + 4 * sub) = o;
+    if (ok[s] && dim_ok) {
+      *reinterpret_cast<f32x4*>(p.df + row[s] * p.lddf + e * D + 4 * sub) = o;
+      cl_planes(p.dfvp, row[s], e * D + 4 * sub, o);
+    }
   }
   // d alpha, d beta partials of this workgroup
   {
@@ -565,6 +577,7 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = wg * sm[SM_AFIN + k * 32 + 4 * sub + q];
         *reinterpret_cast<f32x4*>(p.out + row * p.ldo + coff) = o;
+        cl_planes(p.outp, row, coff, o);
       }
     }
     return;
@@ -613,6 +626,7 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
               for (int q = 0; q < 4; ++q) o[q] += invq * sm[SM_T1 + m * 32 + 4 * sub + q];
             }
           *reinterpret_cast<f32x4*>(p.dv + row * p.lddf + coff) = o;
+          cl_planes(p.dfvp, row, p.E * p.D + coff, o);
         }
         const float dcn = dc * nf;
 #pragma unroll
@@ -661,6 +675,7 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
         for (int q = 0; q < 4; ++q) o[q] += invq * dcen[m][q];
       }
     *reinterpret_cast<f32x4*>(p.df + row * p.lddf + coff) = o;
+    cl_planes(p.dfvp, row, coff, o);
   }
   {
     float ab[4] = {dal, dbe, 0.f, 0.f};
@@ -765,12 +780,19 @@ int cluster_check(const char* name, const void* f, const void* v, long ld, int B
 
 static int cluster_fwd_impl(const float* f, const float* v, long ld, const float* alpha, const float* beta, float* out, long ldo,
                             unsigned char* idx, float* wgt, int B, int H, int W, int E, int D, int fold, const float* alpha2,
-                            const float* beta2, int forced, void* stream);
+                            const float* beta2, int forced, const vrnet_planes_out* outp, void* stream);
 
 extern "C" int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                                      float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E,
                                      int D, int fold, const float* alpha2, const float* beta2, void* stream) {
-  return cluster_fwd_impl(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, D, fold, alpha2, beta2, 0, stream);
+  return cluster_fwd_impl(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, D, fold, alpha2, beta2, 0, nullptr, stream);
+}
+/* The same with a second copy of `out` as bf16 planes (the A operand of the proj conv's plane GEMM and the x operand of its
+ * weight gradient); forced != 0: the teacher-forced form. */
+extern "C" int vrnet_cluster_fwd_planes_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
+                                            float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E,
+                                            int D, int fold, int forced, const vrnet_planes_out* outp, void* stream) {
+  return cluster_fwd_impl(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, D, fold, nullptr, nullptr, forced ? 1 : 0, outp, stream);
 }
 
 /* The same forward with the hard assignment GIVEN (idx is read, not written): every point goes to the centre idx names,
@@ -780,16 +802,16 @@ extern "C" int vrnet_cluster_fwd_forced_f32(const float* f, const float* v, long
                                             float* out, long ldo, const unsigned char* idx, float* wgt, int B, int H, int W,
                                             int E, int D, int fold, const float* alpha2, const float* beta2, void* stream) {
   return cluster_fwd_impl(f, v, ld, alpha, beta, out, ldo, const_cast<unsigned char*>(idx), wgt, B, H, W, E, D, fold, alpha2,
-                          beta2, 1, stream);
+                          beta2, 1, nullptr, stream);
 }
 
 static int cluster_fwd_impl(const float* f, const float* v, long ld, const float* alpha, const float* beta, float* out, long ldo,
                             unsigned char* idx, float* wgt, int B, int H, int W, int E, int D, int fold, const float* alpha2,
-                            const float* beta2, int forced, void* stream) {
+                            const float* beta2, int forced, const vrnet_planes_out* outp, void* stream) {
   int T, npt;
   int rc = cluster_check("cluster_fwd", f, v, ld, B, H, W, E, D, fold, &T, &npt, 0);
   if (rc) return rc;
-  VR_CHECK_ARG(out && idx && alpha && beta && ldo % 4 == 0 && vr_aligned16(out), "cluster_fwd: bad output");
+  VR_CHECK_ARG(out && idx && alpha && beta && ldo % 4 == 0 && vr_aligned16(out) && vr_planes_out_ok(outp, E * D), "cluster_fwd: bad output");
   VR_CHECK_ARG(T != 0 || wgt, "cluster_fwd: regions of more than 256 points need the similarity map `wgt` (B,H,W,E)");
   VR_CHECK_ARG((!alpha2 == !beta2) && (!alpha2 || B % 2 == 0), "cluster_fwd: a two-stream launch needs alpha2, beta2 and an even batch");
   ClusterArgs p{};
@@ -797,6 +819,7 @@ static int cluster_fwd_impl(const float* f, const float* v, long ld, const float
   p.f = f; p.v = v; p.ld = ld; p.alpha = alpha; p.beta = beta; p.out = out; p.ldo = ldo; p.idx = idx; p.wgt = wgt;
   p.B = B; p.H = H; p.W = W; p.E = E; p.D = D; p.fold = fold;
   p.forced = forced;
+  if (outp) p.outp = *outp;
   cluster_launch<false>(p, T, npt, (long)B * E * fold * fold, vr_stream(stream));
   VR_LAUNCH_CHECK("cluster_fwd");
   return VR_OK;
@@ -808,16 +831,40 @@ extern "C" long vrnet_cluster_bwd_workspace2(int B, int H, int W, int E, int fol
 }
 extern "C" long vrnet_cluster_bwd_workspace(int B, int E, int fold) { return (long)B * E * fold * fold * 2 * 4 + 256; }
 
+static int cluster_bwd_impl(const float* f, const float* v, long ld, const float* alpha, const float* beta,
+                            const unsigned char* idx, const float* dout, long lddo, float* df, float* dv,
+                            long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
+                            int E, int D, int fold, const float* alpha2, const float* beta2, float* dalpha2,
+                            float* dbeta2, const vrnet_planes_out* dfvp, void* workspace, long workspace_bytes, void* stream);
 extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                                      const unsigned char* idx, const float* dout, long lddo, float* df, float* dv,
                                      long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
                                      int E, int D, int fold, const float* alpha2, const float* beta2, float* dalpha2,
                                      float* dbeta2, void* workspace, long workspace_bytes, void* stream) {
+  return cluster_bwd_impl(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, dbeta, accumulate_ab, B, H, W, E, D, fold,
+                          alpha2, beta2, dalpha2, dbeta2, nullptr, workspace, workspace_bytes, stream);
+}
+/* The same with a second copy of [df | dv] (one tensor of 2 E D columns, df first) as bf16 planes: the dy operand of the
+ * fc1 | fc_v data- and weight-gradient plane GEMMs. */
+extern "C" int vrnet_cluster_bwd_planes_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
+                                            const unsigned char* idx, const float* dout, long lddo, float* df, float* dv,
+                                            long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
+                                            int E, int D, int fold, const vrnet_planes_out* dfvp, void* workspace,
+                                            long workspace_bytes, void* stream) {
+  return cluster_bwd_impl(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, dbeta, accumulate_ab, B, H, W, E, D, fold,
+                          nullptr, nullptr, nullptr, nullptr, dfvp, workspace, workspace_bytes, stream);
+}
+static int cluster_bwd_impl(const float* f, const float* v, long ld, const float* alpha, const float* beta,
+                            const unsigned char* idx, const float* dout, long lddo, float* df, float* dv,
+                            long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
+                            int E, int D, int fold, const float* alpha2, const float* beta2, float* dalpha2,
+                            float* dbeta2, const vrnet_planes_out* dfvp, void* workspace, long workspace_bytes, void* stream) {
   int T, npt;
   int rc = cluster_check("cluster_bwd", f, v, ld, B, H, W, E, D, fold, &T, &npt, 1);
   if (rc) return rc;
   VR_CHECK_ARG(idx && dout && df && dv && dalpha && dbeta && workspace, "cluster_bwd: null tensor");
-  VR_CHECK_ARG(lddo % 4 == 0 && lddf % 4 == 0 && vr_aligned16(dout) && vr_aligned16(df) && vr_aligned16(dv),
+  VR_CHECK_ARG(lddo % 4 == 0 && lddf % 4 == 0 && vr_aligned16(dout) && vr_aligned16(df) && vr_aligned16(dv) &&
+                   vr_planes_out_ok(dfvp, 2 * E * D),
                "cluster_bwd: rows must be 16-byte aligned");
   const long blocks = (long)B * E * fold * fold;
   const long need = T == 0 ? vrnet_cluster_bwd_workspace2(B, H, W, E, fold) : vrnet_cluster_bwd_workspace(B, E, fold);
@@ -831,6 +878,7 @@ extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, co
   p.alpha2 = alpha2; p.beta2 = beta2;
   p.f = f; p.v = v; p.ld = ld; p.alpha = alpha; p.beta = beta; p.idx = const_cast<unsigned char*>(idx);
   p.g = dout; p.ldg = lddo; p.df = df; p.dv = dv; p.lddf = lddf;
+  if (dfvp) p.dfvp = *dfvp;
   p.ab_partial = reinterpret_cast<float*>(workspace);
   p.wgt = p.ab_partial + ((blocks * 2 + 63) / 64) * 64;       // streaming kernel: per-point d cos scratch
   p.B = B; p.H = H; p.W = W; p.E = E; p.D = D; p.fold = fold;

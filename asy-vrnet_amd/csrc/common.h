@@ -49,6 +49,37 @@ static inline bool vr_aligned16(const void* p) { return (reinterpret_cast<uintpt
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+extern "C" {
+/* include/vrnet_hip.h: optional bf16-plane output of a producing kernel (csrc/pgemm.hip: plane tensors). */
+typedef struct vrnet_planes_out {
+  void* p;          /* plane q of element (row, c) at p[q * plane + row * ld + c], bf16 */
+  long ld, plane;   /* row and plane stride in elements (multiples of 4; 8 to feed the plane GEMMs) */
+  int np;           /* 3: the fp32 value split exactly into three planes; 1: rounded to bf16 */
+} vrnet_planes_out;
+}
+static inline bool vr_planes_out_ok(const vrnet_planes_out* o, int C) {
+  return !o || (o->p && (o->np == 1 || o->np == 3) && o->ld >= C && o->ld % 4 == 0 && (o->np == 1 || o->plane % 4 == 0) &&
+                (reinterpret_cast<uintptr_t>(o->p) & 7) == 0);
+}
+
+// Four consecutive fp32 values -> bf16 planes (8 bytes per plane): np = 3 splits each value exactly, v = p0 + p1 + p2 with
+// round-to-nearest-even at each step (the residuals v - p0 and v - p0 - p1 are exact in fp32 and the last one has at most 8
+// significant bits); np = 1 rounds to bf16.  All arithmetic per component (no packed fp32 with operand broadcast).
+typedef __bf16 vr_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vr_store_planes4(unsigned short* dst, long plane, int np, const f32x4 v) {
+  const vr_bf16x4 p0 = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  *reinterpret_cast<vr_bf16x4*>(dst) = p0;
+  if (np == 3) {
+    const float r0 = v[0] - (float)p0[0], r1 = v[1] - (float)p0[1], r2 = v[2] - (float)p0[2], r3 = v[3] - (float)p0[3];
+    const vr_bf16x4 p1 = {(__bf16)r0, (__bf16)r1, (__bf16)r2, (__bf16)r3};
+    *reinterpret_cast<vr_bf16x4*>(dst + plane) = p1;
+    const vr_bf16x4 p2 = {(__bf16)(r0 - (float)p1[0]), (__bf16)(r1 - (float)p1[1]), (__bf16)(r2 - (float)p1[2]),
+                          (__bf16)(r3 - (float)p1[3])};
+    *reinterpret_cast<vr_bf16x4*>(dst + 2 * plane) = p2;
+  }
+}
+
+
 __device__ __forceinline__ float vr_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 // exact-erf GELU (nn.GELU default, vr_coc.py:204) and its derivative.  erf is evaluated branch-free as
 //   erf(z) = 1 - Q(s) exp(-z^2),  s = p z / (1 + p z),  Q a degree-6 polynomial with Q(0) = 1      (z = |u| / sqrt 2)

@@ -19,16 +19,6 @@
 
 #include <cstdlib>
 
-extern "C" {
-// include/vrnet_hip.h: optional column statistics of a conv's stored outputs
-typedef struct vrnet_conv_colstats {
-  double* partial;              // [ceil(M/32)][N][2]: per output column, (sum v, sum v * f) over each 32-row tile
-  const float* x2; long ldx2;   // f = x2[m, n] (row stride ldx2); NULL: f = v
-  const float* gamma;           // with tile_totals: weights of the columns
-  double* tile_totals;          // [ceil(M/32)][ceil(N/32)][2]: the two sums weighted by gamma, added over a tile's 32 columns
-} vrnet_conv_colstats;
-}
-
 namespace {
 
 template <int BM, int BN, int BK, int TM, int TN, int WM, int WN, int MODE, bool VEC>
@@ -1835,7 +1825,19 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
 }
 
 // Slab reduction shared by every weight-gradient kernel: dw / dbias (+ layer-scale partials) from S slabs per stream.
+// (also called from pgemm.hip: the plane weight gradient writes the same slabs)
+int vr_wgrad_reduce_launch(float* slab, float* bslab, float* ls_part, long ls_stride, int S, int T, int Cout, int Cin,
+                           int streams, const float* row_scale, float* dw, float* dbias, int accumulate,
+                           const float* row_scale2, float* dw2, float* dbias2, const float* w, const float* w2,
+                           const float* bias, const float* bias2, float* dls, float* dls2, hipStream_t st);
 static int wgrad_reduce_launch(float* slab, float* bslab, float* ls_part, long ls_stride, int S, int T, int Cout, int Cin,
+                               int streams, const float* row_scale, float* dw, float* dbias, int accumulate,
+                               const float* row_scale2, float* dw2, float* dbias2, const float* w, const float* w2,
+                               const float* bias, const float* bias2, float* dls, float* dls2, hipStream_t st) {
+  return vr_wgrad_reduce_launch(slab, bslab, ls_part, ls_stride, S, T, Cout, Cin, streams, row_scale, dw, dbias, accumulate,
+                                row_scale2, dw2, dbias2, w, w2, bias, bias2, dls, dls2, st);
+}
+int vr_wgrad_reduce_launch(float* slab, float* bslab, float* ls_part, long ls_stride, int S, int T, int Cout, int Cin,
                                int streams, const float* row_scale, float* dw, float* dbias, int accumulate,
                                const float* row_scale2, float* dw2, float* dbias2, const float* w, const float* w2,
                                const float* bias, const float* bias2, float* dls, float* dls2, hipStream_t st) {

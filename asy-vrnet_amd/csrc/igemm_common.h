@@ -3,6 +3,16 @@
 #pragma once
 #include "common.h"
 
+extern "C" {
+// include/vrnet_hip.h: optional column statistics of a conv's stored outputs
+typedef struct vrnet_conv_colstats {
+  double* partial;              // [ceil(M/32)][N][2]: per output column, (sum v, sum v * f) over each 32-row tile
+  const float* x2; long ldx2;   // f = x2[m, n] (row stride ldx2); NULL: f = v
+  const float* gamma;           // with tile_totals: weights of the columns
+  double* tile_totals;          // [ceil(M/32)][ceil(N/32)][2]: the two sums weighted by gamma, added over a tile's 32 columns
+} vrnet_conv_colstats;
+}
+
 namespace {
 
 struct IgemmArgs {
@@ -40,6 +50,11 @@ struct IgemmArgs {
   // same bits -- with the sample's (mean, rstd) re-added from the (sum, sumsq) tile pairs the PRODUCER of `a` left
   // (gn_pairs: [B][gn_per][2], fixed order) in every workgroup's prologue.  gn_ms (B, 2) receives (mean, rstd).
   const double* gn_pairs; long gn_per; const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_HW; float* gn_ms;
+  // Output as bf16 planes (pgemm.hip; vector epilogue only): plane q of element (m, n) at yp[q * yp_plane + m * ldyp + n].
+  // yp_np = 3: the stored fp32 value split exactly into three bf16 values (v = p0 + p1 + p2, round-to-nearest-even splits) --
+  // the operand format of the next x6 GEMM, which then splits nothing; yp_np = 1: the value rounded to bf16.  `y` may be
+  // null when only the planes are wanted.
+  unsigned short* yp; long ldyp; long yp_plane; int yp_np;
 };
 
 // The argument block a workgroup whose first row is m0 works with: the second stream's parameters behind pair_rows.
@@ -83,19 +98,14 @@ __device__ __forceinline__ long igemm_row_index(const IgemmArgs& p, int m) {
 
 constexpr int STAGE_LD = 36;                       // epilogue staging tile: 32 rows x 36 floats per wave
 
-// One 32x32 accumulator tile (tile row `ti`, tile column `tj` of the wave's TM x TN grid).  A function of ONE
-// accumulator taken by value: looping `acc[i][j]` over runtime-looking indices (the compiler refuses to unroll a
-// loop that contains barriers) makes the whole accumulator array runtime-indexed, i.e. moves it to scratch.
-template <int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32x16 acc, float* smem, int m0, int n0, int ti,
-                                                   int tj) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+// One 32 x 32 accumulator tile whose first output element is (row0, col0); `stage`: this wave's private staging tile of
+// 32 * STAGE_LD floats.
+__device__ __forceinline__ void igemm_epilogue_tile(const IgemmArgs& p, const f32x16 acc, float* stage, int row0, int col0) {
+  const int lane = threadIdx.x & 63;
   const int khalf = lane >> 5;
   // Row-contiguous float4 epilogue: each wave transposes one 32x32 accumulator tile through its private
   // LDS staging tile, then 8 lanes cover one 128-byte output row segment (aux / residual loads and all
   // stores are whole lines).  The main loop ended with a barrier, so the operand images can be reused.
-  float* stage = smem + wave * (32 * STAGE_LD);
 #pragma unroll
   for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * STAGE_LD + (lane & 31)] = acc[r];
   // the staging tile is private to this wave and a wave's LDS operations complete in program order: no workgroup
@@ -112,8 +122,8 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
   for (int t = 0; t < 4; ++t) {
     const int q = lane + 64 * t;
     const int row = q >> 3, c4 = (q & 7) * 4;
-    const int m = m0 + wm * TM * 32 + ti * 32 + row;
-    const int n = n0 + wn * TN * 32 + tj * 32 + c4;
+    const int m = row0 + row;
+    const int n = col0 + c4;
     if (m < p.M && n < p.CN) {
       const long mo = igemm_row_index(p, m);
       f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * STAGE_LD + c4]);
@@ -136,9 +146,12 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
         if (p.res_scale) v = rv + *reinterpret_cast<const f32x4*>(p.res_scale + n) * v;
         else v = rv + v;
       }
-      f32x4* dst = reinterpret_cast<f32x4*>(p.y + mo * p.ldy + n);
-      if (p.accumulate) v += *dst;
-      *dst = v;
+      if (p.y) {
+        f32x4* dst = reinterpret_cast<f32x4*>(p.y + mo * p.ldy + n);
+        if (p.accumulate) v += *dst;
+        *dst = v;
+      }
+      if (p.yp) vr_store_planes4(p.yp + mo * p.ldyp + n, p.yp_plane, p.yp_np, v);
       if (p.stats) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -168,8 +181,8 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
         cs2[e] += __shfl_xor(cs2[e], o, 64);
       }
     }
-    const int mb = (m0 + wm * TM * 32 + ti * 32) >> 5;
-    const int n = n0 + wn * TN * 32 + tj * 32 + (lane & 7) * 4;
+    const int mb = row0 >> 5;
+    const int n = col0 + (lane & 7) * 4;
     double g1 = 0.0, g2 = 0.0;
     if (lane < 8 && mb * 32 < p.M && n < p.CN) {
       double* d = p.col_part + ((long)mb * p.CN + n) * 2;
@@ -190,7 +203,7 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
         g1 += __shfl_xor(g1, o, 64);
         g2 += __shfl_xor(g2, o, 64);
       }
-      const int nb = (n0 + wn * TN * 32 + tj * 32) >> 5;
+      const int nb = col0 >> 5;
       if (lane == 0 && mb * 32 < p.M && nb < p.stats_nb) {
         double* d = p.col_tot + ((long)mb * p.stats_nb + nb) * 2;
         d[0] = g1;
@@ -200,7 +213,7 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
   }
   if (p.stats) {      // statistics of exactly what was stored (fp64, as the moments kernel): GroupNorm of the consumer
     const double st1 = wave_sum(q1), st2 = wave_sum(q2);
-    const int mb = (m0 + wm * TM * 32 + ti * 32) >> 5, nb = (n0 + wn * TN * 32 + tj * 32) >> 5;
+    const int mb = row0 >> 5, nb = col0 >> 5;
     if (lane == 0 && mb * 32 < p.M && nb < p.stats_nb) {
       double* d = p.stats + ((long)mb * p.stats_nb + nb) * 2;
       d[0] = st1;
@@ -208,6 +221,17 @@ __device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32
     }
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+// One 32x32 accumulator tile (tile row `ti`, tile column `tj` of the wave's TM x TN grid).  A function of ONE
+// accumulator taken by value: looping `acc[i][j]` over runtime-looking indices (the compiler refuses to unroll a
+// loop that contains barriers) makes the whole accumulator array runtime-indexed, i.e. moves it to scratch.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue_vec(const IgemmArgs& p, const f32x16 acc, float* smem, int m0, int n0, int ti,
+                                                   int tj) {
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  igemm_epilogue_tile(p, acc, smem + wave * (32 * STAGE_LD), m0 + wm * TM * 32 + ti * 32, n0 + wn * TN * 32 + tj * 32);
 }
 
 template <int TM, int TN, int WM, int WN>

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, 
 // share of the rows: y = (rstd * gamma) * (x - mean) + beta.  One launch where the coefficient kernel + affine were two.
 __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const float* x, long ldx, const double* pairs, long per,
                                                            const float* gamma, const float* beta, float eps, long HW, int C,
-                                                           float* y, long ldy, float* mean_rstd) {
+                                                           float* y, long ldy, float* mean_rstd, vrnet_planes_out yp) {
   __shared__ double red[4];
   const int b = blockIdx.y;
   const double* src = pairs + (long)b * per * 2;
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const float* x, long 
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = fmaf((float)(rstd * (double)g[j]), v[j] - mu, be[j]);
-    *reinterpret_cast<f32x4*>(y + row * ldy + c) = o;
+    if (y) *reinterpret_cast<f32x4*>(y + row * ldy + c) = o;
+    if (yp.p) vr_store_planes4(reinterpret_cast<unsigned short*>(yp.p) + row * yp.ld + c, yp.plane, yp.np, o);
   }
 }
 
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const float* dy, long
                                                            const double* gtot, int gper, const double* partial, int nchunks,
                                                            const float* mean_rstd, const float* gamma, int B, long HW, int C,
                                                            const float* add, long ldadd, float* out, long ldo, float* dgamma,
-                                                           float* dbeta, int accumulate_params) {
+                                                           float* dbeta, int accumulate_params, vrnet_planes_out outp) {
   __shared__ double red[4];
   if ((int)blockIdx.y == B) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const float* dy, long
       for (int j = 0; j < 4; ++j) o[j] += a[j];
     }
     *reinterpret_cast<f32x4*>(out + row * ldo + c) = o;
+    if (outp.p) vr_store_planes4(reinterpret_cast<unsigned short*>(outp.p) + row * outp.ld + c, outp.plane, outp.np, o);
   }
 }
 
@@ -896,22 +898,36 @@ extern "C" int vrnet_gn_coef_fwd(const double* mom, const float* gamma, const fl
 /* GroupNorm(1, C) forward from the producer's tile statistics, ONE launch: y = GN(x); mean_rstd [B][2] for the backward
  * pass.  pairs: `pairs_per_sample` consecutive fp64 (sum, sumsq) pairs per sample (vrnet_conv2d_f32 / vrnet_mlp_fwd_f32
  * `stats`).  Needs C % 4 == 0 and 16-byte rows. */
-extern "C" int vrnet_gn_apply_fwd(const float* x, long ldx, const double* pairs, long pairs_per_sample, const float* gamma,
-                                  const float* beta, float eps, int B, long HW, int C, float* y, long ldy, float* mean_rstd,
-                                  void* stream) {
-  VR_CHECK_ARG(x && pairs && gamma && beta && y && mean_rstd, "gn_apply_fwd: null tensor");
-  VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && vr_aligned16(x) &&
-                   vr_aligned16(y) && vr_aligned16(gamma) && vr_aligned16(beta),
+static int gn_apply_fwd_impl(const float* x, long ldx, const double* pairs, long pairs_per_sample, const float* gamma,
+                             const float* beta, float eps, int B, long HW, int C, float* y, long ldy, float* mean_rstd,
+                             const vrnet_planes_out* yp, void* stream) {
+  VR_CHECK_ARG(x && pairs && gamma && beta && (y || yp) && mean_rstd, "gn_apply_fwd: null tensor");
+  VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldx >= C && (!y || (ldy % 4 == 0 && ldy >= C && vr_aligned16(y))) &&
+                   vr_aligned16(x) && vr_aligned16(gamma) && vr_aligned16(beta) && vr_planes_out_ok(yp, C),
                "gn_apply_fwd: needs C %% 4 == 0 and 16-byte aligned rows");
   if (vr_ablated("affine") || vr_ablated("gnfwd")) return VR_OK;
   long bx = vr_cdiv(HW * (C / 4), 256 * 4);            // ~4 float4 per thread: the pair reduction is repeated per workgroup
   const long cap = vr_cdiv(2048, B);
   if (bx > cap) bx = cap;
   if (bx < 1) bx = 1;
+  const vrnet_planes_out none{};
   hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3((unsigned)bx, B), dim3(256), 0, vr_stream(stream), x, ldx, pairs, pairs_per_sample,
-                     gamma, beta, eps, HW, C, y, ldy, mean_rstd);
+                     gamma, beta, eps, HW, C, y, ldy, mean_rstd, yp ? *yp : none);
   VR_LAUNCH_CHECK("gn_apply_fwd");
   return VR_OK;
+}
+extern "C" int vrnet_gn_apply_fwd(const float* x, long ldx, const double* pairs, long pairs_per_sample, const float* gamma,
+                                  const float* beta, float eps, int B, long HW, int C, float* y, long ldy, float* mean_rstd,
+                                  void* stream) {
+  VR_CHECK_ARG(y, "gn_apply_fwd: null tensor");
+  return gn_apply_fwd_impl(x, ldx, pairs, pairs_per_sample, gamma, beta, eps, B, HW, C, y, ldy, mean_rstd, nullptr, stream);
+}
+/* The same with the result (also, or only: y may be NULL) written as bf16 planes -- the operand format of the plane GEMMs
+ * (vrnet_gemm_planes_f32 / vrnet_wgrad_planes_f32): the conv behind the GroupNorm then splits nothing. */
+extern "C" int vrnet_gn_apply_fwd_planes(const float* x, long ldx, const double* pairs, long pairs_per_sample, const float* gamma,
+                                         const float* beta, float eps, int B, long HW, int C, float* y, long ldy,
+                                         float* mean_rstd, const vrnet_planes_out* yp, void* stream) {
+  return gn_apply_fwd_impl(x, ldx, pairs, pairs_per_sample, gamma, beta, eps, B, HW, C, y, ldy, mean_rstd, yp, stream);
 }
 
 /* GroupNorm(1, C) backward in TWO launches (moments of (dy, dy * x) with gamma-weighted chunk totals; apply + parameter
@@ -919,11 +935,31 @@ extern "C" int vrnet_gn_apply_fwd(const float* x, long ldx, const double* pairs,
 extern "C" long vrnet_gn_bwd_workspace(int B, long HW, int C) {
   return vrnet_moments_workspace(B, HW, C) + (long)B * 512 * 4 * 2 * 8 + 256;
 }
+static int gn_apply_bwd_impl(const float* dy, long lddy, const float* x, long ldx, const float* mean_rstd,
+                             const float* gamma, int B, long HW, int C, const float* add, long ldadd, float* out, long ldo,
+                             float* dgamma, float* dbeta, int accumulate_params, const vrnet_planes_out* outp, void* workspace,
+                             long workspace_bytes, void* stream);
 extern "C" int vrnet_gn_apply_bwd(const float* dy, long lddy, const float* x, long ldx, const float* mean_rstd,
                                   const float* gamma, int B, long HW, int C, const float* add, long ldadd, float* out, long ldo,
                                   float* dgamma, float* dbeta, int accumulate_params, void* workspace, long workspace_bytes,
                                   void* stream) {
-  VR_CHECK_ARG(dy && x && mean_rstd && gamma && out && dgamma && dbeta && workspace, "gn_apply_bwd: null tensor");
+  return gn_apply_bwd_impl(dy, lddy, x, ldx, mean_rstd, gamma, B, HW, C, add, ldadd, out, ldo, dgamma, dbeta, accumulate_params,
+                           nullptr, workspace, workspace_bytes, stream);
+}
+/* The same with a second copy of `out` as bf16 planes: the gradient a block hands to the block before it is the dy operand
+ * of that block's data- and weight-gradient GEMMs. */
+extern "C" int vrnet_gn_apply_bwd_planes(const float* dy, long lddy, const float* x, long ldx, const float* mean_rstd,
+                                         const float* gamma, int B, long HW, int C, const float* add, long ldadd, float* out,
+                                         long ldo, float* dgamma, float* dbeta, int accumulate_params,
+                                         const vrnet_planes_out* outp, void* workspace, long workspace_bytes, void* stream) {
+  return gn_apply_bwd_impl(dy, lddy, x, ldx, mean_rstd, gamma, B, HW, C, add, ldadd, out, ldo, dgamma, dbeta, accumulate_params,
+                           outp, workspace, workspace_bytes, stream);
+}
+static int gn_apply_bwd_impl(const float* dy, long lddy, const float* x, long ldx, const float* mean_rstd,
+                             const float* gamma, int B, long HW, int C, const float* add, long ldadd, float* out, long ldo,
+                             float* dgamma, float* dbeta, int accumulate_params, const vrnet_planes_out* outp, void* workspace,
+                             long workspace_bytes, void* stream) {
+  VR_CHECK_ARG(dy && x && mean_rstd && gamma && out && dgamma && dbeta && workspace && vr_planes_out_ok(outp, C), "gn_apply_bwd: null tensor");
   VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (!add || ldadd % 4 == 0) &&
                    vr_aligned16(dy) && vr_aligned16(x) && vr_aligned16(out) && vr_aligned16(gamma) && (!add || vr_aligned16(add)),
                "gn_apply_bwd: needs C %% 4 == 0 and 16-byte aligned rows");
@@ -945,7 +981,7 @@ extern "C" int vrnet_gn_apply_bwd(const float* dy, long lddy, const float* x, lo
   if (bx < need) bx = need;
   hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3((unsigned)bx, B + 1), dim3(256), 0, st, dy, lddy, x, ldx, gtot, nchunks * ncb,
                      reinterpret_cast<double*>(workspace), nchunks, mean_rstd, gamma, B, HW, C, add, ldadd, out, ldo, dgamma, dbeta,
-                     accumulate_params);
+                     accumulate_params, outp ? *outp : vrnet_planes_out{});
   VR_LAUNCH_CHECK("gn_apply_bwd");
   return VR_OK;
 }
@@ -970,7 +1006,7 @@ extern "C" int vrnet_gn_apply_bwd_from_partials(const float* dy, long lddy, cons
   const int nchunks = (int)(HW / 32);
   hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3((unsigned)bx, B + 1), dim3(256), 0, vr_stream(stream), dy, lddy, x, ldx, tile_totals,
                      nchunks * (int)vr_cdiv(C, 32), partial, nchunks, mean_rstd, gamma, B, HW, C, add, ldadd, out, ldo, dgamma, dbeta,
-                     accumulate_params);
+                     accumulate_params, vrnet_planes_out{});
   VR_LAUNCH_CHECK("gn_apply_bwd_from_partials");
   return VR_OK;
 }

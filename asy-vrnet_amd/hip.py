@@ -33,6 +33,14 @@ _SIGS = {
     "vrnet_conv_planes_bytes": ([I, I], L),
     "vrnet_conv_planes_pack_f32": ([P, I, L, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
+    "vrnet_gemm_planes_ok": ([L, I, I], I),
+    "vrnet_gemm_planes_f32": ([P, L, L, P, L, L, I, L, I, I, P, P, L, P, L, L, I, I, P, L, P, L, P, P, L, I, P, L, P, P], I),
+    "vrnet_planes_split_blocks": ([L, L], L),
+    "vrnet_planes_split_f32": ([P, I, L, I, P], I),
+    "vrnet_planes_from_f32": ([P, L, L, L, P, L, L, I, P], I),
+    "vrnet_wgrad_planes_ok": ([L, I, I], I),
+    "vrnet_wgrad_planes_workspace": ([L, I, I], L),
+    "vrnet_wgrad_planes_f32": ([P, L, L, P, L, L, I, L, I, I, P, P, P, I, P, P, P, P, L, P], I),
     "vrnet_conv2d_dma_tile": ([L, I], I),
     "vrnet_conv2d_wgrad_workspace": ([I] * 8, L),
     "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 14 + [P, P, P, P, P, P, P, P, P, P, L, P], I),
@@ -126,7 +134,7 @@ class ConvGnInput(ctypes.Structure):
     _fields_ = [("pairs", P), ("pairs_per_sample", L), ("gamma", P), ("beta", P), ("eps", F), ("HW", L), ("mean_rstd", P)]
 
 
-_DTYPES = frozenset((torch.float32, torch.float64, torch.uint8, torch.int64, torch.int32))
+_DTYPES = frozenset((torch.float32, torch.float64, torch.uint8, torch.int64, torch.int32, torch.bfloat16))
 
 
 def tuning_build():
@@ -227,6 +235,76 @@ def conv_planes_bytes(J, K):
 def conv_planes_pack(table, nentries, total_blocks):
     """table: int64 device tensor, 8 values per entry (vrnet_conv_planes_pack_f32)."""
     _check(_lib.vrnet_conv_planes_pack_f32(ptr(table), nentries, total_blocks, stream()), "conv_planes_pack")
+
+
+# ---- plane tensors (csrc/pgemm.hip): an fp32 tensor as three bf16 planes, t = p0 + p1 + p2 exactly, or (np = 1) a bf16 tensor
+class Planes:
+    """bf16 planes of a (rows, C) matrix: `t` is a (np, ..., C) bfloat16 tensor, plane q = t[q]; `ld` row stride, `plane`
+    plane stride (elements).  np = 3: the fp32 values, exactly (float(t).sum(0) in the order p2 + p1 + p0 reproduces them);
+    np = 1: the values rounded to bf16."""
+    __slots__ = ("t", "np", "ld", "plane", "C")
+
+    def __init__(self, t, ld=None, plane=None):
+        assert t.dtype == torch.bfloat16 and t.stride(-1) == 1
+        self.t, self.np, self.C = t, t.shape[0], t.shape[-1]
+        self.ld = t.stride(-2) if ld is None else ld
+        self.plane = t.stride(0) if plane is None else plane
+
+    @staticmethod
+    def empty(np_, shape, device):
+        return Planes(torch.empty((np_,) + tuple(shape), dtype=torch.bfloat16, device=device))
+
+    def float(self):
+        """The fp32 tensor the planes stand for (exact for np = 3)."""
+        f = self.t.float()
+        return f[0] if self.np == 1 else (f[2] + f[1]) + f[0]
+
+
+def gemm_planes_ok(rows, cols, K):
+    """Whether gemm_planes has a kernel for a rows x cols product over a contraction of K."""
+    return bool(_lib.vrnet_gemm_planes_ok(rows, cols, K))
+
+
+def gemm_planes(a, b, M, N, K, bias=None, y=None, ldy=0, yp=None, act=0, ypre=None, ldypre=0, res=None, ldres=0,
+                res_scale=None, aux=None, ldaux=0, accumulate=0, stats=None, stats_hw=0, colstats=None):
+    """y / yp = epilogue(A . B^T) on plane operands a, b (Planes, same np); y: fp32 tensor or None, yp: Planes or None."""
+    assert a.np == b.np
+    cs = None
+    if colstats is not None:
+        part, x2, ldx2, gam, tot = colstats
+        cs = ctypes.byref(ConvColStats(ptr(part), ptr(x2), ldx2, ptr(gam), ptr(tot)))
+    _check(_lib.vrnet_gemm_planes_f32(ptr(a.t), a.ld, a.plane, ptr(b.t), b.ld, b.plane, a.np, M, N, K, ptr(bias), ptr(y), ldy,
+                                      None if yp is None else ptr(yp.t), 0 if yp is None else yp.ld,
+                                      0 if yp is None else yp.plane, 0 if yp is None else yp.np, act, ptr(ypre), ldypre,
+                                      ptr(res), ldres, ptr(res_scale), ptr(aux), ldaux, accumulate, ptr(stats), stats_hw, cs,
+                                      stream()), "gemm_planes")
+
+
+def planes_split_blocks(R, K):
+    return _lib.vrnet_planes_split_blocks(R, K)
+
+
+def planes_split(table, nentries, total_blocks, np_):
+    """table: int64 device tensor, 10 values per entry (vrnet_planes_split_f32)."""
+    _check(_lib.vrnet_planes_split_f32(ptr(table), nentries, total_blocks, np_, stream()), "planes_split")
+
+
+def planes_from_f32(src, lds, R, K, out):
+    """out (Planes) = the row-major fp32 matrix `src` (R rows of K values, row stride lds)."""
+    _check(_lib.vrnet_planes_from_f32(ptr(src), lds, R, K, ptr(out.t), out.ld, out.plane, out.np, stream()), "planes_from_f32")
+
+
+def wgrad_planes_ok(M, Cin, Cout):
+    return bool(_lib.vrnet_wgrad_planes_ok(M, Cin, Cout))
+
+
+def wgrad_planes(x, dy, M, Cin, Cout, dw, dbias=None, row_scale=None, accumulate=0, w=None, bias=None, dls=None):
+    """dw (+ dbias, + dls) of a 1x1 conv from plane operands x (M x Cin) and dy (M x Cout) (vrnet_wgrad_planes_f32)."""
+    assert x.np == dy.np
+    ws = _ws.get(_lib.vrnet_wgrad_planes_workspace(M, Cin, Cout), dw.device)
+    _check(_lib.vrnet_wgrad_planes_f32(ptr(x.t), x.ld, x.plane, ptr(dy.t), dy.ld, dy.plane, x.np, M, Cin, Cout, ptr(dw), ptr(dbias),
+                                       ptr(row_scale), accumulate, ptr(w), ptr(bias), ptr(dls), ptr(ws), ws.numel(), stream()),
+           "wgrad_planes")
 
 
 def bf16_conv_ok(lda, Cin, Cout, mode):

@@ -83,17 +83,20 @@ def pmc_traffic_bytes(phi):
 
 
 def x6_issue_ceiling():
-    """Best measured rate of the register-resident x6 loop with in-register operand splits (tools/micro/x6_peak.hip), read
-    from the committed micro-benchmark output; None when no such file exists."""
+    """(rate, file) of the register-resident x6 loop with in-register operand splits (tools/micro/x6_peak.hip), read from
+    the NEWEST round's committed micro-benchmark output only (an older round's file may describe other kernel sources);
+    (None, None) when no such file exists."""
     import glob
     import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_x6_issue_ceiling_micro.txt")))
+    if not files:
+        return None, None
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_x6_issue_ceiling_micro.txt"))):
-        for line in open(f):
-            m = re.match(r"\s*2x2 both .*?:\s*[\d.]+ ms\s+([\d.]+) TF", line)
-            if m:
-                best = max(best or 0.0, float(m.group(1)))
-    return best
+    for line in open(files[-1]):
+        m = re.match(r"\s*2x2 both .*?:\s*[\d.]+ ms\s+([\d.]+) TF", line)
+        if m:
+            best = max(best or 0.0, float(m.group(1)))
+    return best, "profiles/" + os.path.basename(files[-1])
 
 
 def conv_flops(B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil):
@@ -417,9 +420,33 @@ def main():
     roof = None
     if not args.no_roofline:
         model.concurrent = False      # serial launches: an event pair then brackets exactly one kernel
+        # An event pair around a HOST call times GPU work only while the stream is still busy when the host records the
+        # first event; on a drained stream the pair also spans the host's launch latency (round 3: the driver's line read
+        # 27 % lower than rocprofv3 on the same build for exactly that reason).  So every instrumented step is issued
+        # behind a device-side gate -- a spin kernel longer than the host needs to issue the whole step -- and the host
+        # runs ahead of the GPU throughout: every pair then brackets kernel execution (plus the ~1-2 us dispatch gap).
+        eager_step(args.warmup)                      # serial-mode warm-up (allocator pools of the serial schedule)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eager_step(args.warmup)
+        host_issue_ms = 1e3 * (time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        torch.cuda._sleep(20_000_000)
+        c1.record()
+        torch.cuda.synchronize()
+        cycles_per_ms = 20_000_000 / max(c0.elapsed_time(c1), 1e-3)
+        gate_ms = 1.6 * host_issue_ms + 10.0         # ConvTimer's event records lengthen the issue time
+        ahead = 0
         with ConvTimer(hip) as ct:
             for i in range(args.steps):
+                torch.cuda.synchronize()
+                torch.cuda._sleep(int(gate_ms * cycles_per_ms))
+                gate_end = torch.cuda.Event()
+                gate_end.record()
                 eager_step(args.warmup + i)
+                ahead += 0 if gate_end.query() else 1      # gate still spinning when the last launch was issued
             n, flops, ms = ct.summary("igemm")
             nw, fw, msw = ct.summary("wgrad")
             fam, ideal_ms = ct.by_family("igemm")
@@ -449,14 +476,23 @@ def main():
                 "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
                 "frac": round(ach / peak, 4),
                 "peak_note": "FLOP-weighted matrix-pipe ceiling of the kernel mix that ran (x6 416.7 = bf16 2500 / 6; fp32 MFMA 157.3)",
-                "x6_issue_ceiling": {"value": x6_issue_ceiling(), "unit": "TFLOP/s (fp32-equivalent)",
-                                     "note": "measured, register-resident x6 loop: the fragment splits (VALU) and the MFMAs do not "
-                                             "overlap on gfx950, their times add -- tools/micro/x6_peak.hip, "
-                                             "profiles/r02_x6_issue_ceiling_micro.txt"},
+                "x6_issue_ceiling": {"value": x6_issue_ceiling()[0], "unit": "TFLOP/s (fp32-equivalent)",
+                                     "note": "measured, register-resident x6 loop with in-register operand splits (the kernels "
+                                             "that take pre-split operands have no such VALU share) -- tools/micro/x6_peak.hip, "
+                                             + str(x6_issue_ceiling()[1])},
                 "achieved_over_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 "families": fam_rep,
                 "traffic": pmc_traffic_bytes(args.phi) if (args.batch == 8 and args.size == 512 and not bf16) else None,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/; null unless measured on this exact kernel source)",
+                "timing": {"method": "HIP events around every launch of a serialised replay; each replayed step is issued "
+                                     "behind a device-side gate so that the host runs ahead and a pair brackets GPU execution only",
+                           "gate_ms": round(gate_ms, 1), "host_issue_ms_per_step": round(host_issue_ms, 1),
+                           "steps_issued_entirely_ahead_of_the_gpu": f"{ahead}/{args.steps}"},
+                # all dense-conv work of the step (forward, data and weight gradients, fused Mlp) over the TIMED step time
+                "step_level": {"conv_gflop_per_step": round((flops + fw) / args.steps / 1e9, 2),
+                               "achieved": round((flops + fw) / args.steps / (ms_per_step * 1e-3) / 1e12, 2),
+                               "unit": "TFLOP/s (fp32-equivalent) = conv FLOPs of one step / ms_per_step",
+                               "frac_of_mix_peak": round((flops + fw) / args.steps / (ms_per_step * 1e-3) / 1e12 / peak, 4)},
                 "launches_per_step": n // args.steps, "avg_launch_us": round(1e3 * ms / n, 2),
                 "avg_launch_gflop": round(flops / n / 1e9, 3),
                 "share_of_step": round(ms / args.steps / ms_per_step, 3),

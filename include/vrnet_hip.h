@@ -120,6 +120,46 @@ int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias
 long vrnet_conv_planes_bytes(int J, int K);
 int vrnet_conv_planes_pack_f32(const long* table, int nentries, long total_blocks, void* stream);
 
+/* ---- Plane GEMMs (round 4, csrc/pgemm.hip): the 1x1 convolutions of the ClusterBlocks (fc1 | fc_v, the Cluster's proj, the
+ * Mlp's fc1 / fc2: backbone/fusion/vr_coc.py:145-147, 187, 205-207, neck variant backbone/vision/context_cluster.py:211-216)
+ * and their data gradients on operands that ALREADY ARE bf16 planes in HBM, so that the GEMM main loop is LDS-DMA +
+ * ds_read_b128 + MFMA with no VALU work on operands.
+ *   plane tensor: element (r, k) of plane q at base[q * plane + r * ld + k], bf16; ld and plane multiples of 8, base 16-byte
+ *   aligned.  np = 3: an fp32 tensor t split EXACTLY, t = p0 + p1 + p2 (round-to-nearest-even at each step; written by the
+ *   producing kernel's epilogue, by vrnet_planes_split_f32 for the weights of a step, or by vrnet_planes_from_f32); products
+ *   a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1 accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- the x6 scheme of precision 2
+ *   with the same error bound.  np = 1: bf16 tensors, one product (compute_dtype "bf16": bf16 activations in HBM).
+ * vrnet_gemm_planes_f32: y[M][N] = epilogue(A[M][K] . B[N][K]^T); forward: A = activations, B = w[Cout][Cin]; data gradient:
+ * A = dy, B = transposed weights with the layer scale folded in.  Epilogue as vrnet_conv2d_f32: bias, aux (x gelu'(aux)),
+ * ypre, act (0 / 1 ReLU / 2 GELU), res (+ res_scale), accumulate, stats (fp64 (sum, sumsq) per 32 x 32 tile; stats_hw = rows
+ * per sample), colstats.  The result goes to `y` (fp32; may be NULL) and / or to `yp` as planes (yp_np 3 or 1).
+ * K % 32 == 0, N % 4 == 0; ask vrnet_gemm_planes_ok for shapes with too few 128 x 128 tiles.  Kernel families 10 (np 3), 11 (np 1). */
+int vrnet_gemm_planes_ok(long rows, int cols, int K);
+int vrnet_gemm_planes_f32(const void* a, long lda, long a_plane, const void* b, long ldb, long b_plane, int np, long M, int N,
+                          int K, const float* bias, float* y, long ldy, void* yp, long ldyp, long yp_plane, int yp_np, int act,
+                          float* ypre, long ldypre, const float* res, long ldres, const float* res_scale, const float* aux,
+                          long ldaux, int accumulate, double* stats, long stats_hw, const vrnet_conv_colstats* colstats,
+                          void* stream);
+/* fp32 matrices -> planes in one launch for a table of matrices (the weights of a step).  Entry (10 longs): source address,
+ * rows R, contraction K, source element strides (row, k), address of a scale per k or 0 (the layer scale of a data-gradient
+ * pack), destination address, destination row stride, destination plane stride, first block (running sum of
+ * vrnet_planes_split_blocks). */
+long vrnet_planes_split_blocks(long R, long K);
+int vrnet_planes_split_f32(const long* table, int nentries, long total_blocks, int np, void* stream);
+/* One row-major fp32 matrix (R rows of K values, row stride lds) -> planes: conversion pass for an activation tensor whose
+ * producer has no plane output. */
+int vrnet_planes_from_f32(const float* src, long lds, long R, long K, void* dst, long ld, long plane, int np, void* stream);
+/* Weight (+ bias, + layer-scale) gradient of a 1x1 conv on plane operands: dw[Cout][Cin] (+)= row_scale[n] * sum_m dy[m][n] *
+ * x[m][c]; dbias, row_scale, accumulate, (w, bias, dls) as vrnet_conv2d_wgrad_f32 (autograd of vr_coc.py:145-147, 187, 205-207).
+ * x: planes of the conv's input (M rows of Cin), dy: planes of the output gradient (M rows of Cout), same np.  The fragments
+ * -- 8 consecutive rows of one column -- are read with ds_read_b64_tr_b16; no operand is split in the kernel (the in-kernel
+ * split weight gradient splits four fragments per 24 MFMAs).  Channel counts multiples of 8.  Families 12 (np 3) / 13 (np 1). */
+int vrnet_wgrad_planes_ok(long M, int Cin, int Cout);
+long vrnet_wgrad_planes_workspace(long M, int Cin, int Cout);
+int vrnet_wgrad_planes_f32(const void* x, long ldx, long x_plane, const void* dy, long lddy, long dy_plane, int np, long M, int Cin,
+                           int Cout, float* dw, float* dbias, const float* row_scale, int accumulate, const float* w,
+                           const float* bias, float* dls, void* workspace, long workspace_bytes, void* stream);
+
 /* Weight (+ bias) gradient of the same convolutions (autograd of nn.Conv2d): dw in OIHW layout
  * [Cout][Cin][kh][kw], dbias[Cout] (NULL = none), both scaled by row_scale[Cout] when given (layer scale).
  * Deterministic split over output pixels into fp32 slabs in `workspace` (size from ..._workspace).
