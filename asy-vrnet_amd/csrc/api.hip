@@ -1,11 +1,12 @@
 // Library-level entry points: ABI version and the last-error string (thread local).
 #include "common.h"
 
+#include <atomic>
 #include <cstring>
 
 static thread_local char g_err[512] = "";
 static thread_local int g_last_kernel = 0;
-static thread_local long g_kernel_count[16] = {0};
+static std::atomic<long> g_kernel_count[16];      // process-wide: the backward pass runs on autograd's own thread
 void vr_note_kernel(int id) {
   g_last_kernel = id;
   if (id >= 0 && id < 16) ++g_kernel_count[id];
@@ -34,9 +35,10 @@ extern "C" int vrnet_tuning_build(void) { return 0; }
 //   1 fp32 MFMA register-staged   2 fp32 MFMA LDS-DMA ring   3 bf16-rounded operands   4 direct (tiny channel counts)
 //   6 six exact bf16 x bf16 products per fp32 product (x6), LDS-DMA ring
 extern "C" int vrnet_last_kernel(void) { return g_last_kernel; }
-/* Launches of kernel family `family` (the codes of vrnet_last_kernel) issued by the calling thread since the library was
- * loaded: lets a caller assert which kernels a whole forward / backward pass actually ran on. */
-extern "C" long vrnet_kernel_launches(int family) { return (family >= 0 && family < 16) ? g_kernel_count[family] : 0; }
+/* Launches of kernel family `family` (the codes of vrnet_last_kernel) issued by this process since the library was loaded
+ * (all threads: autograd runs the backward pass on a thread of its own): lets a caller assert which kernels a whole
+ * forward / backward pass actually ran on. */
+extern "C" long vrnet_kernel_launches(int family) { return (family >= 0 && family < 16) ? g_kernel_count[family].load() : 0; }
 
 void vr_set_error(const char* fmt, ...) {
   va_list ap;

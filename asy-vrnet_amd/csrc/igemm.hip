@@ -1766,6 +1766,9 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
     if (!x6_wgrad || Cout <= 32 || Cin <= 32) return;
     const int tn = Cout > 64 ? 2 : 1, tc = Cin > 64 ? 2 : 1;
     if (tn == 1 && tc == 1) return;
+    // (128 x 256 / 256 x 128 tiles -- 2 x 4 accumulators per wave, six fragment splits per 48 MFMAs instead of four per 24 --
+    // were measured in round 4: 8-45 % SLOWER on every shape of the net alone (8 192 x 320 x 1 280: 63.5 -> 70.2 us) and
+    // 0.1-0.2 ms per step slower: at two workgroups per CU the loop loses more to latency than the splits cost.)
     *cfg = 10 * tn + tc; *bn = 64 * tc;
     *n_tiles = (int)vr_cdiv(Cout, 64 * tn); *c_tiles = (int)vr_cdiv(Cin, 64 * tc);
     const long tiles = (long)*n_tiles * *c_tiles * T;

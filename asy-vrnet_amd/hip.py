@@ -58,6 +58,10 @@ _SIGS = {
     "vrnet_gn_stats_fwd": ([P, L, P, P, F, I, L, I, P, P, P, P, P, P, P, L, P], I),
     "vrnet_gn_coef_bwd": ([P, P, P, I, L, I, P, P, P, P, P, P, I, P, P, P, P], I),
     "vrnet_gn_apply_fwd": ([P, L, P, L, P, P, F, I, L, I, P, L, P, P], I),
+    "vrnet_gn_apply_fwd_planes": ([P, L, P, L, P, P, F, I, L, I, P, L, P, P, P], I),
+    "vrnet_gn_apply_bwd_planes": ([P, L, P, L, P, P, I, L, I, P, L, P, L, P, P, I, P, P, L, P], I),
+    "vrnet_cluster_fwd_planes_f32": ([P, P, L, P, P, P, L, P, P, I, I, I, I, I, I, I, P, P], I),
+    "vrnet_cluster_bwd_planes_f32": ([P, P, L, P, P, P, P, L, P, P, L, P, P, I, I, I, I, I, I, I, P, P, L, P], I),
     "vrnet_gn_bwd_workspace": ([I, L, I], L),
     "vrnet_gn_apply_bwd_from_partials": ([P, L, P, L, P, P, P, P, I, L, I, P, L, P, L, P, P, I, P], I),
     "vrnet_bn_coef_fwd_from_partials": ([P, P, P, F, F, P, P, P, I, L, I, P, P, P, P, P], I),
@@ -127,6 +131,15 @@ def _check(rc, name):
 class ConvColStats(ctypes.Structure):
     """vrnet_conv_colstats (include/vrnet_hip.h): optional column statistics of a conv's stored outputs."""
     _fields_ = [("partial", P), ("x2", P), ("ldx2", L), ("gamma", P), ("tile_totals", P)]
+
+
+class PlanesOut(ctypes.Structure):
+    """vrnet_planes_out (include/vrnet_hip.h): optional bf16-plane output of a producing kernel."""
+    _fields_ = [("p", P), ("ld", L), ("plane", L), ("np", I)]
+
+
+def _planes_out(pl):
+    return None if pl is None else ctypes.byref(PlanesOut(ptr(pl.t), pl.ld, pl.plane, pl.np))
 
 
 class ConvGnInput(ctypes.Structure):
@@ -413,15 +426,26 @@ def gn_apply_ok(C, *lds):
     return C % 4 == 0 and all(ld % 4 == 0 for ld in lds)
 
 
-def gn_apply_fwd(x, ldx, pairs, per_sample, gamma, beta, eps, B, HW, C, y, ldy, mean_rstd):
-    _check(_lib.vrnet_gn_apply_fwd(ptr(x), ldx, ptr(pairs), per_sample, ptr(gamma), ptr(beta), eps, B, HW, C, ptr(y), ldy,
-                                   ptr(mean_rstd), stream()), "gn_apply_fwd")
+def gn_apply_fwd(x, ldx, pairs, per_sample, gamma, beta, eps, B, HW, C, y, ldy, mean_rstd, planes=None):
+    """planes (Planes): the result also (y given) or only (y None) as bf16 planes."""
+    if planes is None:
+        _check(_lib.vrnet_gn_apply_fwd(ptr(x), ldx, ptr(pairs), per_sample, ptr(gamma), ptr(beta), eps, B, HW, C, ptr(y), ldy,
+                                       ptr(mean_rstd), stream()), "gn_apply_fwd")
+    else:
+        _check(_lib.vrnet_gn_apply_fwd_planes(ptr(x), ldx, ptr(pairs), per_sample, ptr(gamma), ptr(beta), eps, B, HW, C, ptr(y), ldy,
+                                              ptr(mean_rstd), _planes_out(planes), stream()), "gn_apply_fwd_planes")
 
 
-def gn_apply_bwd(dy, lddy, x, ldx, mean_rstd, gamma, B, HW, C, out, ldo, dgamma, dbeta, accumulate_params, add=None, ldadd=0):
+def gn_apply_bwd(dy, lddy, x, ldx, mean_rstd, gamma, B, HW, C, out, ldo, dgamma, dbeta, accumulate_params, add=None, ldadd=0,
+                 planes=None):
     ws = _ws.get(_lib.vrnet_gn_bwd_workspace(B, HW, C), x.device)
-    _check(_lib.vrnet_gn_apply_bwd(ptr(dy), lddy, ptr(x), ldx, ptr(mean_rstd), ptr(gamma), B, HW, C, ptr(add), ldadd, ptr(out),
-                                   ldo, ptr(dgamma), ptr(dbeta), accumulate_params, ptr(ws), ws.numel(), stream()), "gn_apply_bwd")
+    if planes is None:
+        _check(_lib.vrnet_gn_apply_bwd(ptr(dy), lddy, ptr(x), ldx, ptr(mean_rstd), ptr(gamma), B, HW, C, ptr(add), ldadd, ptr(out),
+                                       ldo, ptr(dgamma), ptr(dbeta), accumulate_params, ptr(ws), ws.numel(), stream()), "gn_apply_bwd")
+    else:
+        _check(_lib.vrnet_gn_apply_bwd_planes(ptr(dy), lddy, ptr(x), ldx, ptr(mean_rstd), ptr(gamma), B, HW, C, ptr(add), ldadd,
+                                              ptr(out), ldo, ptr(dgamma), ptr(dbeta), accumulate_params, _planes_out(planes),
+                                              ptr(ws), ws.numel(), stream()), "gn_apply_bwd_planes")
 
 
 def colstats_ok(HW, Cout, *lds):
@@ -536,16 +560,30 @@ def fill_(dst, value):
     _check(_lib.vrnet_fill_f32(ptr(dst), float(value), dst.numel(), stream()), "fill")
 
 
-def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold, alpha2=None, beta2=None, forced=False):
-    """forced: idx is given (read), not computed (teacher-forced assignment for parity comparisons)."""
+def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold, alpha2=None, beta2=None, forced=False,
+                planes=None):
+    """forced: idx is given (read), not computed (teacher-forced assignment for parity comparisons).
+    planes (Planes): a second copy of `out` as bf16 planes (single-stream launches)."""
+    if planes is not None:
+        assert alpha2 is None
+        _check(_lib.vrnet_cluster_fwd_planes_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(out), ldo, ptr(idx), ptr(wgt), B, H,
+                                                 W, E, Dh, fold, 1 if forced else 0, _planes_out(planes), stream()), "cluster_fwd_planes")
+        return
     fn = _lib.vrnet_cluster_fwd_forced_f32 if forced else _lib.vrnet_cluster_fwd_f32
     _check(fn(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(out), ldo, ptr(idx), ptr(wgt), B, H,
                                       W, E, Dh, fold, ptr(alpha2), ptr(beta2), stream()), "cluster_fwd")
 
 
 def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, dbeta, accumulate_ab, B, H, W, E, Dh,
-                fold, alpha2=None, beta2=None, dalpha2=None, dbeta2=None):
+                fold, alpha2=None, beta2=None, dalpha2=None, dbeta2=None, planes=None):
+    """planes (Planes of 2 E Dh columns): a second copy of [df | dv] as bf16 planes (single-stream launches)."""
     ws = _ws.get(_lib.vrnet_cluster_bwd_workspace2(B, H, W, E, fold), f.device)
+    if planes is not None:
+        assert alpha2 is None
+        _check(_lib.vrnet_cluster_bwd_planes_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(idx), ptr(dout), lddo, ptr(df),
+                                                 ptr(dv), lddf, ptr(dalpha), ptr(dbeta), accumulate_ab, B, H, W, E, Dh, fold,
+                                                 _planes_out(planes), ptr(ws), ws.numel(), stream()), "cluster_bwd_planes")
+        return
     _check(_lib.vrnet_cluster_bwd_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(idx), ptr(dout), lddo, ptr(df),
                                       ptr(dv), lddf, ptr(dalpha), ptr(dbeta), accumulate_ab, B, H, W, E, Dh, fold,
                                       ptr(alpha2), ptr(beta2), ptr(dalpha2), ptr(dbeta2), ptr(ws), ws.numel(), stream()),

@@ -453,7 +453,209 @@ def _(images_u8, pngs_u8, num_classes_seg):
             pngs_u8.new_empty((B, H, W, num_classes_seg + 1), dtype=torch.float32))
 
 
+# ---- ShuffleAttention (backbone/attention_modules/shuffle_attention.py:48-72) --------------------------------------------
+@torch.library.custom_op("vrnet::shuffle_attention", mutates_args=(), device_types="cuda")
+def shuffle_attention(x: torch.Tensor, cweight: torch.Tensor, cbias: torch.Tensor, sweight: torch.Tensor, sbias: torch.Tensor,
+                      gn_weight: torch.Tensor, gn_bias: torch.Tensor, groups: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """x: (B,H,W,C) NHWC fp32; the six parameters as in ShuffleAttention.state_dict() (any shape, C / (2 G) elements each).
+    Returns (y, per-(sample, channel) moments, P, Q, Mn): the last four are what the backward pass re-uses."""
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    params = [t.contiguous().reshape(-1) for t in (cweight, cbias, sweight, sbias, gn_weight, gn_bias)]
+    with torch.cuda.device(x.device):
+        mom = hip.moments(x, C, B, H * W, C)
+        P, Q, Mn = (torch.empty((B, C), dtype=torch.float32, device=x.device) for _ in range(3))
+        hip.sa_coef_fwd(mom, *params, B, H * W, C, groups, P, Q, Mn)
+        y = torch.empty_like(x)
+        hip.sa_apply(x, C, P, Q, Mn, y, C, B, H * W, C)
+    return y, mom, P, Q, Mn
+
+
+@shuffle_attention.register_fake
+def _(x, cweight, cbias, sweight, sbias, gn_weight, gn_bias, groups):
+    B, _, _, C = x.shape
+    return (torch.empty_like(x), x.new_empty((B, C, 2), dtype=torch.float64), x.new_empty((B, C)), x.new_empty((B, C)),
+            x.new_empty((B, C)))
+
+
+@torch.library.custom_op("vrnet::shuffle_attention_backward", mutates_args=(), device_types="cuda")
+def shuffle_attention_backward(g: torch.Tensor, x: torch.Tensor, mom: torch.Tensor, P: torch.Tensor, Q: torch.Tensor, Mn: torch.Tensor,
+                               cweight: torch.Tensor, cbias: torch.Tensor, sweight: torch.Tensor, sbias: torch.Tensor,
+                               gn_weight: torch.Tensor, gn_bias: torch.Tensor, groups: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    g, x = g.contiguous(), x.contiguous()
+    B, H, W, C = x.shape
+    plist = (cweight, cbias, sweight, sbias, gn_weight, gn_bias)
+    params = [t.contiguous().reshape(-1) for t in plist]
+    grads = [torch.empty(t.numel(), dtype=torch.float32, device=x.device) for t in plist]
+    dx = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        hip.sa_bwd(g, C, x, C, P, Q, Mn, mom, params, dx, C, grads, torch.empty((2, B, C), dtype=torch.float32, device=x.device),
+                   B, H * W, C, groups, 0, 0)
+    return (dx, *[gr.reshape(t.shape) for gr, t in zip(grads, plist)])
+
+
+@shuffle_attention_backward.register_fake
+def _(g, x, mom, P, Q, Mn, cweight, cbias, sweight, sbias, gn_weight, gn_bias, groups):
+    return (torch.empty_like(x), *[torch.empty_like(t) for t in (cweight, cbias, sweight, sbias, gn_weight, gn_bias)])
+
+
+def _sa_setup(ctx, inputs, output):
+    x, *params, groups = inputs
+    ctx.save_for_backward(x, *output[1:], *params)
+    ctx.groups = groups
+
+
+def _sa_bwd(ctx, g, *unused):
+    x, mom, P, Q, Mn, *params = ctx.saved_tensors
+    return (*torch.ops.vrnet.shuffle_attention_backward(g, x, mom, P, Q, Mn, *params, ctx.groups), None)
+
+
+shuffle_attention.register_autograd(_sa_bwd, setup_context=_sa_setup)
+
+
+# ---- ECA gate (backbone/attention_modules/eca.py:16-22) ------------------------------------------------------------------
+@torch.library.custom_op("vrnet::eca", mutates_args=(), device_types="cuda")
+def eca(x: torch.Tensor, weight: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """x: (B,H,W,C) NHWC fp32; weight: the Conv1d(1, 1, k) weight.  y = x * sigmoid(conv1d(mean over pixels)).
+    Returns (y, gate (B,C), moments)."""
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    wk = weight.contiguous().reshape(-1)
+    with torch.cuda.device(x.device):
+        mom = hip.moments(x, C, B, H * W, C)
+        gate = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        hip.eca_coef_fwd(mom, wk, wk.numel(), B, H * W, C, gate)
+        y = torch.empty_like(x)
+        hip.affine(y, C, B, H * W, C, x1=x, ld1=C, A=gate, bstride=C)
+    return y, gate, mom
+
+
+@eca.register_fake
+def _(x, weight):
+    B, _, _, C = x.shape
+    return torch.empty_like(x), x.new_empty((B, C)), x.new_empty((B, C, 2), dtype=torch.float64)
+
+
+@torch.library.custom_op("vrnet::eca_backward", mutates_args=(), device_types="cuda")
+def eca_backward(g: torch.Tensor, x: torch.Tensor, gate: torch.Tensor, mom: torch.Tensor, weight: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    g, x = g.contiguous(), x.contiguous()
+    B, H, W, C = x.shape
+    wk = weight.contiguous().reshape(-1)
+    with torch.cuda.device(x.device):
+        mom2 = hip.moments(g, C, B, H * W, C, x2=x, ldx2=C)
+        Fc = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        dwk = torch.empty(wk.numel(), dtype=torch.float32, device=x.device)
+        hip.eca_coef_bwd(mom2, mom, gate, wk, wk.numel(), B, H * W, C, Fc, dwk, 0)
+        dx = torch.empty_like(x)
+        hip.affine(dx, C, B, H * W, C, x1=g, ld1=C, A=gate, D2=Fc, bstride=C)
+    return dx, dwk.reshape(weight.shape)
+
+
+@eca_backward.register_fake
+def _(g, x, gate, mom, weight):
+    return torch.empty_like(x), torch.empty_like(weight)
+
+
+def _eca_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], output[1], output[2], inputs[1])
+
+
+def _eca_bwd(ctx, g, *unused):
+    x, gate, mom, weight = ctx.saved_tensors
+    return torch.ops.vrnet.eca_backward(g, x, gate, mom, weight)
+
+
+eca.register_autograd(_eca_bwd, setup_context=_eca_setup)
+
+
+# ---- the gain of ImageEnhanceByRadar (vr_coc.py:59-67, 314): (1 + data_normal(p)) * x -----------------------------------
+@torch.library.custom_op("vrnet::image_enhance", mutates_args=(), device_types="cuda")
+def image_enhance(p: torch.Tensor, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """p: the projected radar map ReLU(BN(conv3x3(radar))), x: the image map, both (B,H,W,C) NHWC fp32.  data_normal maps p to
+    [0, 1] with the minimum / maximum over the WHOLE batch tensor (when they coincide it only subtracts the minimum).
+    Returns (t = (1 + data_normal(p)) * x, (min, max))."""
+    p, x = p.contiguous(), x.contiguous()
+    with torch.cuda.device(x.device):
+        mm = torch.empty(2, dtype=torch.float32, device=x.device)
+        hip.minmax(p, p.numel(), mm)
+        t = torch.empty_like(x)
+        hip.enhance_mul(p, x, mm, t, p.numel())
+    return t, mm
+
+
+@image_enhance.register_fake
+def _(p, x):
+    return torch.empty_like(x), x.new_empty((2,))
+
+
+@torch.library.custom_op("vrnet::image_enhance_backward", mutates_args=(), device_types="cuda")
+def image_enhance_backward(g: torch.Tensor, p: torch.Tensor, x: torch.Tensor, mm: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    g, p, x = g.contiguous(), p.contiguous(), x.contiguous()
+    dx, dp = torch.empty_like(x), torch.empty_like(p)
+    with torch.cuda.device(x.device):
+        hip.enhance_bwd(g, x, p, mm, dx, dp, p.numel())
+    return dp, dx
+
+
+@image_enhance_backward.register_fake
+def _(g, p, x, mm):
+    return torch.empty_like(p), torch.empty_like(x)
+
+
+def _ie_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1], output[1])
+
+
+image_enhance.register_autograd(lambda ctx, g, g_mm: torch.ops.vrnet.image_enhance_backward(g, *ctx.saved_tensors),
+                                setup_context=_ie_setup)
+
+
+# ---- the gate of RadarEnhanceByImage (vr_coc.py:331-359): eca(shuffle(cat(image features, radar features))) -------------
+@torch.library.custom_op("vrnet::radar_enhance", mutates_args=(), device_types="cuda")
+def radar_enhance(a: torch.Tensor, r: torch.Tensor, weight: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """a: image features (after ShuffleAttention, or the raw image at the input stage), r: radar features, NHWC fp32; weight: the
+    ECA Conv1d weight.  u = eca(shuffle_channels(cat([a, r], C), 2)) -- the channel-wise gate in front of the inverse
+    projection -- with the concat + shuffle as ONE strided launch and the gate as moments + coefficient + scale.
+    Returns (u, gate, moments)."""
+    cat = torch.ops.vrnet.cat_shuffle(a, r, a.shape[-1] == r.shape[-1])
+    return torch.ops.vrnet.eca(cat, weight)
+
+
+@radar_enhance.register_fake
+def _(a, r, weight):
+    B, Ct = a.shape[0], a.shape[-1] + r.shape[-1]
+    return a.new_empty(a.shape[:-1] + (Ct,)), a.new_empty((B, Ct)), a.new_empty((B, Ct, 2), dtype=torch.float64)
+
+
+@torch.library.custom_op("vrnet::radar_enhance_backward", mutates_args=(), device_types="cuda")
+def radar_enhance_backward(g: torch.Tensor, a: torch.Tensor, r: torch.Tensor, gate: torch.Tensor, mom: torch.Tensor,
+                           weight: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    il = a.shape[-1] == r.shape[-1]
+    cat = torch.ops.vrnet.cat_shuffle(a, r, il)                      # recomputed: one strided copy instead of a stored tensor
+    dcat, dw = torch.ops.vrnet.eca_backward(g, cat, gate, mom, weight)
+    da, dr = torch.ops.vrnet.cat_shuffle_backward(dcat, a.shape[-1], il)
+    return da, dr, dw
+
+
+@radar_enhance_backward.register_fake
+def _(g, a, r, gate, mom, weight):
+    return torch.empty_like(a), torch.empty_like(r), torch.empty_like(weight)
+
+
+def _re_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1], output[1], output[2], inputs[2])
+
+
+def _re_bwd(ctx, g, *unused):
+    a, r, gate, mom, weight = ctx.saved_tensors
+    return torch.ops.vrnet.radar_enhance_backward(g, a, r, gate, mom, weight)
+
+
+radar_enhance.register_autograd(_re_bwd, setup_context=_re_setup)
+
+
 # Autocast policy (the reference trains under torch.cuda.amp.autocast, utils/utils_fit.py:86-88): these ops compute in fp32
 # whatever the autocast dtype, i.e. floating-point arguments are cast to fp32 on the way in.
-for _op in ("cluster", "conv2d_nhwc", "mlp", "group_norm1", "batch_norm_act", "dwconv3x3", "upsample_bilinear", "cat_shuffle"):
+for _op in ("cluster", "conv2d_nhwc", "mlp", "group_norm1", "batch_norm_act", "dwconv3x3", "upsample_bilinear", "cat_shuffle",
+            "shuffle_attention", "eca", "image_enhance", "radar_enhance"):
     torch.library.register_autocast(f"vrnet::{_op}", "cuda", torch.float32)

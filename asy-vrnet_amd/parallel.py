@@ -144,8 +144,10 @@ class GradBucketer:
 
     def check_layout_across_ranks(self):
         """Every rank derives the arena layout from ITS OWN recording pass; a rank that recorded something else (another
-        frozen set, an exception in its first backward) would reduce mismatched slices silently.  All ranks exchange the
-        layout hash and raise together on a mismatch."""
+        frozen set, another order of completion) would reduce mismatched slices silently.  All ranks that REACH this point
+        exchange the layout hash and raise together on a mismatch.  A rank whose first backward raised never gets here:
+        its peers then wait in this all_gather until the process group's timeout fires -- pass `timeout=` to
+        init_process_group for a bound (a rank that dies takes the job down through the launcher anyway)."""
         if not _dist_on(self.group) or dist.get_world_size(self.group) < 2:
             return
         dev = self.arena.device if self.arena is not None else "cpu"
@@ -266,9 +268,24 @@ class SyncBatchNormStats:
     def __init__(self, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if _dist_on(process_group) else 1
+        self.batch_total = None
 
-    def count(self, n_local):
-        return n_local * self.world
+    def begin_forward(self, batch_local, device):
+        """Once per forward pass: the number of samples over ALL ranks (torch.nn.SyncBatchNorm gathers the per-rank counts
+        too).  The ranks need not hold equal batches -- the reference's loaders drop the last batch (utils/dataloader.py,
+        drop_last=True), but an evaluation loop or a resumed run may not.  One tiny collective and one host read per
+        forward pass, issued by every rank unconditionally."""
+        if self.world > 1:
+            t = torch.tensor([batch_local], dtype=torch.int64, device=device)
+            dist.all_reduce(t, group=self.group)
+            self.batch_total = int(t.item())
+        else:
+            self.batch_total = batch_local
+
+    def count(self, batch_local, per_sample):
+        """Global element count per channel of a map with `per_sample` pixels per sample."""
+        total = self.batch_total if self.batch_total is not None else batch_local * self.world
+        return total * per_sample
 
     def total(self, mom):
         tot = mom.sum(0, keepdim=True)

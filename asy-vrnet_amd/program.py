@@ -25,7 +25,7 @@ class Act:
     samples first) so that a stage's ClusterBlocks run as one launch per layer; `half(k)` is the Act of one stream --
     a view whose gradient is the matching half of the parent's gradient buffer (`written[k]`: that half holds data)."""
     __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad", "pairs", "colpart", "parent", "slot", "written", "_halves",
-                 "__weakref__")
+                 "gradp", "want_gradp", "__weakref__")
 
     def __init__(self, t, need_grad=True):
         self.t = t
@@ -34,6 +34,8 @@ class Act:
         self.B, self.H, self.W, self.C = t.shape
         self.ld = t.stride(2)
         self.grad = None
+        self.gradp = None       # hip.Planes copy of `grad` (valid only while grad is the buffer it was written with)
+        self.want_gradp = 0     # np of the plane copy the consumer of d(act) would like to receive (0: none)
         self.need_grad = need_grad
         self.parent, self.slot, self.written, self._halves = None, 0, None, None
 
@@ -91,6 +93,10 @@ class RT:
                                     # identical, tested; same-call A/B: 27.0-27.3 ms with it at any K threshold, 26.8-27.1 without --
                                     # the per-workgroup statistics prologue, the 16 extra VALU operations per K16 step and the
                                     # re-made tensor for the weight gradient cost what the 32 launches it removes were worth)
+        self.pnp = 0                # plane GEMMs (csrc/pgemm.hip) in the ClusterBlocks: 0 off, 3 fp32 values as three bf16 planes,
+                                    # 1 bf16 tensors (compute_dtype "bf16"); pg_fwd / pg_wgrad: which GEMM kinds take them
+        self.pg_fwd, self.pg_wgrad = True, True
+        self.pweights = None        # PlaneWeights: the weights of the plane GEMMs, split once per forward
         self.forced_idx = None      # {block name: (B,H,W,E) uint8}: Cluster assignments to replay instead of the arg-max (model.forced_idx_maps)
         self.sync_bn = None         # parallel.SyncBatchNormStats: BatchNorm statistics over all ranks (model._sync_bn)
         self.consts = {}
@@ -380,12 +386,16 @@ class RT:
             act.written = None
             return act.grad, 0
         _complete(act)
+        act.gradp = None
         return act.grad, 1
 
-    def give_grad(self, act, g):
-        """Hands an owned, contiguous gradient buffer to `act`."""
+    def give_grad(self, act, g, planes=None):
+        """Hands an owned, contiguous gradient buffer to `act` (planes: a bf16-plane copy of it, kept only when `g` becomes
+        the gradient as it is)."""
         if not act.need_grad:
             return
+        if planes is not None and act.parent is None and (act.grad is None or act.written == [False, False]):
+            act.gradp = planes
         if act.parent is not None:
             buf, acc = self.grad_target(act)
             if acc:
@@ -398,6 +408,7 @@ class RT:
             act.written = None
         else:
             _complete(act)
+            act.gradp = None
             hip.add_(act.grad, g)
 
 
@@ -427,6 +438,12 @@ def take_grad(act):
         _complete(act)
     act.grad = None
     return g
+
+
+def take_gradp(act):
+    """The plane copy of the gradient take_grad just returned (None: there is none)."""
+    gp, act.gradp = act.gradp, None
+    return gp
 
 
 def _pair(m):
@@ -597,7 +614,7 @@ def bn_forward(rt, z, bn, relu, out=None, residual=None):
         # synchronised BatchNorm: per-sample moments -> sum over samples and ranks -> coefficients with the global count
         tot = rt.sync_bn.total(hip.moments(z.t, z.ld, B, HW, C))
         hip.bn_coef_fwd(tot, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                        bn.num_batches_tracked, True, 1, rt.sync_bn.count(B * HW), C, A, D, S, ms)
+                        bn.num_batches_tracked, True, 1, rt.sync_bn.count(B, HW), C, A, D, S, ms)
         z.colpart = None
     elif rt.training and z.colpart is not None:
         hip.bn_coef_fwd_from_partials(z.colpart, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
@@ -633,7 +650,7 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
         mom2 = hip.moments(dy, lddy, B, HW, C, x2=z.t, ldx2=z.ld, mask=None if mask is None else mask.t,
                            ldm=0 if mask is None else mask.ld)
         tot2 = rt.sync_bn.total(mom2)
-        hip.bn_coef_bwd(tot2, ms, bn.weight, True, 1, rt.sync_bn.count(B * HW), C, A, E, D, S, rt.buf(C), rt.buf(C), 0)
+        hip.bn_coef_bwd(tot2, ms, bn.weight, True, 1, rt.sync_bn.count(B, HW), C, A, E, D, S, rt.buf(C), rt.buf(C), 0)
         hip.bn_coef_bwd(mom2, ms, bn.weight, True, B, HW, C, rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C), gw, gb, accw)
     else:
         hip.bn_stats_bwd(dy, lddy, z.t, z.ld, None if mask is None else mask.t, 0 if mask is None else mask.ld, ms, bn.weight,
@@ -834,6 +851,12 @@ def cluster_block(rt, x, m, name=None):
     E, Dh, fold = tm0.heads, tm0.head_dim, tm0.fold
     ED = E * Dh
     rows_half = (B // 2) * H * W
+    if rt.pnp and not paired and C % 8 == 0 and ED % 8 == 0:
+        hid_ = mlp0.fc1.weight.shape[0]
+        pmlp_ = rt.prec_mlp(C, hid_, B * H * W, H * W)
+        plan = _planes_plan(rt, B * H * W, C, ED, hid_, bool(pmlp_))
+        if any(any(v) for v in plan.values()):
+            return cluster_block_planes(rt, x, m0, name, plan, pmlp_)
     wcat, bcat = tm0._fused_qkv                                  # [fc1 ; fc_v]: one GEMM, f | v side by side
     kwq = dict(pair_rows=rows_half, w2=tm1._fused_qkv[0], bias2=tm1._fused_qkv[1]) if paired else {}
     fv = rt.new(B, H, W, 2 * ED)
@@ -957,15 +980,274 @@ def cluster_block(rt, x, m, name=None):
     return x2
 
 
-def _fused_qkv_wgrad(rt, tm, xn, dfv):
-    """Weight / bias gradients of fc1 and fc_v as one GEMM into [2ED, C] | [2ED] (per stream), deferred off the critical
+def _planes_plan(rt, M, C, ED, hid, fused_mlp):
+    """Which GEMMs of a ClusterBlock of M pixels run on plane operands: {conv: (forward, data gradient, weight gradient)},
+    conv in fcfv / proj / fc1 / fc2 (rows x columns x contraction of each product; the Mlp convs only when the block has no
+    fused Mlp kernel)."""
+    def gemm(cols, K):
+        return rt.pg_fwd and M <= PG_MAX_ROWS and hip.gemm_planes_ok(M, cols, K)
+
+    def wg(ci, co):
+        return rt.pg_wgrad and M <= PG_MAX_ROWS and hip.wgrad_planes_ok(M, ci, co)
+    plan = {"fcfv": (gemm(2 * ED, C), gemm(C, 2 * ED), wg(C, 2 * ED)),
+            "proj": (gemm(C, ED), gemm(ED, C), wg(ED, C))}
+    if not fused_mlp:
+        plan["fc1"] = (gemm(hid, C), gemm(C, hid), wg(C, hid))
+        plan["fc2"] = (gemm(C, hid), gemm(hid, C), wg(hid, C))
+    else:
+        plan["fc1"] = plan["fc2"] = (False, False, False)
+    return plan
+
+
+def cluster_block_planes(rt, x, m, name, plan, pmlp):
+    """cluster_block for ONE stream with the GEMMs `plan` selects on plane operands (csrc/pgemm.hip): the tensors that are
+    only ever GEMM operands -- both GroupNorm outputs, the Cluster output, the Mlp hidden activation, and on the way back the
+    block's incoming gradient, d(pre-activation), d(residual) and [df | dv] -- are written as bf16 planes by the kernels that
+    produce them (np = 3: the fp32 value, exactly; np = 1: bf16 tensors) and the GEMMs split nothing.  A tensor keeps its fp32
+    form only while some consumer still wants it (a GEMM kind the plan leaves on the in-kernel-split kernels)."""
+    np_ = rt.pnp
+    pw = rt.pweights
+    tm, mlp = m.token_mixer, m.mlp
+    B, H, W, C = x.B, x.H, x.W, x.C
+    E, Dh, fold = tm.heads, tm.head_dim, tm.fold
+    ED, M, HW = E * Dh, B * H * W, H * W
+    hid = mlp.fc1.weight.shape[0]
+    wcat, bcat = tm._fused_qkv
+    ls1, ls2 = m.layer_scale_1, m.layer_scale_2
+    P = lambda c: hip.Planes.empty(np_, (B, H, W, c), x.t.device)
+    f32 = lambda c, ng=True: rt.new(B, H, W, c, need_grad=ng)
+    fcfv, proj, fc1, fc2 = plan["fcfv"], plan["proj"], plan["fc1"], plan["fc2"]
+    rec = rt.record
+
+    def stats_buf(c):
+        return hip.conv_stats_buffer(B, HW, c, x.t.device)
+
+    # ---- GroupNorm 1 -> [fc1 | fc_v]
+    xn_p = P(C) if (fcfv[0] or (rec and fcfv[2])) else None
+    xn_f = f32(C) if (not fcfv[0] or (rec and not fcfv[2])) else None
+    ms1 = rt.buf(B, 2)
+    if x.pairs is not None and hip.gn_apply_ok(C, x.ld):
+        hip.gn_apply_fwd(x.t, x.ld, x.pairs[0], x.pairs[1], m.norm1.weight, m.norm1.bias, m.norm1.eps, B, HW, C,
+                         None if xn_f is None else xn_f.t, C, ms1, planes=xn_p)
+    else:      # no tile statistics from the producer: the three-launch form, then one conversion pass
+        xn_f, ms1 = gn_forward(rt, x, m.norm1)
+        if xn_p is not None:
+            hip.planes_from_f32(xn_f.t, C, M, C, xn_p)
+    fv = f32(2 * ED)
+    if fcfv[0]:
+        hip.gemm_planes(xn_p, pw.fwd(wcat), M, 2 * ED, C, bias=bcat, y=fv.t, ldy=2 * ED)
+    else:
+        hip.conv2d(xn_f.t, C, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0,
+                   precision=rt.prec_fwd(C, C, 2 * ED), w_planes=rt.planes(wcat, 0, 2 * ED, C, M))
+    # ---- Cluster core -> proj
+    f_t, v_t = fv.t, fv.t[..., ED:]
+    o = f32(ED)
+    o_p = P(ED) if (proj[0] or (rec and proj[2])) else None
+    idx = rt.buf(B, H, W, E, dtype=torch.uint8)
+    big = (H // max(fold, 1)) * (W // max(fold, 1)) > 256
+    forced = rt.forced_idx is not None and name is not None and name in rt.forced_idx
+    if forced:
+        idx.copy_(rt.forced_idx[name])
+    hip.cluster_fwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, o.t, ED, idx, rt.buf(B, H, W, E) if big else None,
+                    B, H, W, E, Dh, fold, forced=forced, planes=o_p)
+    if name is not None:
+        rt.idx_maps[name] = idx
+    x1 = f32(C)
+    pr1, per1 = stats_buf(C)
+    if proj[0]:
+        hip.gemm_planes(o_p, pw.fwd(tm.fc2.weight), M, C, ED, bias=tm.fc2.bias, y=x1.t, ldy=C, res=x.t, ldres=x.ld, res_scale=ls1,
+                        stats=pr1, stats_hw=HW)
+        if pr1 is not None:
+            x1.pairs = (pr1, per1)
+    else:
+        conv_call(rt, o, tm.fc2, x1, res=x, res_scale=ls1, stats=True)
+    # ---- GroupNorm 2 -> Mlp
+    u = f32(hid, False) if rec else None
+    x2 = f32(C)
+    xn2_p = P(C) if (fc1[0] or (rec and fc1[2])) else None
+    xn2_f = f32(C) if (pmlp or not fc1[0] or (rec and not fc1[2])) else None
+    ms2 = rt.buf(B, 2)
+    if x1.pairs is not None and hip.gn_apply_ok(C, x1.ld):
+        hip.gn_apply_fwd(x1.t, x1.ld, x1.pairs[0], x1.pairs[1], m.norm2.weight, m.norm2.bias, m.norm2.eps, B, HW, C,
+                         None if xn2_f is None else xn2_f.t, C, ms2, planes=xn2_p)
+    else:
+        xn2_f, ms2 = gn_forward(rt, x1, m.norm2)
+        if xn2_p is not None:
+            hip.planes_from_f32(xn2_f.t, C, M, C, xn2_p)
+    h_f = h_p = packs = None
+    if pmlp:
+        packs = hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, pmlp, want_bwd=rec)
+        pairs, per = stats_buf(C)
+        hip.mlp_fwd(xn2_f.t, C, packs[0], mlp.fc1.bias, mlp.fc2.bias, x1.t, x1.ld, ls2, x2.t, C,
+                    None if u is None else u.t, hid, pairs, M, C, hid, pmlp)
+        if pairs is not None:
+            x2.pairs = (pairs, per)
+    else:
+        h_p = P(hid) if (fc2[0] or (rec and fc2[2])) else None
+        h_f = f32(hid) if (not fc2[0] or (rec and not fc2[2])) else None
+        if fc1[0]:
+            hip.gemm_planes(xn2_p, pw.fwd(mlp.fc1.weight), M, hid, C, bias=mlp.fc1.bias, y=None if h_f is None else h_f.t, ldy=hid,
+                            yp=h_p, act=2, ypre=None if u is None else u.t, ldypre=hid)
+        else:
+            conv_call(rt, xn2_f, mlp.fc1, h_f, act=2, ypre=u)
+            if h_p is not None:
+                hip.planes_from_f32(h_f.t, hid, M, hid, h_p)
+        pr2, per2 = stats_buf(C)
+        if fc2[0]:
+            hip.gemm_planes(h_p, pw.fwd(mlp.fc2.weight), M, C, hid, bias=mlp.fc2.bias, y=x2.t, ldy=C, res=x1.t, ldres=C,
+                            res_scale=ls2, stats=pr2, stats_hw=HW)
+            if pr2 is not None:
+                x2.pairs = (pr2, per2)
+        else:
+            conv_call(rt, h_f, mlp.fc2, x2, res=x1, res_scale=ls2, stats=True)
+    # the gradient this block would like to receive for x2 as planes: the dy operand of fc2's data / weight gradient
+    x2.want_gradp = np_ if (not pmlp and (fc2[1] or fc2[2])) else 0
+    want_dxp = x.want_gradp == np_          # whoever produced x wants ITS incoming gradient as planes
+
+    def planes_of(t2d, c, have):
+        """plane copy of a contiguous fp32 (M, c) tensor when no producer wrote one."""
+        if have is not None:
+            return have
+        pl = P(c)
+        hip.planes_from_f32(t2d, c, M, c, pl)
+        return pl
+
+    def wgrad(xf, xp, dyf, dyp, conv, cin, cout, use_planes, row_scale=None, ls=None):
+        """weight (+ bias, + layer-scale) gradient of a 1x1 conv, off the critical path."""
+        gw, accw = rt.pgrad(conv.weight)
+        gb, _ = (None, 0) if conv.bias is None else rt.pgrad(conv.bias)
+        gl = None
+        if ls is not None:
+            gl, _ = rt.pgrad(ls)
+        if gw is None:
+            return
+        if use_planes:
+            def run():
+                hip.wgrad_planes(xp, dyp, M, cin, cout, gw, gb, row_scale, accumulate=accw,
+                                 w=conv.weight if gl is not None else None, bias=conv.bias if gl is not None else None, dls=gl)
+                if rt.on_param_grad:
+                    rt.on_param_grad(conv.weight)
+                    if gb is not None:
+                        rt.on_param_grad(conv.bias)
+                    if gl is not None:
+                        rt.on_param_grad(ls)
+            rt.aside(run, (xp.t, dyp.t))
+        else:
+            kwl = dict(w=conv.weight, bias=conv.bias, dls=gl) if gl is not None else {}
+
+            def run():
+                hip.conv2d_wgrad(xf, cin, dyf, cout, gw, gb, row_scale, B, H, W, cin, H, W, cout, 1, 1, 1, 0, 1, accumulate=accw,
+                                 precision=rt.prec_wgrad(cin, cout, cin, cout), **kwl)
+                if rt.on_param_grad:
+                    rt.on_param_grad(conv.weight)
+                    if gb is not None:
+                        rt.on_param_grad(conv.bias)
+                    if gl is not None:
+                        rt.on_param_grad(ls)
+            rt.aside(run, (xf, dyf))
+
+    def bwd():
+        dx2 = take_grad(x2)
+        dx2_p = take_gradp(x2)
+        if dx2 is None:
+            return
+        if dx2_p is not None and dx2_p.np != np_:
+            dx2_p = None
+        # ---- MLP branch
+        dxn2 = f32(C)
+        if pmlp:
+            du = f32(hid)
+            hb = f32(hid, False)
+            hip.mlp_bwd(dx2, C, ls2, packs[1], u.t, hid, hb.t, hid, du.t, hid, dxn2.t, C, M, C, hid, pmlp)
+            conv_backward(rt, hb, mlp.fc2, dx2, C, row_scale=ls2, ls_grad=ls2, no_dx=True)
+            conv_backward(rt, xn2_f, mlp.fc1, du.t, hid, no_dx=True)
+        else:
+            if fc2[1] or fc2[2]:
+                dx2_p = planes_of(dx2, C, dx2_p)
+            du_p = P(hid) if (fc1[1] or fc1[2]) else None
+            du_f = f32(hid) if (not fc1[1] or not fc1[2] or not fc2[1]) else None
+            if fc2[1]:      # du = (dx2 . (ls2 W2)) * gelu'(u)
+                hip.gemm_planes(dx2_p, pw.dgrad(mlp.fc2.weight, ls2), M, hid, C, y=None if du_f is None else du_f.t, ldy=hid,
+                                yp=du_p, aux=u.t, ldaux=hid)
+            else:
+                wd, ks, prec = rt.dgrad_operands(mlp.fc2, mlp.fc2.weight, mlp.fc2.weight, C, hid, 1, 1, ls2, C, M)
+                hip.conv2d(dx2, C, wd, None, du_f.t, hid, B, H, W, hid, H, W, C, 1, 1, 1, 0, 1, mode=1, kscale=ks, aux=u.t, ldaux=hid,
+                           precision=prec, w_planes=rt.planes(mlp.fc2.weight, 1, hid, C, M, kscale=ks) if prec == 2 else None)
+                if du_p is not None:
+                    hip.planes_from_f32(du_f.t, hid, M, hid, du_p)
+            wgrad(None if h_f is None else h_f.t, h_p, dx2, dx2_p, mlp.fc2, hid, C, fc2[2], row_scale=ls2, ls=ls2)
+            if fc1[1]:
+                hip.gemm_planes(du_p, pw.dgrad(mlp.fc1.weight), M, C, hid, y=dxn2.t, ldy=C)
+            else:
+                wd, ks, prec = rt.dgrad_operands(mlp.fc1, mlp.fc1.weight, mlp.fc1.weight, hid, C, 1, 1, None, hid, M)
+                hip.conv2d(du_f.t, hid, wd, None, dxn2.t, C, B, H, W, C, H, W, hid, 1, 1, 1, 0, 1, mode=1, precision=prec,
+                           w_planes=rt.planes(mlp.fc1.weight, 1, C, hid, M) if prec == 2 else None)
+            wgrad(None if xn2_f is None else xn2_f.t, xn2_p, None if du_f is None else du_f.t, du_p, mlp.fc1, C, hid, fc1[2])
+        # dx1 = dx2 + d(GN -> Mlp branch), also as planes when proj's gradients take them
+        dx1 = rt.buf(B, H, W, C)
+        dx1_p = P(C) if (proj[1] or proj[2]) else None
+        (gw, gb), accw = _pgrads_or_scratch(rt, (m.norm2.weight, m.norm2.bias), (C, C))
+        hip.gn_apply_bwd(dxn2.t, C, x1.t, x1.ld, ms2, m.norm2.weight, B, HW, C, dx1, C, gw, gb, accw, add=dx2, ldadd=C, planes=dx1_p)
+        if rt.on_param_grad:
+            rt.on_param_grad(m.norm2.weight)
+            rt.on_param_grad(m.norm2.bias)
+        # ---- Cluster branch
+        do = f32(ED)
+        if proj[1]:
+            hip.gemm_planes(dx1_p, pw.dgrad(tm.fc2.weight, ls1), M, ED, C, y=do.t, ldy=ED)
+        else:
+            wd, ks, prec = rt.dgrad_operands(tm.fc2, tm.fc2.weight, tm.fc2.weight, C, ED, 1, 1, ls1, C, M)
+            hip.conv2d(dx1, C, wd, None, do.t, ED, B, H, W, ED, H, W, C, 1, 1, 1, 0, 1, mode=1, kscale=ks, precision=prec,
+                       w_planes=rt.planes(tm.fc2.weight, 1, ED, C, M, kscale=ks) if prec == 2 else None)
+        wgrad(o.t, o_p, dx1, dx1_p, tm.fc2, ED, C, proj[2], row_scale=ls1, ls=ls1)
+        dfv = f32(2 * ED)
+        dfv_p = P(2 * ED) if (fcfv[1] or fcfv[2]) else None
+        (ga, gb_), acca = _pgrads_or_scratch(rt, (tm.sim_alpha, tm.sim_beta), (1, 1))
+        hip.cluster_bwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, idx, do.t, ED, dfv.t, dfv.t[..., ED:], 2 * ED, ga, gb_,
+                        acca, B, H, W, E, Dh, fold, planes=dfv_p)
+        if rt.on_param_grad:
+            rt.on_param_grad(tm.sim_alpha)
+            rt.on_param_grad(tm.sim_beta)
+        if fcfv[2]:
+            _fused_qkv_wgrad(rt, tm, xn_p, dfv_p, planes=True)
+        else:
+            _fused_qkv_wgrad(rt, tm, xn_f, dfv)
+        dxn = f32(C)
+        if fcfv[1]:
+            hip.gemm_planes(dfv_p, pw.dgrad(wcat), M, C, 2 * ED, y=dxn.t, ldy=C)
+        else:
+            wd, _, prec = rt.dgrad_operands(tm, wcat, wcat, 2 * ED, C, 1, 1, None, 2 * ED, M)
+            hip.conv2d(dfv.t, 2 * ED, wd, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1, precision=prec,
+                       w_planes=rt.planes(wcat, 1, C, 2 * ED, M) if prec == 2 else None)
+        dx = rt.buf(B, H, W, C)
+        dx_p = P(C) if want_dxp else None
+        (gw, gb), accw = _pgrads_or_scratch(rt, (m.norm1.weight, m.norm1.bias), (C, C))
+        if hip.gn_apply_ok(C, x.ld):
+            hip.gn_apply_bwd(dxn.t, C, x.t, x.ld, ms1, m.norm1.weight, B, HW, C, dx, C, gw, gb, accw, add=dx1, ldadd=C, planes=dx_p)
+            if rt.on_param_grad:
+                rt.on_param_grad(m.norm1.weight)
+                rt.on_param_grad(m.norm1.bias)
+        else:
+            gn_backward(rt, m.norm1, x, ms1, dxn.t, dx, add=dx1)
+            dx_p = None
+        rt.give_grad(x, dx, planes=dx_p)
+    rt.push(bwd)
+    return x2
+
+
+def _fused_qkv_wgrad(rt, tm, xn, dfv, planes=False):
+    """(planes: xn and dfv are hip.Planes -- the plane weight gradient, single stream.)
+    Weight / bias gradients of fc1 and fc_v as one GEMM into [2ED, C] | [2ED] (per stream), deferred off the critical
     path like every other weight gradient.  The GEMM writes the four parameter gradients IN PLACE when their buffers are
     adjacent -- always without a bucketer (they are handed out as views of one buffer), and with the execution-order
     arena of parallel.GradBucketer, where the four are reported ready back to back; otherwise (the bucketer's recording
     pass) through a scratch matrix and four strided copies."""
     tms = [t for t in _pair(tm) if t is not None]
     ed, c = tms[0].fc1.weight.shape[0], tms[0].fc1.weight.shape[1]
-    B, H, W = xn.B, xn.H, xn.W
+    if planes:
+        B, H, W = xn.t.shape[1:4]
+    else:
+        B, H, W = xn.B, xn.H, xn.W
     plans = []
     for t in tms:
         prms = (t.fc1.weight, t.fc_v.weight, t.fc1.bias, t.fc_v.bias)
@@ -996,8 +1278,11 @@ def _fused_qkv_wgrad(rt, tm, xn, dfv):
 
     def wgrad():
         kw2 = dict(dw2=plans[1][0], dbias2=plans[1][1]) if len(plans) == 2 else {}
-        hip.conv2d_wgrad(xn.t, xn.ld, dfv.t, 2 * ed, plans[0][0], plans[0][1], None, B, H, W, c, H, W, 2 * ed, 1, 1, 1, 0, 1,
-                         accumulate=plans[0][2], precision=rt.prec_wgrad(xn.ld, 2 * ed, c, 2 * ed), **kw2)
+        if planes:
+            hip.wgrad_planes(xn, dfv, B * H * W, c, 2 * ed, plans[0][0], plans[0][1], None, accumulate=plans[0][2])
+        else:
+            hip.conv2d_wgrad(xn.t, xn.ld, dfv.t, 2 * ed, plans[0][0], plans[0][1], None, B, H, W, c, H, W, 2 * ed, 1, 1, 1, 0, 1,
+                             accumulate=plans[0][2], precision=rt.prec_wgrad(xn.ld, 2 * ed, c, 2 * ed), **kw2)
         for t, (gw, gbias, _, scatter) in zip(tms, plans):
             if scatter is not None:
                 for (prm, g, acc), (src, width) in zip(scatter, ((gw, c), (gw[ed:], c), (gbias, 1), (gbias[ed:], 1))):
@@ -1006,7 +1291,7 @@ def _fused_qkv_wgrad(rt, tm, xn, dfv):
             if rt.on_param_grad:
                 for prm in (t.fc1.weight, t.fc_v.weight, t.fc1.bias, t.fc_v.bias):     # back to back: adjacent in the arena
                     rt.on_param_grad(prm)
-    rt.aside(wgrad, (xn.keep if isinstance(xn, FoldedGN) else xn.t, dfv.t))
+    rt.aside(wgrad, (xn.t if planes else (xn.keep if isinstance(xn, FoldedGN) else xn.t), dfv.t))
 
 
 # ----------------------------------------------------------------------------------------- fusion blocks
@@ -1442,6 +1727,13 @@ class WeightPlanes:
         return torch.tensor(rows, dtype=torch.int64, device=self.device), first
 
     def refresh(self):
+        # entries whose source storage has been replaced since they were registered (model.to, load_state_dict(assign=True),
+        # p.data = ..., a rebuilt FusedQKV) must not be re-split from the old address: drop them, their next use re-registers
+        stale = [k for k, e in self.entries.items()
+                 if e[7] != (e[0].data_ptr(), None if e[5] is None else e[5].data_ptr())]
+        for k in stale:
+            del self.entries[k]
+            self.dirty = True
         if not self.entries:
             return
         if self.dirty:
@@ -1449,6 +1741,68 @@ class WeightPlanes:
             self.table, self.nblocks = self._table(self.ents)
             self.dirty = False
         hip.conv_planes_pack(self.table, len(self.ents), self.nblocks)
+
+
+PG_MAX_ROWS = int(os.environ.get("VRNET_PG_MAX_ROWS", "1000000000"))      # plane GEMMs only for maps of at most this many pixels (diagnostic override)
+# which GEMM kinds of the ClusterBlocks run on plane operands by default, per compute_dtype (measured: DESIGN 3.6)
+PLANE_GEMMS_DEFAULT = {"f32": False, "bf16": "fwd+wgrad", "off": False}
+
+
+class PlaneWeights:
+    """Weights of the plane GEMMs (hip.gemm_planes): every 1x1 weight a ClusterBlock multiplies with is split into bf16 planes
+    ONCE per forward, all of them in one launch (hip.planes_split) -- forward form w[Cout][Cin] as it is, data-gradient form
+    the transpose with the layer scale folded in.  Same life cycle as WeightPlanes: the first forward that needs a pack
+    builds it on the spot and registers it, `refresh()` re-splits the whole table at the start of every later forward."""
+
+    def __init__(self, model, device, np_):
+        self.owner, self.device, self.np = id(model), device, np_
+        self.entries = {}          # key -> [source, R, K, sr, sk, kscale or None, Planes, (pointers)]
+        self.table, self.nblocks, self.dirty, self.ents = None, 0, False, []
+
+    def get(self, key, w, R, K, sr, sk, kscale=None):
+        ent = self.entries.get(key)
+        ids = (w.data_ptr(), None if kscale is None else kscale.data_ptr())
+        if ent is not None and ent[7] == ids:
+            return ent[6]
+        ent = [w, R, K, sr, sk, kscale, hip.Planes.empty(self.np, (R, K), self.device), ids]
+        self.entries[key] = ent
+        self.dirty = True
+        tab, nb = self._table([ent])
+        hip.planes_split(tab, 1, nb, self.np)          # first use: split now (later forwards: refresh())
+        return ent[6]
+
+    def _table(self, ents):
+        rows, first = [], 0
+        for w, R, K, sr, sk, kscale, pl, _ in ents:
+            rows += [w.data_ptr(), R, K, sr, sk, 0 if kscale is None else kscale.data_ptr(), pl.t.data_ptr(), pl.ld, pl.plane, first]
+            first += hip.planes_split_blocks(R, K)
+        return torch.tensor(rows, dtype=torch.int64, device=self.device), first
+
+    def refresh(self):
+        # entries whose source storage has been replaced since they were registered (model.to, load_state_dict(assign=True),
+        # p.data = ...) are dropped: their next use re-registers them
+        stale = [k for k, e in self.entries.items()
+                 if e[7] != (e[0].data_ptr(), None if e[5] is None else e[5].data_ptr())]
+        for k in stale:
+            del self.entries[k]
+            self.dirty = True
+        if not self.entries:
+            return
+        if self.dirty:
+            self.ents = list(self.entries.values())
+            self.table, self.nblocks = self._table(self.ents)
+            self.dirty = False
+        hip.planes_split(self.table, len(self.ents), self.nblocks, self.np)
+
+    def fwd(self, w):
+        """planes of w[Cout][Cin] (a 1x1 conv weight or a 2-D matrix): the B operand of the forward GEMM."""
+        co, ci = w.shape[0], w.shape[1]
+        return self.get((id(w), 0), w, co, ci, ci, 1)
+
+    def dgrad(self, w, kscale=None):
+        """planes of w^T [Cin][Cout] with kscale[Cout] folded in: the B operand of the data-gradient GEMM."""
+        co, ci = w.shape[0], w.shape[1]
+        return self.get((id(w), 1), w, ci, co, 1, ci, kscale)
 
 
 class FusedQKV:
@@ -1525,6 +1879,8 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         rt.sync_bn = getattr(model, "_sync_bn", None)
         if rt.sync_bn is not None:
             rt.bn_colstats = False          # the statistics come from the per-sample moments pass that feeds the collective
+            if model.training:
+                rt.sync_bn.begin_forward(B, x.device)
         cd = str(os.environ.get("VRNET_COMPUTE_DTYPE") or getattr(model, "compute_dtype", "f32")).lower()   # env: diagnostics
         if cd not in ("f32", "fp32", "float32", "torch.float32", "f32-mfma", "bf16", "bfloat16", "torch.bfloat16"):
             raise RuntimeError(f"compute_dtype {cd!r}: expected 'f32', 'f32-mfma' or 'bf16'")
@@ -1551,6 +1907,20 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
                 wp = model._weight_planes = WeightPlanes(model, x.device)
             wp.refresh()                       # after fq.refresh(): the concatenated fc1 | fc_v weights are sources too
             rt.wplanes = wp
+        # plane GEMMs in the ClusterBlocks (csrc/pgemm.hip): model.plane_gemms = None (default: see below), False, True or a
+        # string of GEMM kinds "fwd", "wgrad", "fwd+wgrad"
+        pg = getattr(model, "plane_gemms", None)
+        if pg is None:
+            pg = PLANE_GEMMS_DEFAULT["bf16" if rt.bf16 else ("f32" if rt.fp32_precision == 2 else "off")]
+        if pg:
+            kinds = pg if isinstance(pg, str) else "fwd+wgrad"
+            rt.pg_fwd, rt.pg_wgrad = "fwd" in kinds, "wgrad" in kinds
+            rt.pnp = 1 if rt.bf16 else 3
+            pwts = getattr(model, "_plane_weights", None)
+            if pwts is None or pwts.owner != id(model) or pwts.device != x.device or pwts.np != rt.pnp:
+                pwts = model._plane_weights = PlaneWeights(model, x.device, rt.pnp)
+            pwts.refresh()
+            rt.pweights = pwts
         xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=need_dx)
         ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=need_dr)
         hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)

@@ -28,9 +28,10 @@ int vrnet_abi_version(void);                 /* == 5 */
  * 5 direct HBM-streaming kernels for 1x1 convs with <= 16 output channels over wide inputs (head predictions, seg logits),
  * 6 "x6": every fp32 product as six exact bf16 x bf16 products on the bf16 MFMA, fp32 accumulate;
  * 9: x6 with pre-split weights (vrnet_conv2d_f32 `w_planes`);
- * 7 / 8: the fused Mlp kernels (vrnet_mlp_fwd_f32 / vrnet_mlp_bwd_f32) at precision 2 (x6) / 1 (bf16-rounded operands). */
+ * 7 / 8: the fused Mlp kernels (vrnet_mlp_fwd_f32 / vrnet_mlp_bwd_f32) at precision 2 (x6) / 1 (bf16-rounded operands);
+ * 10 / 11: plane GEMM forward / data gradient (vrnet_gemm_planes_f32) with np = 3 / 1; 12 / 13: plane weight gradient. */
 int vrnet_last_kernel(void);
-/* Launches of kernel family `family` (same codes) issued by the calling thread since the library was loaded. */
+/* Launches of kernel family `family` (same codes) issued by this process (all threads) since the library was loaded. */
 long vrnet_kernel_launches(int family);
 const char* vrnet_last_error(void);          /* host string, thread local */
 /* 0 for the product library, which reads NO environment variable; 1 for the diagnostic build (make tuning:
@@ -154,6 +155,32 @@ int vrnet_planes_from_f32(const float* src, long lds, long R, long K, void* dst,
  * x: planes of the conv's input (M rows of Cin), dy: planes of the output gradient (M rows of Cout), same np.  The fragments
  * -- 8 consecutive rows of one column -- are read with ds_read_b64_tr_b16; no operand is split in the kernel (the in-kernel
  * split weight gradient splits four fragments per 24 MFMAs).  Channel counts multiples of 8.  Families 12 (np 3) / 13 (np 1). */
+/* Optional bf16-plane output of a producing kernel: the tensor it hands to a plane GEMM.  plane q of element (row, c) at
+ * p[q * plane + row * ld + c]; np = 3 exact split, 1 rounded to bf16. */
+typedef struct vrnet_planes_out {
+  void* p;
+  long ld, plane;
+  int np;
+} vrnet_planes_out;
+/* Producers with a plane output (same arguments as the functions they extend, plus the planes):
+ *   vrnet_gn_apply_fwd_planes    GroupNorm(1, C) output (vr_coc.py:264, 268) -- y may be NULL (planes only);
+ *   vrnet_gn_apply_bwd_planes    its input gradient: the block's outgoing gradient as the next GEMMs' dy operand;
+ *   vrnet_cluster_fwd_planes_f32 the Cluster core's output (vr_coc.py:158-186), forced != 0 = the teacher-forced form;
+ *   vrnet_cluster_bwd_planes_f32 [df | dv] as ONE plane tensor of 2 E D columns (df first). */
+int vrnet_gn_apply_fwd_planes(const float* x, long ldx, const double* pairs, long pairs_per_sample, const float* gamma,
+                              const float* beta, float eps, int B, long HW, int C, float* y, long ldy, float* mean_rstd,
+                              const vrnet_planes_out* yp, void* stream);
+int vrnet_gn_apply_bwd_planes(const float* dy, long lddy, const float* x, long ldx, const float* mean_rstd, const float* gamma,
+                              int B, long HW, int C, const float* add, long ldadd, float* out, long ldo, float* dgamma,
+                              float* dbeta, int accumulate_params, const vrnet_planes_out* outp, void* workspace,
+                              long workspace_bytes, void* stream);
+int vrnet_cluster_fwd_planes_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta, float* out,
+                                 long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E, int D, int fold,
+                                 int forced, const vrnet_planes_out* outp, void* stream);
+int vrnet_cluster_bwd_planes_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
+                                 const unsigned char* idx, const float* dout, long lddo, float* df, float* dv, long lddf,
+                                 float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W, int E, int D, int fold,
+                                 const vrnet_planes_out* dfvp, void* workspace, long workspace_bytes, void* stream);
 int vrnet_wgrad_planes_ok(long M, int Cin, int Cout);
 long vrnet_wgrad_planes_workspace(long M, int Cin, int Cout);
 int vrnet_wgrad_planes_f32(const void* x, long ldx, long x_plane, const void* dy, long lddy, long dy_plane, int np, long M, int Cin,

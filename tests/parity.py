@@ -132,3 +132,25 @@ def _compare_with_oracle(model, batch, size, iseed, check_grads, oracle_dtype, t
         ok = ok and max(rep["dx_err"], rep["dr_err"]) < max(gtol, 3 * ref_in) and worst < max(gtol, 3 * ref_worst)
     rep["ok"] = bool(ok)
     return rep
+
+
+def load_reference_decisions(golden_dir, name):
+    """The reference's own hard decisions for a golden case (tools/make_golden.py, class Discontinuities):
+    ({cluster prefix: (B,E,H,W) uint8 assignment}, {BatchNorm prefix: (B,C,H,W) bool: output > 0})."""
+    import json
+    import os
+    import numpy as np
+    shapes = json.load(open(os.path.join(golden_dir, name + "_decisions.json")))
+    zi = np.load(os.path.join(golden_dir, name + "_decisions.npz"))
+    zb = np.load(os.path.join(golden_dir, name + "_relu_masks.npz"))
+    idx, masks = {}, {}
+    for k in zi.files:
+        shp = shapes[k]
+        n = int(np.prod(shp))
+        p = zi[k]
+        v = np.stack([p & 3, (p >> 2) & 3, (p >> 4) & 3, (p >> 6) & 3], 1).reshape(-1)[:n]
+        idx[k[2:]] = torch.from_numpy(v.reshape(shp).astype(np.uint8))
+    for k in zb.files:
+        shp = shapes[k]
+        masks[k[2:]] = torch.from_numpy(np.unpackbits(zb[k])[:int(np.prod(shp))].reshape(shp).astype(bool))
+    return idx, masks

@@ -59,3 +59,43 @@ def test_bench_defaults_are_the_headline_config():
         assert m and m.group(1).strip() == default, (flag, m and m.group(1))
     # nothing under /root/reference is read at run time; the oracle is imported only for the cpu_baseline leg
     assert "/root/reference" not in src
+
+
+def test_bench_starts_its_ranks_as_a_child_before_anything_touches_hip():
+    """`python bench.py --gpus N` without RANK in the environment must hand over to `python -m torch.distributed.run` as a CHILD
+    process, with the loopback rendezvous the GPU box needs, BEFORE this process has imported the package (which loads the
+    HIP library) or initialised the GPU: a process that has touched HIP must never start another program in its place."""
+    import subprocess
+    import sys
+    probe = r'''
+import sys, subprocess, json
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"]
+seen = {}
+def fake_run(cmd, *a, **k):
+    import torch
+    seen["cmd"] = cmd
+    seen["pkg_loaded"] = any(m.startswith("asy_vrnet_amd") for m in sys.modules)
+    seen["cuda_initialised"] = torch.cuda.is_initialized()
+    class R: returncode = 7
+    return R()
+subprocess.run = fake_run
+import os
+os.environ.pop("RANK", None)
+import bench
+try:
+    bench.main()
+except SystemExit as e:
+    seen["exit"] = e.code
+print("PROBE" + json.dumps(seen))
+'''
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-c", probe], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("PROBE")]
+    assert line, out.stdout + out.stderr
+    seen = json.loads(line[0][5:])
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["exit"] == 7, "the child's return code is passed on"
+    assert not seen["pkg_loaded"] and not seen["cuda_initialised"]

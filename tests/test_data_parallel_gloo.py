@@ -244,15 +244,17 @@ def _worker_sync_bn(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from asy_vrnet_amd.parallel import SyncBatchNormStats, DataParallelVRNet
     import asy_vrnet_amd as A
-    B, C, HW = 3, 5, 7
-    xs = [torch.randn(B, HW, C, dtype=torch.float64, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
-    x = xs[rank]
+    C, HW = 5, 7
+    Bs = [3, 2]                                                            # UNEVEN local batches (an odd last batch)
+    xs = [torch.randn(Bs[r], HW, C, dtype=torch.float64, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    x, B = xs[rank], Bs[rank]
     mom = torch.stack([x.sum(1), (x * x).sum(1)], -1)                      # (B, C, 2): what hip.moments hands over
     sb = SyncBatchNormStats()
+    sb.begin_forward(B, "cpu")                                             # the per-rank sample counts are summed too
     tot = sb.total(mom)
     full = torch.cat(xs, 0)
-    n = sb.count(B * HW)
-    ok = tot.shape == (1, C, 2) and n == world * B * HW
+    n = sb.count(B, HW)
+    ok = tot.shape == (1, C, 2) and n == sum(Bs) * HW
     mean = tot[0, :, 0] / n
     var = tot[0, :, 1] / n - mean * mean
     ok = ok and torch.allclose(mean, full.mean((0, 1)), atol=1e-12) and torch.allclose(var, full.var((0, 1), unbiased=False), atol=1e-12)

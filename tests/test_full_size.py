@@ -246,3 +246,61 @@ def test_forward_backward_repeat_bitwise_over_many_runs(A, net):
             bad.append(it)
     net.load_state_dict(state)
     assert not bad, f"runs {bad} differ from run 0"
+
+
+@pytest.mark.parametrize("kinds", ["fwd+wgrad", "wgrad", "fwd"])
+def test_plane_gemms_agree_with_the_in_kernel_split_path(A, net, kinds):
+    """model.plane_gemms (csrc/pgemm.hip: the ClusterBlock GEMMs on operands their producers wrote as three bf16 planes,
+    t = p0 + p1 + p2 exactly) against the kernels that split the fp32 operands themselves: the same six products of the same
+    values in another summation order.  TRAIN mode, BASELINE configs[1], forward and every parameter gradient; the second
+    pass is teacher-forced to the first one's Cluster assignments, so the arg-max is out of the comparison.  The outputs
+    must agree to rounding level everywhere.  The gradients: "wgrad" leaves the forward pass untouched -- rounding level
+    (measured 3e-7 in aggregate); a forward pass that differs by rounding decides a few ReLU bits behind the BatchNorms the
+    other way (measured 53 of 122 M), each of which moves a weight-gradient row -- rare, and then per cent."""
+    net.train()
+    x, r = A.synthetic_inputs(8, 512, 5, "cuda")
+    bn = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+
+    def restore():
+        sd = net.state_dict()
+        for k, v in bn.items():
+            sd[k].copy_(v)
+
+    def run_masks(gdet, gseg):
+        net.record_relu_masks = True
+        try:
+            out = run(net, x, r, gdet, gseg)
+        finally:
+            net.record_relu_masks = False
+        return out, {k: v.clone() for k, v in net._last_relu_masks.items()}
+    try:
+        net.plane_gemms = False
+        with torch.no_grad():
+            det, seg = net(x, r)
+        gdet, gseg = upstream(det, seg, 3)
+        restore()
+        (d0, s0, g0), m0 = run_masks(gdet, gseg)
+        net.forced_idx_maps = {k: v.clone() for k, v in net._last_idx_maps.items()}
+        restore()
+        net.plane_gemms = kinds
+        from asy_vrnet_amd import hip
+        before = [hip.kernel_launches(f) for f in (10, 12)]
+        (d1, s1, g1), m1 = run_masks(gdet, gseg)
+        ran = [hip.kernel_launches(f) - b for f, b in zip((10, 12), before)]
+        print("plane GEMM launches (forward / data gradient, weight gradient):", ran)
+        assert (ran[0] > 0) == ("fwd" in kinds) and (ran[1] > 0) == ("wgrad" in kinds)
+        for k in net.forced_idx_maps:
+            assert torch.equal(net._last_idx_maps[k], net.forced_idx_maps[k]), k
+    finally:
+        net.forced_idx_maps = None
+        net.plane_gemms = None
+        restore()
+    for a, b in list(zip(d1, d0)) + [(s1, s0)]:
+        assert rel(a, b) < 1e-4, rel(a, b)
+    flips = sum(int((m1[k] != m0[k]).sum()) for k in m0)
+    bits = sum(v.numel() for v in m0.values())
+    num = sum(float(((g1[k].double() - g0[k].double()) ** 2).sum()) for k in g0)
+    den = sum(float((g0[k].double() ** 2).sum()) for k in g0)
+    print("ReLU bits decided differently", flips, "of", bits, "| gradient difference, aggregate", (num / den) ** 0.5)
+    assert flips <= bits // 100000
+    assert (num / den) ** 0.5 < (1e-5 if flips == 0 else 2e-2), (num / den) ** 0.5

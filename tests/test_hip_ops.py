@@ -1223,6 +1223,80 @@ def test_torch_library_custom_ops_round3(hip):
     close(ya, torch.ops.vrnet.dwconv3x3(x.detach().bfloat16().float(), wd.detach()), 1e-6, what="autocast")
 
 
+def test_torch_library_custom_ops_round4(hip):
+    """torch.ops.vrnet.{shuffle_attention, eca, image_enhance, radar_enhance} (ops.py): values and autograd against
+    the CPU oracle's restatement of the reference modules, schema / fake kernels by opcheck, autocast registration."""
+    import asy_vrnet_amd.ops  # noqa: F401
+    from oracle import vrnet_oracle as O
+    opcheck = lambda op, args: torch.library.opcheck(op, args, test_utils=("test_schema", "test_faketensor"))
+    B, H, W, C, G = 2, 8, 6, 64, 8
+    cp = C // (2 * G)
+    x = rnd(B, C, H, W, seed=1).requires_grad_(True)
+    names = ["cweight", "cbias", "sweight", "sbias"]
+    P = {"m." + n: rnd(1, cp, 1, 1, seed=10 + i).requires_grad_(True) for i, n in enumerate(names)}
+    P["m.gn.weight"] = (rnd(cp, seed=20) * 0.3 + 1).requires_grad_(True)
+    P["m.gn.bias"] = rnd(cp, seed=21).requires_grad_(True)
+    order = ["m.cweight", "m.cbias", "m.sweight", "m.sbias", "m.gn.weight", "m.gn.bias"]
+    g = rnd(B, C, H, W, seed=3)
+    ref = O.shuffle_attention(P, "m", x, G)
+    want = torch.autograd.grad(ref, [x] + [P[k] for k in order], g)
+    xg = nhwc(x).requires_grad_(True)
+    prm = [P[k].detach().cuda().requires_grad_(True) for k in order]
+    y = torch.ops.vrnet.shuffle_attention(xg, *prm, G)[0]
+    close(nchw(y), ref, what="shuffle_attention op")
+    mine = torch.autograd.grad(y, [xg] + prm, nhwc(g))
+    close(nchw(mine[0]), want[0], 2e-4, what="shuffle_attention op dx")
+    for a, b_, k in zip(mine[1:], want[1:], order):
+        assert a.shape == b_.shape
+        close(a, b_, 2e-4, what="shuffle_attention op d" + k)
+    opcheck(torch.ops.vrnet.shuffle_attention.default, (xg.detach(), *[t.detach() for t in prm], G))
+    # ---- ECA
+    k = O.eca_kernel_size(C)
+    Pe = {"m.conv.weight": rnd(1, 1, k, seed=2).requires_grad_(True)}
+    ref = O.eca(Pe, "m", x)
+    want = torch.autograd.grad(ref, [x, Pe["m.conv.weight"]], g)
+    we = Pe["m.conv.weight"].detach().cuda().requires_grad_(True)
+    y = torch.ops.vrnet.eca(xg, we)[0]
+    close(nchw(y), ref, what="eca op")
+    mine = torch.autograd.grad(y, [xg, we], nhwc(g))
+    close(nchw(mine[0]), want[0], 2e-4, what="eca op dx")
+    close(mine[1], want[1], 2e-4, what="eca op dw")
+    opcheck(torch.ops.vrnet.eca.default, (xg.detach(), we.detach()))
+    # ---- the gain of ImageEnhanceByRadar: (1 + data_normal(p)) * x, data_normal over the whole batch tensor (vr_coc.py:59-67)
+    p = torch.relu(rnd(B, C, H, W, seed=4)).requires_grad_(True)
+    d = p.max() - p.min()
+    ref = (1 + (p - p.min()) / d) * x
+    want = torch.autograd.grad(ref, [p, x], g)
+    pg = nhwc(p).requires_grad_(True)
+    t = torch.ops.vrnet.image_enhance(pg, xg)[0]
+    close(nchw(t), ref, what="image_enhance op")
+    mine = torch.autograd.grad(t, [pg, xg], nhwc(g))
+    close(nchw(mine[0]), want[0], 2e-4, what="image_enhance op dp")
+    close(nchw(mine[1]), want[1], 2e-4, what="image_enhance op dx")
+    opcheck(torch.ops.vrnet.image_enhance.default, (pg.detach(), xg.detach()))
+    # ---- the gate of RadarEnhanceByImage: eca(shuffle_channels(cat([a, r]), 2))
+    r = rnd(B, C, H, W, seed=5).requires_grad_(True)
+    k2 = O.eca_kernel_size(2 * C)
+    Pr = {"m.conv.weight": rnd(1, 1, k2, seed=6).requires_grad_(True)}
+    ref = O.eca(Pr, "m", O.shuffle2(torch.cat([x, r], 1)))
+    g2 = rnd(B, 2 * C, H, W, seed=7)
+    want = torch.autograd.grad(ref, [x, r, Pr["m.conv.weight"]], g2)
+    rg = nhwc(r).requires_grad_(True)
+    wr = Pr["m.conv.weight"].detach().cuda().requires_grad_(True)
+    u = torch.ops.vrnet.radar_enhance(xg, rg, wr)[0]
+    close(nchw(u), ref, what="radar_enhance op")
+    mine = torch.autograd.grad(u, [xg, rg, wr], nhwc(g2))
+    close(nchw(mine[0]), want[0], 2e-4, what="radar_enhance op da")
+    close(nchw(mine[1]), want[1], 2e-4, what="radar_enhance op dr")
+    close(mine[2], want[2], 2e-4, what="radar_enhance op dw")
+    opcheck(torch.ops.vrnet.radar_enhance.default, (xg.detach(), rg.detach(), wr.detach()))
+    # ---- autocast: half-precision arguments are cast to fp32 on the way in
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = torch.ops.vrnet.eca(xg.detach().bfloat16(), we.detach())[0]
+    assert ya.dtype == torch.float32
+    close(ya, torch.ops.vrnet.eca(xg.detach().bfloat16().float(), we.detach())[0], 1e-6, what="autocast")
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64), (3, 8, 8, 320), (8, 128, 128, 64), (2, 32, 32, 128)])
 def test_group_norm_one_and_two_launch_forms(hip, shape):
     """GroupNorm(1, C) as the network runs it on the block chain: forward in ONE launch from the producer's tile pairs

@@ -251,3 +251,68 @@ def test_wgrad_planes_bf16_tensors(hip):
     xb, yb = x.to(torch.bfloat16).double().cpu(), dy.to(torch.bfloat16).double().cpu()
     close(dw, yb.t() @ xb, 2e-5, what="dw (bf16 operands)")
     close(db, yb.sum(0), 2e-5, what="db (bf16 operands)")
+
+
+def _nhwc(x):
+    return x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+
+
+@pytest.mark.parametrize("np_", [3, 1])
+@pytest.mark.parametrize("case", [(2, 4, 32, 16, 16, 2), (2, 8, 32, 32, 32, 2), (1, 4, 24, 64, 64, 2), (2, 8, 32, 16, 16, 1)])
+def test_producers_write_the_planes_of_what_they_store(hip, case, np_):
+    """The kernels with a plane output (GroupNorm apply forward / backward, Cluster forward / backward) must write, next to
+    their fp32 result, exactly its planes (np = 3: the planes add up to the stored value bit for bit; np = 1: its bf16
+    rounding) -- also planes-only where the fp32 output is optional."""
+    B, E, D, H, W, fold = case
+    C = E * D
+    def check(planes, stored, what):
+        if np_ == 3:
+            assert torch.equal(planes.float(), stored), what
+        else:
+            assert torch.equal(planes.t[0], stored.to(torch.bfloat16)), what
+    # ---- GroupNorm apply, forward and backward
+    x = (rnd(B, H, W, C, seed=1) * 1.5 + 3.0).cuda()
+    gam, bet = (rnd(C, seed=2) * 0.3 + 1).cuda(), (rnd(C, seed=3) * 0.5).cuda()
+    nb = (C + 31) // 32
+    t = x.double().view(B, H * W // 32, 32, C)
+    pairs = torch.zeros(B, H * W // 32, nb, 2, dtype=torch.float64, device="cuda")
+    for j in range(nb):
+        blk = t[..., 32 * j:32 * (j + 1)]
+        pairs[:, :, j, 0], pairs[:, :, j, 1] = blk.sum((2, 3)), (blk * blk).sum((2, 3))
+    y, ms = torch.empty(B, H, W, C, device="cuda"), torch.empty(B, 2, device="cuda")
+    yp = hip.Planes.empty(np_, (B, H, W, C), "cuda")
+    hip.gn_apply_fwd(x, C, pairs, (H * W // 32) * nb, gam, bet, 1e-5, B, H * W, C, y, C, ms, planes=yp)
+    y0 = torch.empty_like(y)
+    hip.gn_apply_fwd(x, C, pairs, (H * W // 32) * nb, gam, bet, 1e-5, B, H * W, C, y0, C, ms)
+    assert torch.equal(y, y0)
+    check(yp, y, "gn_apply_fwd planes")
+    yp2 = hip.Planes.empty(np_, (B, H, W, C), "cuda")
+    hip.gn_apply_fwd(x, C, pairs, (H * W // 32) * nb, gam, bet, 1e-5, B, H * W, C, None, C, ms, planes=yp2)      # planes only
+    assert torch.equal(yp2.t, yp.t)
+    g, addend = rnd(B, H, W, C, seed=4).cuda(), rnd(B, H, W, C, seed=5).cuda()
+    dx, dg, db = torch.empty(B, H, W, C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dxp = hip.Planes.empty(np_, (B, H, W, C), "cuda")
+    hip.gn_apply_bwd(g, C, x, C, ms, gam, B, H * W, C, dx, C, dg, db, 0, add=addend, ldadd=C, planes=dxp)
+    dx0 = torch.empty_like(dx)
+    hip.gn_apply_bwd(g, C, x, C, ms, gam, B, H * W, C, dx0, C, dg, db, 0, add=addend, ldadd=C)
+    assert torch.equal(dx, dx0)
+    check(dxp, dx, "gn_apply_bwd planes")
+    # ---- Cluster core, forward and backward
+    f, v = rnd(B, H, W, C, seed=6).cuda(), rnd(B, H, W, C, seed=7).cuda()
+    al, be = torch.tensor([1.3], device="cuda"), torch.tensor([-0.2], device="cuda")
+    out, out0 = torch.empty(B, H, W, C, device="cuda"), torch.empty(B, H, W, C, device="cuda")
+    idx = torch.empty(B, H, W, E, dtype=torch.uint8, device="cuda")
+    wgt = torch.empty(B, H, W, E, device="cuda")
+    op = hip.Planes.empty(np_, (B, H, W, C), "cuda")
+    hip.cluster_fwd(f, v, C, al, be, out, C, idx, wgt, B, H, W, E, D, fold, planes=op)
+    hip.cluster_fwd(f, v, C, al, be, out0, C, idx, wgt, B, H, W, E, D, fold)
+    assert torch.equal(out, out0)
+    check(op, out, "cluster_fwd planes")
+    go = rnd(B, H, W, C, seed=8).cuda()
+    dfv, dfv0 = torch.empty(B, H, W, 2 * C, device="cuda"), torch.empty(B, H, W, 2 * C, device="cuda")
+    dab = torch.zeros(2, device="cuda")
+    dfvp = hip.Planes.empty(np_, (B, H, W, 2 * C), "cuda")
+    hip.cluster_bwd(f, v, C, al, be, idx, go, C, dfv, dfv[..., C:], 2 * C, dab[0:1], dab[1:2], 0, B, H, W, E, D, fold, planes=dfvp)
+    hip.cluster_bwd(f, v, C, al, be, idx, go, C, dfv0, dfv0[..., C:], 2 * C, dab[0:1], dab[1:2], 0, B, H, W, E, D, fold)
+    assert torch.equal(dfv, dfv0)
+    check(dfvp, dfv, "cluster_bwd planes [df | dv]")

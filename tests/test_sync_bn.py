@@ -16,8 +16,11 @@ class TwoRankStub:
     def __init__(self, others=()):
         self.others, self.seen = list(others), []
 
-    def count(self, n):
-        return 2 * n
+    def begin_forward(self, batch_local, device):
+        pass
+
+    def count(self, batch_local, per_sample):
+        return 2 * batch_local * per_sample
 
     def total(self, mom):
         tot = mom.sum(0, keepdim=True)

@@ -79,7 +79,78 @@ STAT_KEYS = [
 ]
 
 
-def whole_net(name, phi, size, batch, training, pseed, iseed, seg_stride=1, with_grads=True, dtype=torch.float32):
+class Discontinuities:
+    """Records the reference's two kinds of hard decisions during one forward pass, without restating its code:
+    the Cluster arg-max (vr_coc.py:173-176: `mask.scatter_(1, sim_max_idx, 1.)` -- the index tensor of that scatter_ call
+    is captured while a Cluster module is running) and the sign of every BatchNorm2d output (the ReLU masks of the
+    conv -> BN -> ReLU sites are a subset of them, selected by name in the tests)."""
+
+    def __init__(self, model):
+        self.idx, self.bn_pos, self.cur = {}, {}, None
+        self.handles = []
+        for name, mod in model.named_modules():
+            if hasattr(mod, "sim_alpha") and hasattr(mod, "fc_v"):
+                self.handles.append(mod.register_forward_pre_hook(lambda m, a, n=name: setattr(self, "cur", (n, m, a[0].shape))))
+                self.handles.append(mod.register_forward_hook(lambda m, a, o: setattr(self, "cur", None)))
+            elif isinstance(mod, torch.nn.BatchNorm2d):
+                self.handles.append(mod.register_forward_hook(lambda m, a, o, n=name: self.bn_pos.__setitem__(n, (o > 0).numpy())))
+        self.orig = torch.Tensor.scatter_
+        rec = self
+
+        def scatter_(t, dim, index, *a, **k):
+            if rec.cur is not None and dim == 1 and index.dtype == torch.int64:
+                name, mod, shp = rec.cur
+                B, _, H, W = shp
+                E, f1, f2 = mod.heads, max(mod.fold_w, 1), max(mod.fold_h, 1)
+                if not (mod.fold_w > 1 and mod.fold_h > 1):
+                    f1 = f2 = 1
+                w, h = H // f1, W // f2
+                m = index.reshape(B, E, f1, f2, w, h).permute(0, 1, 2, 4, 3, 5).reshape(B, E, H, W)     # (b e f1 f2)(w h) -> b e (f1 w)(f2 h)
+                rec.idx[name] = m.to(torch.uint8).numpy()
+            return rec.orig(t, dim, index, *a, **k)
+        torch.Tensor.scatter_ = scatter_
+
+    def close(self):
+        torch.Tensor.scatter_ = self.orig
+        for h in self.handles:
+            h.remove()
+
+    @staticmethod
+    def relu_sites(phi, size):
+        """Names of the BatchNorms that have a ReLU behind them: the keys the CPU oracle's relu_site() is called with on one
+        forward pass (= the keys of the HIP path's recorded masks, tests/parity.py)."""
+        from oracle import vrnet_oracle as O
+        keys, orig = [], O.relu_site
+        O.relu_site = lambda ctx, key, z: (keys.append(key), orig(ctx, key, z))[1]
+        try:
+            m = A.EfficientVRNet(4, 9, phi, img_size=size)
+            A.randomize_state_dict(m.state_dict(), seed=1)
+            x, r = A.synthetic_inputs(2, size, 1)
+            with torch.no_grad():
+                O.forward({k: v.clone() for k, v in m.state_dict().items()}, x, r, phi, True)
+        finally:
+            O.relu_site = orig
+        return set(keys)
+
+    def arrays(self, relu_keys):
+        """2 bits per assignment, 1 bit per BatchNorm output sign (only the BatchNorms with a ReLU behind them); shapes in
+        the meta record."""
+        arrs, shapes = {}, {}
+        self.bn_pos = {k: v for k, v in self.bn_pos.items() if k in relu_keys}
+        assert len(self.bn_pos) == len(relu_keys), (sorted(relu_keys - set(self.bn_pos)))
+        for k, v in self.idx.items():
+            assert v.max() < 4
+            f = v.reshape(-1).astype(np.uint8)
+            f = np.concatenate([f, np.zeros((-len(f)) % 4, np.uint8)]).reshape(-1, 4)
+            arrs["i:" + k] = (f[:, 0] | (f[:, 1] << 2) | (f[:, 2] << 4) | (f[:, 3] << 6)).astype(np.uint8)
+            shapes["i:" + k] = list(v.shape)
+        for k, v in self.bn_pos.items():
+            arrs["b:" + k] = np.packbits(v.reshape(-1))
+            shapes["b:" + k] = list(v.shape)
+        return arrs, shapes
+
+
+def whole_net(name, phi, size, batch, training, pseed, iseed, seg_stride=1, with_grads=True, dtype=torch.float32, decisions=False):
     """dtype=torch.float64: the reference itself evaluated in double (`m.double()`), i.e. the exact outputs and
     gradients of the reference ALGORITHM -- the pin for the oracle's backward at the benchmark resolution, where
     the reference's fp32 backward is 1-25 % away from the exact gradient."""
@@ -91,7 +162,21 @@ def whole_net(name, phi, size, batch, training, pseed, iseed, seg_stride=1, with
         m, x, r = m.to(dtype), x.to(dtype), r.to(dtype)
     x.requires_grad_(with_grads)
     r.requires_grad_(with_grads)
-    det, seg = m(x, r)
+    disc = Discontinuities(m) if decisions else None
+    try:
+        det, seg = m(x, r)
+    finally:
+        if disc is not None:
+            disc.close()
+    if disc is not None:      # the reference's hard decisions, in a file of their own: <name>_decisions.npz
+        arrs, shapes = disc.arrays(Discontinuities.relu_sites(phi, min(size, 128)))
+        # two files (each stays below 1.5 MB): the Cluster assignments, the ReLU masks
+        np.savez_compressed(os.path.join(OUT, name + "_decisions.npz"), **{k: v for k, v in arrs.items() if k[0] == "i"})
+        np.savez_compressed(os.path.join(OUT, name + "_relu_masks.npz"), **{k: v for k, v in arrs.items() if k[0] == "b"})
+        with open(os.path.join(OUT, name + "_decisions.json"), "w") as f:
+            json.dump(shapes, f)
+        print(name + "_decisions", sum(a.nbytes for a in arrs.values()) // 1024, "KiB raw,", len(disc.idx), "Cluster maps,",
+              len(disc.bn_pos), "BatchNorm sign maps")
     rec = {"det0": det[0], "det1": det[1], "det2": det[2], "seg": seg[:, :, ::seg_stride, ::seg_stride],
            "seg_sum": seg.double().sum(), "seg_abs_sum": seg.double().abs().sum()}
     meta = dict(phi=phi, size=size, batch=batch, training=training, pseed=pseed, iseed=iseed,
@@ -158,6 +243,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "fp64":        # only the double-precision 512 px case
         whole_net("net_nano_512_train_fp64", "nano", 512, 2, True, 3, 9, seg_stride=16, dtype=torch.float64)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "decisions":   # only the two cases that also pin the reference's hard decisions
+        whole_net("net_nano_128_train", "nano", 128, 2, True, 2, 8, decisions=True)
+        whole_net("net_nano_512_train", "nano", 512, 2, True, 3, 9, seg_stride=8, decisions=True)
+        return
     # ---- state_dict surface (names, shapes, dtypes) for nano and l
     for phi in ("nano", "l"):
         m = build_reference_model(phi=phi, img_size=512)
@@ -168,9 +257,9 @@ def main():
     # ---- whole net
     whole_net("net_nano_64_train", "nano", 64, 2, True, 1, 7)
     whole_net("net_nano_64_eval", "nano", 64, 2, False, 1, 7, with_grads=False)
-    whole_net("net_nano_128_train", "nano", 128, 2, True, 2, 8)
+    whole_net("net_nano_128_train", "nano", 128, 2, True, 2, 8, decisions=True)
     whole_net("net_tiny_128_eval", "tiny", 128, 1, False, 4, 10, with_grads=False)
-    whole_net("net_nano_512_train", "nano", 512, 2, True, 3, 9, seg_stride=8)
+    whole_net("net_nano_512_train", "nano", 512, 2, True, 3, 9, seg_stride=8, decisions=True)
     whole_net("net_nano_512_train_fp64", "nano", 512, 2, True, 3, 9, seg_stride=16, dtype=torch.float64)
     # ---- sub-modules (seeded inputs: shape, seed, kind recorded in meta)
     def case(name, mod, shapes, kinds=None, **meta):
