@@ -41,7 +41,23 @@ struct MlpArgs {
 constexpr int MLP_HID_MAX = 2560;
 
 // NPL: 3 = fp32 products as six bf16 products (x6), 1 = operands rounded to bf16 (compute_dtype "bf16")
-template <int C, int MODE, int NPL>
+// HB (with NPL = 1): the hidden-sized tensors -- the pre-activation u, and in the backward pass h and du, the operands of the two
+// weight gradients -- are bf16 in HBM (precision 4: compute_dtype "bf16" with bf16 tensors; the addresses in MlpArgs are then of
+// bf16 elements, row strides in elements): half the bytes of the kernel's dominant traffic.
+__device__ __forceinline__ f32x4 mlp_ld4(const float* base, long off, bool hb) {
+  if (!hb) return *reinterpret_cast<const f32x4*>(base + off);
+  const vr_bf16x4 v = *reinterpret_cast<const vr_bf16x4*>(reinterpret_cast<const unsigned short*>(base) + off);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void mlp_st4(float* base, long off, const f32x4 v, bool hb) {
+  if (!hb) {
+    *reinterpret_cast<f32x4*>(base + off) = v;
+  } else {
+    const vr_bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<vr_bf16x4*>(reinterpret_cast<unsigned short*>(base) + off) = b;
+  }
+}
+template <int C, int MODE, int NPL, bool HB = false>
 __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const MlpArgs p) {
   constexpr int KS = C / 16;                          // k16 steps of the first GEMM
   constexpr int CB = C / 32;                          // 32-channel row blocks of the second GEMM
@@ -99,7 +115,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
   f32x4 uin[4], unext[4];
   if (MODE == 1) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) uin[j] = *reinterpret_cast<const f32x4*>(p.upre + row * p.ldu + 8 * j + 4 * hf);
+    for (int j = 0; j < 4; ++j) uin[j] = mlp_ld4(p.upre, row * p.ldu + 8 * j + 4 * hf, HB);
   }
   issue(0);
   for (int hc = 0; hc < nchunks; ++hc) {
@@ -117,7 +133,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
       if (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          unext[j] = *reinterpret_cast<const f32x4*>(p.upre + row * p.ldu + 32 * (hc + 1) + 8 * j + 4 * hf);
+          unext[j] = mlp_ld4(p.upre, row * p.ldu + 32 * (hc + 1) + 8 * j + 4 * hf, HB);
       }
     }
     const unsigned char* st = smem + (hc & 1) * ST_BYTES + lane * 16;
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
       }
       if (p.upre && live && !(p.dbg & 1)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(p.upre + row * p.ldu + 32 * hc + 8 * j + 4 * hf) = t4[j];
+        for (int j = 0; j < 4; ++j) mlp_st4(p.upre, row * p.ldu + 32 * hc + 8 * j + 4 * hf, t4[j], HB);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -165,8 +181,8 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
       if (live && !(p.dbg & 1)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          *reinterpret_cast<f32x4*>(p.hout + row * p.ldh + 32 * hc + 8 * j + 4 * hf) = h4[j];
-          *reinterpret_cast<f32x4*>(p.du + row * p.lddu + 32 * hc + 8 * j + 4 * hf) = t4[j];
+          mlp_st4(p.hout, row * p.ldh + 32 * hc + 8 * j + 4 * hf, h4[j], HB);
+          mlp_st4(p.du, row * p.lddu + 32 * hc + 8 * j + 4 * hf, t4[j], HB);
         }
       }
     }
@@ -301,8 +317,8 @@ extern "C" int vrnet_mlp_pack_f32(const float* w1, const float* w2, int C, int H
                                   void* pack_bwd, void* stream) {
   VR_CHECK_ARG(w1 && w2 && (pack_fwd || pack_bwd), "mlp_pack: null tensor");
   VR_CHECK_ARG(vrnet_mlp_fused_ok(C, HID, 32), "mlp_pack: no fused Mlp kernel for C = %d, hidden = %d", C, HID);
-  VR_CHECK_ARG(precision == 1 || precision == 2, "mlp_pack: precision 2 (x6) or 1 (bf16-rounded operands)");
-  const int npl = precision == 1 ? 1 : 3;
+  VR_CHECK_ARG(precision == 1 || precision == 2 || precision == 4, "mlp_pack: precision 2 (x6) or 1 / 4 (bf16-rounded operands)");
+  const int npl = precision == 2 ? 3 : 1;
   const long total = (long)(HID / 32) * (C / 16 + 2 * (C / 32)) * 64;
   hipStream_t st = vr_stream(stream);
   if (pack_fwd)
@@ -321,6 +337,9 @@ static int mlp_launch(const MlpArgs& p, int mode, int precision, hipStream_t st)
   if (precision == 2) {
     if (mode == 0) hipLaunchKernelGGL((mlp_fused_kernel<C, 0, 3>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((mlp_fused_kernel<C, 1, 3>), grid, block, 0, st, p);
+  } else if (precision == 4) {
+    if (mode == 0) hipLaunchKernelGGL((mlp_fused_kernel<C, 0, 1, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((mlp_fused_kernel<C, 1, 1, true>), grid, block, 0, st, p);
   } else {
     if (mode == 0) hipLaunchKernelGGL((mlp_fused_kernel<C, 0, 1>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((mlp_fused_kernel<C, 1, 1>), grid, block, 0, st, p);
@@ -335,7 +354,8 @@ extern "C" int vrnet_mlp_fwd_f32(const float* x, long ldx, const void* pack_fwd,
                                  long ldu, double* stats, long M, int C, int HID, int precision, void* stream) {
   VR_CHECK_ARG(x && pack_fwd && y, "mlp_fwd: null tensor");
   VR_CHECK_ARG(vrnet_mlp_fused_ok(C, HID, M), "mlp_fwd: no fused Mlp kernel for C = %d, hidden = %d, %ld rows", C, HID, M);
-  VR_CHECK_ARG(precision == 1 || precision == 2, "mlp_fwd: precision 2 (x6) or 1 (bf16-rounded operands)");
+  VR_CHECK_ARG(precision == 1 || precision == 2 || precision == 4, "mlp_fwd: precision 2 (x6), 1 (bf16-rounded operands) or 4 (1 with "
+                                                                      "the pre-activation stored as bf16)");
   VR_CHECK_ARG(M < (1L << 31), "mlp_fwd: too many rows");
   VR_CHECK_ARG(mlp_vec_ok(x, ldx) && mlp_vec_ok(y, ldy) && mlp_vec_ok(res, ldres) && mlp_vec_ok(upre, ldu) &&
                    mlp_vec_ok(b1, 0) && mlp_vec_ok(b2, 0) && mlp_vec_ok(res_scale, 0) && vr_aligned16(pack_fwd),
@@ -359,7 +379,8 @@ extern "C" int vrnet_mlp_bwd_f32(const float* dy, long lddy, const float* dy_sca
                                  int HID, int precision, void* stream) {
   VR_CHECK_ARG(dy && pack_bwd && upre && h && du && dx, "mlp_bwd: null tensor");
   VR_CHECK_ARG(vrnet_mlp_fused_ok(C, HID, M), "mlp_bwd: no fused Mlp kernel for C = %d, hidden = %d, %ld rows", C, HID, M);
-  VR_CHECK_ARG(precision == 1 || precision == 2, "mlp_bwd: precision 2 (x6) or 1 (bf16-rounded operands)");
+  VR_CHECK_ARG(precision == 1 || precision == 2 || precision == 4, "mlp_bwd: precision 2 (x6), 1 (bf16-rounded operands) or 4 (1 with "
+                                                                      "upre / h / du as bf16 tensors)");
   VR_CHECK_ARG(M < (1L << 31), "mlp_bwd: too many rows");
   VR_CHECK_ARG(mlp_vec_ok(dy, lddy) && mlp_vec_ok(upre, ldu) && mlp_vec_ok(h, ldh) && mlp_vec_ok(du, lddu) &&
                    mlp_vec_ok(dx, lddx) && mlp_vec_ok(dy_scale, 0) && vr_aligned16(pack_bwd),

@@ -680,7 +680,7 @@ static void pwgrad_plan(long M, int Cin, int Cout, int* nt, int* ct, int* S, int
 
 /* Whether vrnet_wgrad_planes_f32 takes a weight gradient of M contraction rows, Cin x Cout channels (1 / 0). */
 extern "C" int vrnet_wgrad_planes_ok(long M, int Cin, int Cout) {
-  static const int min_c = vr_tune("VRNET_PWGRAD_MIN_C", 96);
+  static const int min_c = vr_tune("VRNET_PWGRAD_MIN_C", 64);      // (64 channels fill half a tile: such layers have >= 32 768 rows and stream from HBM)
   return (M >= 256 && Cin >= min_c && Cout >= min_c && Cin % 8 == 0 && Cout % 8 == 0) ? 1 : 0;
 }
 

@@ -193,6 +193,82 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* x, lo
     for (int t = 0; t < 9; ++t) partial[((long)blockIdx.x * C + c) * 9 + t] = acc[t];
   }
 }
+// Sliding-window form for the vector-aligned maps (C % 4 == 0, W % 16 == 0: every depthwise conv of the head): a thread owns
+// four channels and a 16-pixel run of an image row and carries the 3 x 3 input window along it in registers -- per pixel
+// three new 16-byte loads of x and one of dy instead of nine scalar loads of x and one of dy (the kernel above reads
+// every input element nine times through the cache and streamed at 1.1 TB/s); the three rows a window spans are re-read by
+// the thread's next row from L2.  The threads of a channel quad (row runs x rows of the workgroup) meet through LDS in a
+// fixed order; one partial per workgroup and channel, reduced as before.
+__device__ __forceinline__ f32x4 dw_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_slide_kernel(const float* x, long ldx, const float* dy, long lddy,
+                                                                    int B, int H, int W, int C, int rows_per_chunk,
+                                                                    float* partial) {
+  constexpr int SEG = 16;
+  extern __shared__ __attribute__((aligned(16))) float smx[];       // [groups - 1][quads][9] float4
+  const int quads = min(C / 4, 64), nseg = W / SEG;
+  const int cq = threadIdx.x % quads, rest = threadIdx.x / quads;      // rest: (row lane, segment)
+  const int groups = 256 / quads;
+  const int seg = rest % nseg, rl = rest / nseg, rpar = groups / nseg;
+  const int c = (blockIdx.y * quads + cq) * 4;
+  const int nrows = B * H;
+  const int r0 = blockIdx.x * rows_per_chunk, r1 = min(nrows, r0 + rows_per_chunk);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = zero;
+  const bool live = c < C && rl < rpar;
+  if (live) {
+    const int x0 = seg * SEG;
+    for (int row = r0 + rl; row < r1; row += rpar) {
+      const int b = row / H, yy = row - b * H;
+      const float* xr[3];
+      bool ok[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int sy = yy + ky - 1;
+        ok[ky] = sy >= 0 && sy < H;
+        xr[ky] = x + ((long)(b * H + (ok[ky] ? sy : yy)) * W) * ldx + c;
+      }
+      const float* gr = dy + ((long)row * W) * lddy + c;
+      f32x4 w0[3], w1[3], w2[3];      // window columns xx - 1, xx, xx + 1
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        w0[ky] = (ok[ky] && x0 > 0) ? dw_ld4(xr[ky] + (long)(x0 - 1) * ldx) : zero;
+        w1[ky] = ok[ky] ? dw_ld4(xr[ky] + (long)x0 * ldx) : zero;
+      }
+#pragma unroll 4
+      for (int i = 0; i < SEG; ++i) {
+        const int xx = x0 + i;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) w2[ky] = (ok[ky] && xx + 1 < W) ? dw_ld4(xr[ky] + (long)(xx + 1) * ldx) : zero;
+        const f32x4 g = dw_ld4(gr + (long)xx * lddy);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          acc[ky * 3] += g * w0[ky];
+          acc[ky * 3 + 1] += g * w1[ky];
+          acc[ky * 3 + 2] += g * w2[ky];
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) { w0[ky] = w1[ky]; w1[ky] = w2[ky]; }
+      }
+    }
+  }
+  if (rest > 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(smx + (((rest - 1) * quads + cq) * 9 + t) * 4) = acc[t];
+  }
+  __syncthreads();
+  if (rest == 0 && c < C) {
+    for (int r = 1; r < groups; ++r)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] += *reinterpret_cast<const f32x4*>(smx + (((r - 1) * quads + cq) * 9 + t) * 4);
+    float* d = partial + ((long)blockIdx.x * C + c) * 9;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) d[j * 9 + t] = acc[t][j];
+  }
+}
 // 16 lanes per output, chunks strided over the lanes, partials added in lane order through LDS (deterministic)
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_reduce_kernel(const float* partial, int nchunks, int C, float* dw,
                                                                      int accumulate) {
@@ -686,6 +762,10 @@ extern "C" int vrnet_dwconv3x3_f32(const float* x, long ldx, const float* w, flo
   return VR_OK;
 }
 
+static bool dw_wgrad_slide_ok(int W, int C, long ldx, long lddy, const void* x, const void* dy) {
+  return W % 16 == 0 && W <= 64 && C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && vr_aligned16(x) && vr_aligned16(dy) &&
+         (C / 4 <= 64 ? 256 % (C / 4) == 0 && (256 / (C / 4)) % (W / 16) == 0 : (C / 4) % 64 == 0);
+}
 static void dw_wgrad_plan(long nrows, int W, int C, int* nchunks, long* rpc) {   // chunks of whole image rows
   long nc = vr_cdiv(nrows * W * C, 16384);
   if (nc < 1) nc = 1;
@@ -714,8 +794,15 @@ extern "C" int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* 
   const int TPR = C <= 32 ? 32 : 64;
   float* partial = reinterpret_cast<float*>(workspace);
   hipStream_t st = vr_stream(stream);
-  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(nchunks, vr_cdiv(C, TPR)), dim3(256), 0, st, x, ldx, dy, lddy, B, H, W,
-                     C, ppc, partial);
+  if (dw_wgrad_slide_ok(W, C, ldx, lddy, x, dy) && vr_tune("VRNET_DW_WGRAD_SLIDE", 1)) {
+    // (the chunk plan above is in whole image rows with <= 512 chunks: <= 2.4 MB of partials at the head's largest map)
+    const int quads = C / 4 < 64 ? C / 4 : 64, groups = 256 / quads;
+    hipLaunchKernelGGL(dwconv3x3_wgrad_slide_kernel, dim3(nchunks, (C / 4) / quads), dim3(256), (size_t)(groups - 1) * quads * 9 * 16, st,
+                       x, ldx, dy, lddy, B, H, W, C, (int)ppc, partial);
+  } else {
+    hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(nchunks, vr_cdiv(C, TPR)), dim3(256), 0, st, x, ldx, dy, lddy, B, H, W,
+                       C, ppc, partial);
+  }
   VR_LAUNCH_CHECK("dwconv3x3_wgrad");
   hipLaunchKernelGGL(dwconv3x3_wgrad_reduce_kernel, dim3(vr_cdiv(C * 9, 16)), dim3(256), 0, st, partial, nchunks, C, dw,
                      accumulate);

@@ -855,7 +855,7 @@ def cluster_block(rt, x, m, name=None):
         hid_ = mlp0.fc1.weight.shape[0]
         pmlp_ = rt.prec_mlp(C, hid_, B * H * W, H * W)
         plan = _planes_plan(rt, B * H * W, C, ED, hid_, bool(pmlp_))
-        if any(any(v) for v in plan.values()):
+        if any(any(v) for v in plan.values()) or (pmlp_ and rt.pnp == 1 and rt.pg_wgrad):
             return cluster_block_planes(rt, x, m0, name, plan, pmlp_)
     wcat, bcat = tm0._fused_qkv                                  # [fc1 ; fc_v]: one GEMM, f | v side by side
     kwq = dict(pair_rows=rows_half, w2=tm1._fused_qkv[0], bias2=tm1._fused_qkv[1]) if paired else {}
@@ -1062,9 +1062,14 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
     else:
         conv_call(rt, o, tm.fc2, x1, res=x, res_scale=ls1, stats=True)
     # ---- GroupNorm 2 -> Mlp
-    u = f32(hid, False) if rec else None
+    # fused Mlp kernels on bf16 tensors (compute_dtype "bf16"): the hidden-sized tensors -- u, and on the way back h and du, the
+    # operands of the two weight gradients -- are bf16 in HBM (hip.mlp_fwd / mlp_bwd precision 4) and the weight gradients take
+    # them as they are (hip.wgrad_planes, np = 1)
+    mlp_hb = bool(pmlp) and np_ == 1 and rt.pg_wgrad and hip.wgrad_planes_ok(M, hid, C) and hip.wgrad_planes_ok(M, C, hid)
+    u_b = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=x.t.device) if (mlp_hb and rec) else None
+    u = (f32(hid, False) if not mlp_hb else True) if rec else None
     x2 = f32(C)
-    xn2_p = P(C) if (fc1[0] or (rec and fc1[2])) else None
+    xn2_p = P(C) if (fc1[0] or (rec and (fc1[2] or mlp_hb))) else None
     xn2_f = f32(C) if (pmlp or not fc1[0] or (rec and not fc1[2])) else None
     ms2 = rt.buf(B, 2)
     if x1.pairs is not None and hip.gn_apply_ok(C, x1.ld):
@@ -1079,7 +1084,7 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
         packs = hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, pmlp, want_bwd=rec)
         pairs, per = stats_buf(C)
         hip.mlp_fwd(xn2_f.t, C, packs[0], mlp.fc1.bias, mlp.fc2.bias, x1.t, x1.ld, ls2, x2.t, C,
-                    None if u is None else u.t, hid, pairs, M, C, hid, pmlp)
+                    None if u is None else (u_b if mlp_hb else u.t), hid, pairs, M, C, hid, 4 if mlp_hb else pmlp)
         if pairs is not None:
             x2.pairs = (pairs, per)
     else:
@@ -1101,7 +1106,7 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
         else:
             conv_call(rt, h_f, mlp.fc2, x2, res=x1, res_scale=ls2, stats=True)
     # the gradient this block would like to receive for x2 as planes: the dy operand of fc2's data / weight gradient
-    x2.want_gradp = np_ if (not pmlp and (fc2[1] or fc2[2])) else 0
+    x2.want_gradp = np_ if ((not pmlp and (fc2[1] or fc2[2])) or mlp_hb) else 0
     want_dxp = x.want_gradp == np_          # whoever produced x wants ITS incoming gradient as planes
 
     def planes_of(t2d, c, have):
@@ -1155,7 +1160,13 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
             dx2_p = None
         # ---- MLP branch
         dxn2 = f32(C)
-        if pmlp:
+        if mlp_hb:
+            hb_p, du_p = P(hid), P(hid)
+            hip.mlp_bwd(dx2, C, ls2, packs[1], u_b, hid, hb_p.t[0], hid, du_p.t[0], hid, dxn2.t, C, M, C, hid, 4)
+            dx2_p = planes_of(dx2, C, dx2_p)
+            wgrad(None, hb_p, dx2, dx2_p, mlp.fc2, hid, C, True, row_scale=ls2, ls=ls2)
+            wgrad(None, xn2_p, None, du_p, mlp.fc1, C, hid, True)
+        elif pmlp:
             du = f32(hid)
             hb = f32(hid, False)
             hip.mlp_bwd(dx2, C, ls2, packs[1], u.t, hid, hb.t, hid, du.t, hid, dxn2.t, C, M, C, hid, pmlp)

@@ -225,6 +225,10 @@ int vrnet_pack_weight_t_f32(const float* w_oihw, const float* kscale, float* w_t
  *   + b2)  (exact-erf GELU; res / res_scale / b1 / b2 optional);  stats as in vrnet_conv2d_f32 ([M/32][C/32][2] fp64).
  * backward: given dy and the stored u:  du = gelu'(u) * ((dy * dy_scale) w2);  dx = du w1;  h = gelu(u) is recomputed.
  *   du and h are written once (operands of the two weight gradients, vrnet_conv2d_wgrad_f32), dx is the data gradient.
+ * precision 4 (round 4): precision 1 with the hidden-sized tensors in bf16 -- `upre` (forward: written, backward: read), `h` and
+ *   `du` are then addresses of bf16 elements (row strides in elements): half the bytes of the kernels' dominant traffic; h and
+ *   du are what vrnet_wgrad_planes_f32 (np = 1) takes as they are.  The forward output does not change (u is rounded only on
+ *   its way to memory); the backward pass evaluates gelu / gelu' at the rounded u.  Packs: those of precision 1.
  * x6 on non-finite / tiny operands (both here and in vrnet_conv2d_f32 precision 2): an operand of +-Inf splits into
  *   (Inf, NaN, NaN), so an Inf in the data yields NaN where fp32 arithmetic yields Inf; NaN stays NaN.  The low planes of an
  *   operand below 2^-110 in magnitude fall into the bf16 denormal range, which the matrix pipe flushes: such operands

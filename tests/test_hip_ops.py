@@ -362,6 +362,25 @@ def test_depthwise(hip, C):
     close(dw, w.grad, what="dw wgrad")
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 64, 256), (2, 32, 32, 256), (3, 16, 16, 256), (2, 16, 32, 64), (2, 48, 48, 32), (1, 64, 64, 512)])
+def test_depthwise_wgrad_sliding_window(hip, shape):
+    """The head's depthwise convs (decouplehead.py:23-34: 256 channels at 64 / 32 / 16 px) take the sliding-window weight-gradient
+    kernel (four channels and a 16-pixel run per thread); against fp64 ATen, accumulate on and off, twice for bitwise equality."""
+    B, H, W, C = shape
+    x, g = rnd(B, C, H, W, seed=1), rnd(B, C, H, W, seed=3)
+    w = rnd(C, 1, 3, 3, seed=2).double().requires_grad_(True)
+    F.conv2d(x.double(), w, None, 1, 1, 1, C).backward(g.double())
+    xg, gg = nhwc(x), nhwc(g)
+    dw, dw2 = torch.empty(C, 1, 3, 3, device="cuda"), torch.full((C, 1, 3, 3), 2.0, device="cuda")
+    hip.dwconv3x3_wgrad(xg, C, gg, C, dw, B, H, W, C)
+    close(dw, w.grad, 2e-5, what="dw wgrad")
+    hip.dwconv3x3_wgrad(xg, C, gg, C, dw2, B, H, W, C, accumulate=1)
+    close(dw2, w.grad + 2.0, 2e-5, what="dw wgrad, accumulate")
+    dw3 = torch.empty_like(dw)
+    hip.dwconv3x3_wgrad(xg, C, gg, C, dw3, B, H, W, C)
+    assert torch.equal(dw, dw3)
+
+
 @pytest.mark.parametrize("scale,nchw_out", [(2, 0), (4, 0), (4, 1), (2, 1)])
 def test_upsample(hip, scale, nchw_out):
     B, H, W, C = 2, 6, 5, 9
@@ -1063,6 +1082,35 @@ def test_fused_mlp_against_fp64(hip, case, precision):
     close(hb, uu * cdf, 2e-6, what="recomputed h")
     close(du, du_ref, 2e-5, what="du")
     close(dx, dx_ref, tol, what="dx")
+
+
+@pytest.mark.parametrize("case", MLP_CASES[:3])
+def test_fused_mlp_bf16_hidden_tensors(hip, case):
+    """precision 4 (compute_dtype "bf16" with bf16 tensors): the kernels of precision 1 with the hidden-sized tensors -- u forward,
+    h and du backward -- stored as bf16.  Forward output identical to precision 1 (u is rounded only on its way to memory);
+    the stored tensors are the bf16 roundings of what precision 1 stores / computes from the rounded u."""
+    B, H, W, C, hid = case
+    M = B * H * W
+    x, res = rnd(M, C, seed=1).cuda(), rnd(M, C, seed=2).cuda()
+    w1, b1 = (rnd(hid, C, seed=3) / np.sqrt(C)).cuda(), rnd(hid, seed=4).cuda()
+    w2, b2 = (rnd(C, hid, seed=5) / np.sqrt(hid)).cuda(), rnd(C, seed=6).cuda()
+    ls, dy = rnd(C, seed=7).cuda(), rnd(M, C, seed=8).cuda()
+    fwd, bwd = hip.mlp_pack(w1, w2, C, hid, 1)
+    y1, u1 = torch.empty(M, C, device="cuda"), torch.empty(M, hid, device="cuda")
+    hip.mlp_fwd(x, C, fwd, b1, b2, res, C, ls, y1, C, u1, hid, None, M, C, hid, 1)
+    y4, u4 = torch.empty(M, C, device="cuda"), torch.empty(M, hid, dtype=torch.bfloat16, device="cuda")
+    hip.mlp_fwd(x, C, fwd, b1, b2, res, C, ls, y4, C, u4, hid, None, M, C, hid, 4)
+    assert torch.equal(y4, y1) and torch.equal(u4, u1.to(torch.bfloat16))
+    # backward from the bf16 pre-activation: precision 1 fed the SAME (rounded) u must give the same h, du (before rounding), dx
+    ub = u4.float()
+    hb1, du1, dx1 = (torch.empty(M, hid, device="cuda") for _ in range(2)) , None, torch.empty(M, C, device="cuda")
+    hb1, du1 = hb1
+    hip.mlp_bwd(dy, C, ls, bwd, ub, hid, hb1, hid, du1, hid, dx1, C, M, C, hid, 1)
+    hb4, du4 = (torch.empty(M, hid, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+    dx4 = torch.empty(M, C, device="cuda")
+    hip.mlp_bwd(dy, C, ls, bwd, u4, hid, hb4, hid, du4, hid, dx4, C, M, C, hid, 4)
+    assert torch.equal(dx4, dx1)
+    assert torch.equal(hb4, hb1.to(torch.bfloat16)) and torch.equal(du4, du1.to(torch.bfloat16))
 
 
 def test_fused_mlp_rejects_bad_arguments(hip):
