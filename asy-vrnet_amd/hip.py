@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VRNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libvrnet_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

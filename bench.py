@@ -34,12 +34,16 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense bf16 MFMA (no sp
 X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # fp32-equivalent FLOP/s of the x6 kernels: six bf16 MFMAs per fp32 product block
 # matrix-pipe ceiling per kernel family (hip.last_kernel()): fp32-equivalent TFLOP/s
 FAMILY_PEAK = {1: FP32_MFMA_PEAK_TFLOPS, 2: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS, 4: None, 5: None, 6: X6_PEAK_TFLOPS,
-               7: X6_PEAK_TFLOPS, 8: BF16_MFMA_PEAK_TFLOPS, 9: X6_PEAK_TFLOPS}
+               7: X6_PEAK_TFLOPS, 8: BF16_MFMA_PEAK_TFLOPS, 9: X6_PEAK_TFLOPS, 10: X6_PEAK_TFLOPS, 11: BF16_MFMA_PEAK_TFLOPS,
+               12: X6_PEAK_TFLOPS, 13: BF16_MFMA_PEAK_TFLOPS}
 FAMILY_NAME = {1: "fp32 MFMA, register-staged", 2: "fp32 MFMA, LDS-DMA ring", 3: "bf16-rounded operands",
                4: "direct (tiny channel counts, no MFMA)", 5: "direct (narrow outputs over wide inputs, HBM streams, no MFMA)", 6: "x6: six exact bf16 x bf16 products per fp32 product",
                7: "fused Mlp (fc1 -> GELU -> fc2 in one kernel), x6, weights pre-split into bf16 planes",
                8: "fused Mlp, bf16-rounded operands",
-               9: "x6 with weights pre-split into bf16 planes once per step (1x1 convs)"}
+               9: "x6 with weights pre-split into bf16 planes once per step (1x1 convs)",
+               10: "plane GEMM, x6: both operands already bf16 planes in HBM (1x1 convs of the ClusterBlocks)",
+               11: "plane GEMM on bf16 tensors (compute_dtype bf16)",
+               12: "plane weight gradient, x6", 13: "plane weight gradient on bf16 tensors"}
 
 
 def kernel_source_hash():
@@ -133,6 +137,7 @@ class ConvTimer:
         self.rec = {"igemm": [], "wgrad": [], "cluster_fwd": [], "cluster_bwd": []}
         self.orig = (hip.conv2d, hip.conv2d_wgrad, hip.cluster_fwd, hip.cluster_bwd)
         self.orig_mlp = (hip.mlp_fwd, hip.mlp_bwd)
+        self.orig_planes = (hip.gemm_planes, hip.wgrad_planes)
 
     def __enter__(self):
         hip, rec = self.hip, self.rec
@@ -189,11 +194,30 @@ class ConvTimer:
             e1.record()
             rec["igemm"].append((4.0 * M * C * HID, e0, e1, f"mlpB M{M} C{C} H{HID} k{hip.last_kernel()}", hip.last_kernel()))
         hip.mlp_fwd, hip.mlp_bwd = mlp_fwd, mlp_bwd
+        o_gp, o_wp = self.orig_planes
+
+        # the plane GEMMs (csrc/pgemm.hip) are launches of the same two classes: a 1x1 conv's forward / data gradient, its
+        # weight gradient
+        def gemm_planes(a, b, M, N, K, *rest, **kw_):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_gp(a, b, M, N, K, *rest, **kw_)
+            e1.record()
+            rec["igemm"].append((2.0 * M * N * K, e0, e1, f"M{M} N{N} K{K}x1x1 k{hip.last_kernel()}", hip.last_kernel()))
+
+        def wgrad_planes(x, dy, M, Cin, Cout, *rest, **kw_):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_wp(x, dy, M, Cin, Cout, *rest, **kw_)
+            e1.record()
+            rec["wgrad"].append((2.0 * M * Cin * Cout, e0, e1, f"M{M} N{Cout} K{Cin}x1x1 k{hip.last_kernel()}", hip.last_kernel()))
+        hip.gemm_planes, hip.wgrad_planes = gemm_planes, wgrad_planes
         return self
 
     def __exit__(self, *a):
         self.hip.conv2d, self.hip.conv2d_wgrad, self.hip.cluster_fwd, self.hip.cluster_bwd = self.orig
         self.hip.mlp_fwd, self.hip.mlp_bwd = self.orig_mlp
+        self.hip.gemm_planes, self.hip.wgrad_planes = self.orig_planes
 
     def summary(self, key):
         torch.cuda.synchronize()
@@ -437,7 +461,7 @@ def main():
         c1.record()
         torch.cuda.synchronize()
         cycles_per_ms = 20_000_000 / max(c0.elapsed_time(c1), 1e-3)
-        gate_ms = 1.6 * host_issue_ms + 10.0         # ConvTimer's event records lengthen the issue time
+        gate_ms = 2.2 * host_issue_ms + 20.0         # ConvTimer's event records lengthen the issue time
         ahead = 0
         with ConvTimer(hip) as ct:
             for i in range(args.steps):

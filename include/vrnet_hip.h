@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------- */
-int vrnet_abi_version(void);                 /* == 5 */
+int vrnet_abi_version(void);                 /* == 6 */
 /* Kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to: 1 fp32 MFMA
  * (register-staged), 2 fp32 MFMA (LDS-DMA ring), 3 bf16-rounded operands, 4 direct kernels for tiny channel counts,
  * 5 direct HBM-streaming kernels for 1x1 convs with <= 16 output channels over wide inputs (head predictions, seg logits),
