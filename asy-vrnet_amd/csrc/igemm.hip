@@ -670,8 +670,9 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
 // kernel: the forward pack holds w[n][c] (columns n, contraction c), the data-gradient pack the transposed weights with
 // the layer scale folded in (columns c, contraction n).  A operand, ring, XCD-aware tile map and epilogue as in
 // igemm_dma_kernel.  Measured bound of the idea (diagnostic build, B splits skipped): 27.8 -> 26.6 ms per step.
-constexpr int GN_KMAX = 512;      // widest GroupNorm input the folded form takes (two float tables of this length in LDS)
-template <int TN, int NST, bool GN = false>
+// (Round 3 also had a variant that folded the GroupNorm in front of the conv into the A fragments -- bit-identical to launch +
+// conv, measured neutral-to-negative in the step at every threshold, never on by default; removed in round 4.)
+template <int TN, int NST>
 __global__ __launch_bounds__(256, (NST * (8192 + TN * 6144) <= 49152) ? 3 : 2) void igemm_planes_kernel(const IgemmArgs p,
                                                                                                       const unsigned char* planes,
                                                                                                       int JB, int MT, int NT) {
@@ -684,8 +685,6 @@ __global__ __launch_bounds__(256, (NST * (8192 + TN * 6144) <= 49152) ? 3 : 2) v
   constexpr int NBT = B_BYTES / 1024;                     // B pieces per stage: 6 (waves 0-1 issue 2, waves 2-3 one) or 12 (3 each)
   static_assert(NST * ST_BYTES >= 4 * 32 * STAGE_LD * 4, "epilogue staging must fit the ring");
   __shared__ __attribute__((aligned(16))) unsigned char smem[NST * ST_BYTES];
-  __shared__ __attribute__((aligned(16))) float gn_tab[GN ? 2 * GN_KMAX : 4];      // [0, K): rstd * gamma, [GN_KMAX, ..): beta
-  __shared__ double gn_red[4];
   const int tid = threadIdx.x, lane = tid & 63;
   const float* zero_page = vr_zero_page;
   asm volatile("" : "+s"(zero_page));
@@ -755,42 +754,6 @@ __global__ __launch_bounds__(256, (NST * (8192 + TN * 6144) <= 49152) ? 3 : 2) v
 #pragma unroll
   for (int st = 0; st < NST - 1; ++st)
     if (st < nsteps) issue();
-  float gn_mu = 0.f;
-  if (GN) {      // while the first stages fly: the sample's statistics exactly as gn_apply_fwd_kernel adds them, then the tables
-    const int b = m0 / p.gn_HW;                  // a row tile lies inside one sample (gn_HW % 128 == 0)
-    const double* src = p.gn_pairs + (long)b * p.gn_per * 2;
-    double s1 = 0, s2 = 0, t1 = 0, t2 = 0;
-    long i = tid;
-    for (; i + 256 < p.gn_per; i += 512) {
-      s1 += src[2 * i]; s2 += src[2 * i + 1];
-      t1 += src[2 * (i + 256)]; t2 += src[2 * (i + 256) + 1];
-    }
-    if (i < p.gn_per) { s1 += src[2 * i]; s2 += src[2 * i + 1]; }
-    auto bsum = [&](double v) {
-      v = wave_sum(v);
-      __syncthreads();
-      if (lane == 0) gn_red[tid >> 6] = v;
-      __syncthreads();
-      return gn_red[0] + gn_red[1] + gn_red[2] + gn_red[3];      // ((0 + r0) + r1) + ... of block_sum: 0 + r0 is exact
-    };
-    s1 = bsum(s1 + t1);
-    s2 = bsum(s2 + t2);
-    const double n = (double)p.gn_HW * p.CK;
-    const double mean = s1 / n;
-    double var = s2 / n - mean * mean;
-    if (var < 0) var = 0;
-    const double rstd = 1.0 / sqrt(var + (double)p.gn_eps);
-    if (nt == 0 && m0 % p.gn_HW == 0 && tid == 0) {
-      p.gn_ms[2 * b] = (float)mean;
-      p.gn_ms[2 * b + 1] = (float)rstd;
-    }
-    gn_mu = (float)mean;
-    for (int k = tid; k < p.CK; k += 256) {
-      gn_tab[k] = (float)(rstd * (double)p.gn_gamma[k]);
-      gn_tab[GN_KMAX + k] = p.gn_beta[k];
-    }
-    __syncthreads();
-  }
   int cur = 0;
   for (int s = 0; s < nsteps; ++s) {
     if (NST >= 3 && nsteps - 1 - s >= 1) {       // one younger stage stays in flight
@@ -813,16 +776,6 @@ __global__ __launch_bounds__(256, (NST * (8192 + TN * 6144) <= 49152) ? 3 : 2) v
     {
       f32x4 lo = *reinterpret_cast<const f32x4*>(As + a_off + 16 * ((2 * h) ^ a_swz));
       f32x4 hi = *reinterpret_cast<const f32x4*>(As + a_off + 16 * ((2 * h + 1) ^ a_swz));
-      if (GN) {      // this lane's 8 contraction indices: 16 s + 8 h + 0..7 (the same address in a half wave: broadcast reads)
-        const float* t = gn_tab + 16 * s + 8 * h;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(t), g1 = *reinterpret_cast<const f32x4*>(t + 4);
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(t + GN_KMAX), e1 = *reinterpret_cast<const f32x4*>(t + GN_KMAX + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          lo[e] = fmaf(g0[e], lo[e] - gn_mu, e0[e]);
-          hi[e] = fmaf(g1[e], hi[e] - gn_mu, e1[e]);
-        }
-      }
       vr_split3(lo, hi, a3);
     }
     // each DMA instruction of the next stage goes behind a group of six MFMAs, whose execution hides its issue cost
@@ -1465,24 +1418,6 @@ static int vr_dma_tile(long M, int CN) {
  * back to the fp32 MFMA).  Alignment requirements (16-byte rows, channel counts % 4) are the caller's, as for precision 1. */
 extern "C" int vrnet_conv2d_dma_tile(long rows, int cols) { return vr_dma_tile(rows, cols); }
 
-/* GroupNorm(1, C) input folded into the forward of a 1x1 conv (see IgemmArgs::gn_*). */
-struct vrnet_conv_gn_input {
-  const double* pairs; long pairs_per_sample;
-  const float* gamma; const float* beta; float eps;
-  long HW;
-  float* mean_rstd;
-};
-static bool vr_gn_fold_shape_ok(long rows, int cols, int K, long HW) {
-  // (every workgroup re-adds its sample's tile pairs and builds the two tables before its first MFMA; thresholds on K -- 16,
-  // 128, 256 -- were all within noise of each other and of the unfolded step)
-  static const int min_k = vr_tune("VRNET_GN_FOLD_MIN_K", 16);      // tuning aid
-  return vr_dma_tile(rows, cols) != 0 && K % 16 == 0 && K >= min_k && K <= GN_KMAX && HW % 128 == 0 && rows % HW == 0;
-}
-/* Whether vrnet_conv2d_f32 (mode 0, 1x1, precision 2, w_planes given) takes `gn_input` for rows = B*H*W GEMM rows, cols =
- * Cout columns, K = Cin and HW pixels per sample: 1 / 0.  Callers ask first and otherwise run the GroupNorm as its own
- * launch (vrnet_gn_apply_fwd). */
-extern "C" int vrnet_conv2d_gn_fold_ok(long rows, int cols, int K, long HW) { return vr_gn_fold_shape_ok(rows, cols, K, HW) ? 1 : 0; }
-
 extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias, float* y, long ldy,
                                 int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride,
                                 int pad, int dil, int mode, int act, float* ypre, long ldypre, const float* res,
@@ -1490,15 +1425,8 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                                 long ldaux, int out_nchw, int out_ctot, int out_coff, int accumulate,
                                 double* stats, int precision, int pair_rows, const float* w2, const float* bias2,
                                 const float* res_scale2, const float* kscale2, const void* w_planes,
-                                const vrnet_conv_colstats* colstats, const vrnet_conv_gn_input* gn_input, void* stream) {
+                                const vrnet_conv_colstats* colstats, void* stream) {
   VR_CHECK_ARG(a && w && y, "conv2d: null tensor");
-  VR_CHECK_ARG(!gn_input || (mode == 0 && kh == 1 && kw == 1 && stride == 1 && pad == 0 && precision == 2 && w_planes && !pair_rows &&
-                             gn_input->pairs && gn_input->gamma && gn_input->beta && gn_input->mean_rstd &&
-                             gn_input->pairs_per_sample > 0 &&
-                             vr_gn_fold_shape_ok((long)B * H * W, Cout, Cin, gn_input->HW) && gn_input->HW == (long)H * W &&
-                             lda % 4 == 0 && vr_aligned16(a)),
-               "conv2d: a GroupNorm-folded input needs a forward 1x1 conv at precision 2 with pre-split weights on an x6 tile, "
-               "Cin %% 16 == 0, Cin <= 512 and HW %% 128 == 0: ask vrnet_conv2d_gn_fold_ok first");
   if (vr_ablated("igemm")) return VR_OK;
   {   // finer timing ablations by output-row class (diagnostic): stage-0/1 maps, stage-2 maps, neck / head maps
     const long rows_ = (long)B * (mode == 0 ? OH * OW : H * W);
@@ -1670,21 +1598,6 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
       IgemmArgs q = p;
       q.kscale = nullptr;
       const int JB = (int)(((p.CN + 127) >> 7) << 1);
-      if (gn_input) {
-        q.gn_pairs = gn_input->pairs; q.gn_per = gn_input->pairs_per_sample; q.gn_gamma = gn_input->gamma;
-        q.gn_beta = gn_input->beta; q.gn_eps = gn_input->eps; q.gn_HW = (int)gn_input->HW; q.gn_ms = gn_input->mean_rstd;
-        const unsigned char* pl = reinterpret_cast<const unsigned char*>(w_planes);
-        if (tile == 22) {
-          dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt22));
-          hipLaunchKernelGGL((igemm_planes_kernel<2, 2, true>), grid, block, 0, st, q, pl, JB, (int)mt, (int)nt22);
-        } else {
-          dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt21));
-          hipLaunchKernelGGL((igemm_planes_kernel<1, 3, true>), grid, block, 0, st, q, pl, JB, (int)mt, (int)nt21);
-        }
-        vr_note_kernel(9);
-        VR_LAUNCH_CHECK("conv2d(x6, pre-split weights, GroupNorm-folded input)");
-        return VR_OK;
-      }
       if (tile == 22) {
         dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt22));
         // 128 x 128 tile: two stages (40 KB, 3 workgroups per CU) measured 0.2 ms per step ahead of three (60 KB, 2 per CU)
@@ -1703,7 +1616,6 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
       VR_LAUNCH_CHECK("conv2d(x6, pre-split weights)");
       return VR_OK;
     }
-    VR_CHECK_ARG(!gn_input, "conv2d: this launch cannot take a GroupNorm-folded input (operand alignment)");
     if (tile) {
       if (precision == 2) VR_TILE_LAUNCH(6);
       else VR_TILE_LAUNCH(1);
@@ -1713,7 +1625,6 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
     }
 #undef VR_TILE_LAUNCH
   }
-  VR_CHECK_ARG(!gn_input, "conv2d: this launch cannot take a GroupNorm-folded input (no x6 tile kernel for it)");
   VR_CHECK_ARG(precision != 3, "conv2d: precision 3 (bf16-rounded operands on the LDS-DMA tiles, standard weight layout) has "
                                "no kernel for this shape / alignment: ask vrnet_conv2d_dma_tile first");
   if (dma_ok && dma_shape) {

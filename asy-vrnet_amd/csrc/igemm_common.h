@@ -44,12 +44,6 @@ struct IgemmArgs {
   // sums weighted by col_gamma[n] and added over the tile's 32 columns (GroupNorm backward: per-sample coefficients).
   double* col_part; const float* col_x2; long ld_col_x2; const float* col_gamma; double* col_tot;
   int dbg_fake_presplit;   // diagnostic build only (timing experiment, igemm.hip)
-  // GroupNorm(1, C) folded into the A operand (igemm_planes_kernel, forward of a 1x1 conv whose input is a GroupNorm's
-  // output): the kernel reads the UN-normalised tensor and normalises each fragment in registers,
-  // a' = fma(rstd * gamma[k], a - mean, beta[k]) -- the very expression gn_apply_fwd_kernel stores, so the conv sees the
-  // same bits -- with the sample's (mean, rstd) re-added from the (sum, sumsq) tile pairs the PRODUCER of `a` left
-  // (gn_pairs: [B][gn_per][2], fixed order) in every workgroup's prologue.  gn_ms (B, 2) receives (mean, rstd).
-  const double* gn_pairs; long gn_per; const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_HW; float* gn_ms;
   // Output as bf16 planes (pgemm.hip; vector epilogue only): plane q of element (m, n) at yp[q * yp_plane + m * ldyp + n].
   // yp_np = 3: the stored fp32 value split exactly into three bf16 values (v = p0 + p1 + p2, round-to-nearest-even splits) --
   // the operand format of the next x6 GEMM, which then splits nothing; yp_np = 1: the value rounded to bf16.  `y` may be

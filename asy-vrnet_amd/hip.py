@@ -28,8 +28,7 @@ _SIGS = {
     "vrnet_tuning_build": ([], I),
     "vrnet_kernel_launches": ([I], L),
     "vrnet_device_arch": ([ctypes.c_char_p, I], I),
-    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P, P, P, P], I),
-    "vrnet_conv2d_gn_fold_ok": ([L, I, I, L], I),
+    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P, P, P], I),
     "vrnet_conv_planes_bytes": ([I, I], L),
     "vrnet_conv_planes_pack_f32": ([P, I, L, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
@@ -142,11 +141,6 @@ def _planes_out(pl):
     return None if pl is None else ctypes.byref(PlanesOut(ptr(pl.t), pl.ld, pl.plane, pl.np))
 
 
-class ConvGnInput(ctypes.Structure):
-    """vrnet_conv_gn_input (include/vrnet_hip.h): GroupNorm(1, C) folded into the A operand of a forward 1x1 conv."""
-    _fields_ = [("pairs", P), ("pairs_per_sample", L), ("gamma", P), ("beta", P), ("eps", F), ("HW", L), ("mean_rstd", P)]
-
-
 _DTYPES = frozenset((torch.float32, torch.float64, torch.uint8, torch.int64, torch.int32, torch.bfloat16))
 
 
@@ -216,15 +210,9 @@ _ws = Workspace()
 def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil, mode=0, act=0,
            ypre=None, ldypre=0, res=None, ldres=0, res_scale=None, kscale=None, aux=None, ldaux=0,
            out_nchw=0, out_ctot=0, out_coff=0, accumulate=0, stats=None, precision=0, pair_rows=0, w2=None, bias2=None,
-           res_scale2=None, kscale2=None, colstats=None, w_planes=None, gn_input=None):
+           res_scale2=None, kscale2=None, colstats=None, w_planes=None):
     """pair_rows > 0: two-stream launch, GEMM rows >= pair_rows use (w2, bias2, res_scale2, kscale2).
-    colstats = (partial, x2, ldx2, gamma, tile_totals) (None entries allowed): column statistics of the stored outputs.
-    gn_input = (pairs, pairs_per_sample, gamma, beta, eps, HW, mean_rstd): `a` is the un-normalised input of a GroupNorm(1, C)
-    whose output this conv consumes (ask conv2d_gn_fold_ok first)."""
-    gi = None
-    if gn_input is not None:
-        prs, per, gam_, bet_, eps_, hw_, ms_ = gn_input
-        gi = ctypes.byref(ConvGnInput(ptr(prs), per, ptr(gam_), ptr(bet_), eps_, hw_, ptr(ms_)))
+    colstats = (partial, x2, ldx2, gamma, tile_totals) (None entries allowed): column statistics of the stored outputs."""
     cs = None
     if colstats is not None:
         part, x2, ldx2, gam, tot = colstats
@@ -232,13 +220,8 @@ def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, 
     _check(_lib.vrnet_conv2d_f32(ptr(a), lda, ptr(w), ptr(bias), ptr(y), ldy, B, H, W, Cin, OH, OW, Cout, kh, kw,
                                  stride, pad, dil, mode, act, ptr(ypre), ldypre, ptr(res), ldres, ptr(res_scale),
                                  ptr(kscale), ptr(aux), ldaux, out_nchw, out_ctot, out_coff, accumulate, ptr(stats),
-                                 precision, pair_rows, ptr(w2), ptr(bias2), ptr(res_scale2), ptr(kscale2), ptr(w_planes), cs, gi, stream()),
+                                 precision, pair_rows, ptr(w2), ptr(bias2), ptr(res_scale2), ptr(kscale2), ptr(w_planes), cs, stream()),
            "conv2d")
-
-
-def conv2d_gn_fold_ok(rows, cols, K, HW):
-    """Whether a forward 1x1 conv2d launch (precision 2, w_planes) takes `gn_input` (vrnet_conv2d_gn_fold_ok)."""
-    return bool(_lib.vrnet_conv2d_gn_fold_ok(rows, cols, K, HW))
 
 
 def conv_planes_bytes(J, K):

@@ -86,13 +86,6 @@ class RT:
         self.fused_mlp = True       # Mlp of a ClusterBlock as one kernel per direction where the library has one
         self.wplanes = None         # WeightPlanes: pre-split weights for the x6 kernels (model.weight_planes, default on)
         self.bn_colstats = True     # BatchNorm batch statistics from the producing conv's epilogue (no pass over z)
-        self.gn_colstats = False    # GroupNorm backward moments from the producing data-gradient conv's epilogue (built and
-                                    # tested; same-box A/B: 29.16 -> 29.16 ms with it, 29.01 without: the epilogue work it adds to
-                                    # the x6 data-gradient kernels costs what the 46 moments launches it removes were worth)
-        self.gn_fold = False        # GroupNorm in front of a 1x1 conv folded into that conv's A operand (model.gn_fold; built, bit-
-                                    # identical, tested; same-call A/B: 27.0-27.3 ms with it at any K threshold, 26.8-27.1 without --
-                                    # the per-workgroup statistics prologue, the 16 extra VALU operations per K16 step and the
-                                    # re-made tensor for the weight gradient cost what the 32 launches it removes were worth)
         self.pnp = 0                # plane GEMMs (csrc/pgemm.hip) in the ClusterBlocks: 0 off, 3 fp32 values as three bf16 planes,
                                     # 1 bf16 tensors (compute_dtype "bf16"); pg_fwd / pg_wgrad: which GEMM kinds take them
         self.pg_fwd, self.pg_wgrad = True, True
@@ -477,8 +470,7 @@ def _pair_kw(rt, x, convs, w_of, bias=True, res_scale=None, kscale=None):
     return dict(w2=w_of(c1), bias2=c1.bias if bias else None, res_scale2=rs1, kscale2=ks1)
 
 
-def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw=None, bias=True, stats=False, bn_stats=False,
-              gn_input=None):
+def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw=None, bias=True, stats=False, bn_stats=False):
     """out: Act (NHWC target) or, with nchw=(tensor, ctot, coff), a channel range of an NCHW tensor.
     conv / res_scale may be pairs (two-stream launch over a (2B,...) input: first half of the rows = first module)."""
     c0, c1 = _pair(conv)
@@ -497,8 +489,6 @@ def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw
             kw2["pair_rows"] = (x.B // 2) * OH * OW
         if c1 is None and kh == 1 and kw == 1 and s == 1 and p == 0:
             kw2["w_planes"] = rt.planes(c0.weight, 0, co, ci, x.B * OH * OW)
-        if gn_input is not None:      # x is the un-normalised input of the GroupNorm in front of this conv (gn_folded said yes)
-            kw2["gn_input"] = gn_input
         hip.conv2d(x.t, x.ld, rt.weight(c0), b, out.t, out.ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d,
                    mode=0, act=act, ypre=None if ypre is None else ypre.t, ldypre=0 if ypre is None else ypre.ld,
                    res=None if res is None else res.t, ldres=0 if res is None else res.ld,
@@ -560,7 +550,7 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
                         if l is not None and kwl:
                             rt.on_param_grad(l)
         if defer_ok:
-            rt.aside(wgrad, (x.keep if isinstance(x, FoldedGN) else x.t, dy))
+            rt.aside(wgrad, (x.t, dy))
         else:                    # dy is updated in place later in this closure: the weight gradient must read it now
             wgrad()
     target = dx_to if dx_to is not None else (x if x.need_grad else None)
@@ -665,45 +655,6 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
     return dz
 
 
-class FoldedGN:
-    """Output of a GroupNorm(1, C) that was never written: its consumer -- a forward 1x1 conv on the pre-split-weight x6
-    kernel -- read the un-normalised tensor `src` and normalised every A fragment in registers (hip.conv2d `gn_input`, the
-    same expression hip.gn_apply_fwd stores: the conv saw identical bits).  The only other reader is the conv's weight
-    gradient, which runs on an auxiliary stream during the backward pass: `.t` makes the tensor THERE, when that closure
-    runs (one gn_apply launch beside the data gradients instead of one on the forward chain), so it is not held from the
-    forward to the backward pass either.  `ms` (B, 2): (mean, rstd), written by the conv."""
-    __slots__ = ("rt", "src", "gn", "pairs", "ms", "B", "H", "W", "C", "ld")
-
-    def __init__(self, rt, src, gn, ms):
-        self.rt, self.src, self.gn, self.pairs, self.ms = rt, src, gn, src.pairs, ms
-        self.B, self.H, self.W, self.C, self.ld = src.B, src.H, src.W, src.C, src.C
-
-    def gn_input(self):
-        return (self.pairs[0], self.pairs[1], self.gn.weight, self.gn.bias, self.gn.eps, self.H * self.W, self.ms)
-
-    @property
-    def keep(self):
-        return self.src.t
-
-    @property
-    def t(self):
-        y = self.rt.buf(self.B, self.H, self.W, self.C)
-        hip.gn_apply_fwd(self.src.t, self.src.ld, self.pairs[0], self.pairs[1], self.gn.weight, self.gn.bias, self.gn.eps,
-                         self.B, self.H * self.W, self.C, y, self.C, self.rt.buf(self.B, 2))
-        return y
-
-
-def gn_folded(rt, x, gn, cols):
-    """FoldedGN for y = GN(x) feeding a forward 1x1 conv with `cols` output channels, or None when that launch cannot take
-    it (then gn_forward runs the GroupNorm as its own launch)."""
-    if not rt.gn_fold or isinstance(gn, tuple) or x.pairs is None or rt.wplanes is None or rt.bf16 or rt.fp32_precision != 2:
-        return None
-    rows = x.B * x.H * x.W
-    if not (hip.gn_apply_ok(x.C, x.ld) and x.t.data_ptr() % 16 == 0 and hip.conv2d_gn_fold_ok(rows, cols, x.C, x.H * x.W)):
-        return None
-    return FoldedGN(rt, x, gn, rt.buf(x.B, 2))
-
-
 def gn_forward(rt, x, gn):
     """GroupNorm(1, C); gn may be a pair of modules (two-stream launch: second half of the samples = second module)."""
     g0, g1 = _pair(gn)
@@ -738,28 +689,13 @@ def _pgrads_or_scratch(rt, params, sizes):
     return outs, acc
 
 
-def gn_colstats(rt, gn, x):
-    """Buffers for the column statistics a data-gradient conv leaves for the backward pass of the GroupNorm `gn` whose
-    input was `x` (conv2d `colstats`), or None when the shape does not qualify."""
-    if not rt.gn_colstats or isinstance(gn, tuple) or not hip.colstats_ok(x.HW, x.C, x.ld) or x.t.data_ptr() % 16:
-        return None
-    part, tot = hip.colstats_buffers(x.B, x.HW, x.C, x.t.device, totals=True)
-    return (part, x.t, x.ld, gn.weight, tot)
-
-
-def gn_backward(rt, gn, x, ms, dy, out, accumulate=0, add=None, partials=None):
+def gn_backward(rt, gn, x, ms, dy, out, accumulate=0, add=None):
     """out = dx of y = GN(x) given contiguous dy [+ out (accumulate) | + add (another contiguous tensor)].
-    partials: the colstats tuple the conv that produced dy was launched with (its moments are then already there)."""
+    (Round 3 could also take the moments from the epilogue of the data-gradient conv that produced dy -- vrnet_conv_colstats with
+    x2 / gamma, vrnet_gn_apply_bwd_from_partials: measured neutral-to-negative in the step, never on by default; the program path
+    was removed in round 4, the library entry points remain.)"""
     g0, g1 = _pair(gn)
     B, HW, C = x.B, x.HW, x.C
-    if partials is not None and (not accumulate or add is None):
-        (gw, gb), accw = _pgrads_or_scratch(rt, (g0.weight, g0.bias), (C, C))
-        hip.gn_apply_bwd_from_partials(dy, C, x.t, x.ld, partials[0], partials[4], ms, g0.weight, B, HW, C, out, C, gw, gb, accw,
-                                       add=out if accumulate else add, ldadd=C if (accumulate or add is not None) else 0)
-        if rt.on_param_grad:
-            rt.on_param_grad(g0.weight)
-            rt.on_param_grad(g0.bias)
-        return
     if g1 is None and hip.gn_apply_ok(C, x.ld) and (not accumulate or add is None):
         # two launches (moments; apply + parameter gradients) where moments, reduce, coefficients and affine were four
         (gw, gb), accw = _pgrads_or_scratch(rt, (g0.weight, g0.bias), (C, C))
@@ -862,15 +798,9 @@ def cluster_block(rt, x, m, name=None):
     fv = rt.new(B, H, W, 2 * ED)
     if not paired:
         kwq["w_planes"] = rt.planes(wcat, 0, 2 * ED, C, B * H * W)
-    xn = gn_folded(rt, x, m0.norm1, 2 * ED) if kwq.get("w_planes") is not None else None
-    if xn is not None:       # the GroupNorm rides in the conv's A operand: no launch, no normalised tensor on the forward chain
-        ms1 = xn.ms
-        hip.conv2d(x.t, x.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0, precision=2,
-                   gn_input=xn.gn_input(), **kwq)
-    else:
-        xn, ms1 = gn_forward(rt, x, _attr(m, "norm1"))
-        hip.conv2d(xn.t, xn.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0,
-                   precision=rt.prec_fwd(xn.ld, C, 2 * ED), **kwq)
+    xn, ms1 = gn_forward(rt, x, _attr(m, "norm1"))
+    hip.conv2d(xn.t, xn.ld, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0,
+               precision=rt.prec_fwd(xn.ld, C, 2 * ED), **kwq)
     f_t, v_t = fv.t, fv.t[..., ED:]
     o = rt.new(B, H, W, ED)
     idx = rt.buf(B, H, W, E, dtype=torch.uint8)
@@ -894,13 +824,7 @@ def cluster_block(rt, x, m, name=None):
     u = rt.new(B, H, W, hid, need_grad=False) if rt.record else None
     x2 = rt.new(B, H, W, C)
     pmlp = 0 if paired else rt.prec_mlp(C, hid, B * H * W, H * W)
-    xn2 = None
-    if not pmlp and not paired and rt.planes(mlp0.fc1.weight, 0, hid, C, B * H * W) is not None:
-        xn2 = gn_folded(rt, x1, m0.norm2, hid)
-    if xn2 is not None:
-        ms2 = xn2.ms
-    else:
-        xn2, ms2 = gn_forward(rt, x1, _attr(m, "norm2"))
+    xn2, ms2 = gn_forward(rt, x1, _attr(m, "norm2"))
     if pmlp:
         # fc1 -> GELU -> fc2 (+ layer-scale residual, + GroupNorm statistics of the output) as ONE kernel: the hidden
         # activation never reaches HBM; only the pre-activation is stored, for the backward pass
@@ -913,10 +837,7 @@ def cluster_block(rt, x, m, name=None):
         h = None
     else:
         h = rt.new(B, H, W, hid)
-        if isinstance(xn2, FoldedGN):
-            conv_call(rt, x1, mlp0.fc1, h, act=2, ypre=u, gn_input=xn2.gn_input())
-        else:
-            conv_call(rt, xn2, _attr(mlp, "fc1"), h, act=2, ypre=u)
+        conv_call(rt, xn2, _attr(mlp, "fc1"), h, act=2, ypre=u)
         conv_call(rt, h, _attr(mlp, "fc2"), x2, res=x1, res_scale=ls2, stats=True)
 
     def bwd():
@@ -929,7 +850,6 @@ def cluster_block(rt, x, m, name=None):
         # ---- MLP branch
         du = rt.new(B, H, W, hid)
         dxn2 = rt.new(B, H, W, C)
-        cs2 = None
         if pmlp:
             # one kernel: d(pre-activation) and the recomputed activation are written once for the two weight gradients,
             # which run beside the rest of the block's backward like every other weight gradient
@@ -939,10 +859,9 @@ def cluster_block(rt, x, m, name=None):
             conv_backward(rt, xn2, mlp0.fc1, du.t, hid, no_dx=True)
         else:
             conv_backward(rt, h, _attr(mlp, "fc2"), dx2, C, kscale=ls2, aux=u, row_scale=ls2, dx_to=du, ls_grad=ls2)
-            cs2 = None if paired else gn_colstats(rt, m0.norm2, x1)     # d xn2's GroupNorm moments from this conv's epilogue
-            conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2, colstats=cs2)
+            conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2)
         dx1 = rt.buf(B, H, W, C)
-        gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx1, add=dx2, partials=cs2)   # dx1 = dx2 + d(GN -> Mlp branch)
+        gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx1, add=dx2)   # dx1 = dx2 + d(GN -> Mlp branch)
         # ---- Cluster branch
         do = rt.new(B, H, W, ED)
         conv_backward(rt, o, _attr(tm, "fc2"), dx1, C, kscale=ls1, row_scale=ls1, dx_to=do, ls_grad=ls1)
@@ -967,14 +886,11 @@ def cluster_block(rt, x, m, name=None):
         if paired:
             wd1, _, _ = rt.dgrad_operands(tm1, tm1._fused_qkv[0], tm1._fused_qkv[0], 2 * ED, C, 1, 1, None, 2 * ED, B * H * W)
             kwd = dict(pair_rows=rows_half, w2=wd1)
-        cs1 = None if paired else gn_colstats(rt, m0.norm1, x)
-        if cs1 is not None:
-            kwd["colstats"] = cs1
         if not paired and prec == 2:
             kwd["w_planes"] = rt.planes(wcat, 1, C, 2 * ED, B * H * W)
         hip.conv2d(dfv.t, 2 * ED, wd, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1, precision=prec, **kwd)
         dx = rt.buf(B, H, W, C)
-        gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx, add=dx1, partials=cs1)     # dx = dx1 + d(GN -> Cluster branch)
+        gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx, add=dx1)     # dx = dx1 + d(GN -> Cluster branch)
         rt.give_grad(x, dx)
     rt.push(bwd)
     return x2
@@ -1302,7 +1218,7 @@ def _fused_qkv_wgrad(rt, tm, xn, dfv, planes=False):
             if rt.on_param_grad:
                 for prm in (t.fc1.weight, t.fc_v.weight, t.fc1.bias, t.fc_v.bias):     # back to back: adjacent in the arena
                     rt.on_param_grad(prm)
-    rt.aside(wgrad, (xn.t if planes else (xn.keep if isinstance(xn, FoldedGN) else xn.t), dfv.t))
+    rt.aside(wgrad, (xn.t, dfv.t))
 
 
 # ----------------------------------------------------------------------------------------- fusion blocks
@@ -1884,8 +1800,6 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         rt.pair_streams = bool(getattr(model, "pair_streams", False))
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
         rt.bn_colstats = bool(getattr(model, "bn_colstats", True))
-        rt.gn_colstats = bool(getattr(model, "gn_colstats", False))
-        rt.gn_fold = bool(getattr(model, "gn_fold", False))
         rt.forced_idx = getattr(model, "forced_idx_maps", None)
         rt.sync_bn = getattr(model, "_sync_bn", None)
         if rt.sync_bn is not None:

@@ -87,29 +87,13 @@ typedef struct vrnet_conv_colstats {
   const float* gamma;
   double* tile_totals;
 } vrnet_conv_colstats;
-/* GroupNorm(1, C) folded into the A operand of a forward 1x1 conv (round 3; vr_coc.py:105-111 in front of fc1 / fc_v /
- * Mlp.fc1): `a` is the UN-normalised tensor; the kernel re-adds the sample's (sum, sum of squares) tile pairs that the
- * producer of `a` left (`pairs`: [B][pairs_per_sample][2] fp64, the `stats` output of the conv that wrote `a`), in the fixed
- * order of vrnet_gn_apply_fwd, and normalises every fragment in registers with the same expression that function stores
- * -- the conv sees bit-identical operands -- then writes (mean, rstd) per sample to mean_rstd (B, 2).  The normalised
- * tensor itself is never written; a caller that needs it later (the weight gradient) makes it with vrnet_gn_apply_fwd.
- * vrnet_conv2d_gn_fold_ok(rows, cols, K, HW): whether a forward 1x1 launch of rows = B*H*W, cols = Cout, K = Cin takes it
- * (x6 tile kernel, K % 16 == 0, K <= 512, HW % 128 == 0); additionally precision = 2, w_planes, 16-byte aligned rows. */
-typedef struct vrnet_conv_gn_input {
-  const double* pairs; long pairs_per_sample;
-  const float* gamma; const float* beta; float eps;
-  long HW;
-  float* mean_rstd;
-} vrnet_conv_gn_input;
-int vrnet_conv2d_gn_fold_ok(long rows, int cols, int K, long HW);
 int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias, float* y, long ldy,
                      int B, int H, int W, int Cin, int OH, int OW, int Cout, int kh, int kw, int stride, int pad,
                      int dil, int mode, int act, float* ypre, long ldypre, const float* res, long ldres,
                      const float* res_scale, const float* kscale, const float* aux, long ldaux, int out_nchw,
                      int out_ctot, int out_coff, int accumulate, double* stats, int precision, int pair_rows,
                      const float* w2, const float* bias2, const float* res_scale2, const float* kscale2,
-                     const void* w_planes, const vrnet_conv_colstats* colstats, const vrnet_conv_gn_input* gn_input,
-                     void* stream);
+                     const void* w_planes, const vrnet_conv_colstats* colstats, void* stream);
 /* Pre-split weights for the x6 kernels (precision 2, 1x1 convs, contraction % 16 == 0): the six-product scheme spends its
  * VALU time on splitting fragments into bf16 planes; weights are the same for every row tile of a step, so they can be
  * split ONCE per step.  vrnet_conv_planes_pack_f32 does that for a whole table of weights in one launch (round-to-nearest-

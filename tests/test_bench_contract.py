@@ -105,9 +105,10 @@ print("PROBE" + json.dumps(seen))
 
 def test_roofline_families_follow_the_rocprof_summary_of_the_same_round():
     """The per-family rates in the committed headline line (HIP events, gated replay) against FLOPs / rocprofv3 serial
-    duration of the same round's refresh call (profiles/rNN_kernel_stats_*_serial.csv): within 6 % for every family that
-    carries >= 5 % of the FLOPs.  (Round 3's driver line read family 9 27 % low: the event pairs had included the host's launch
-    latency; from round 4 the instrumented replay is issued behind a device-side gate.)"""
+    duration of the same round's refresh call (profiles/rNN_kernel_stats_*_serial.csv), for every family that carries >= 5 % of
+    the FLOPs: the line may read LOW by the dispatch gap + event packets an event pair adds (2.5-7 us per launch: 3-7 % on
+    these 36-155 us launches) and never high.  (Round 3's driver line read family 9 27 % low: the event pairs had included
+    the host's launch latency; from round 4 the instrumented replay is issued behind a device-side gate.)"""
     import csv
     benches = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_phi-l_bs8_512.json")))
     line = json.loads(open(benches[-1]).read().strip().splitlines()[-1])
@@ -134,6 +135,9 @@ def test_roofline_families_follow_the_rocprof_summary_of_the_same_round():
         assert calls and calls % v["launches_per_step"] == 0, (fam, calls, v["launches_per_step"])
         steps = calls // v["launches_per_step"]
         rate = v["share_of_flops"] * total_gf / (ns / steps * 1e-9) / 1e3          # TFLOP/s by rocprofv3
-        assert abs(rate - v["achieved"]) < 0.06 * rate, (fam, "rocprofv3", round(rate, 1), "line", v["achieved"])
+        us_prof = ns / calls / 1e3                                                  # average launch by rocprofv3
+        us_line = us_prof * rate / v["achieved"]                                    # ... by the line's event pairs
+        assert -0.5 < us_line - us_prof < 8.0, (fam, "rocprofv3", round(rate, 1), "line", v["achieved"], us_prof, us_line)
+        assert abs(rate - v["achieved"]) < 0.08 * rate, (fam, "rocprofv3", round(rate, 1), "line", v["achieved"])
         checked += 1
     assert checked >= 2

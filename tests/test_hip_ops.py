@@ -1488,49 +1488,6 @@ def test_x6_conv_with_presplit_weights(hip, case):
     assert 9 in (fam_f, fam_d), (fam_f, fam_d)        # at least one of the two launches had a tile kernel and used the planes
 
 
-@pytest.mark.parametrize("case", [(8, 32, 32, 320, 512), (8, 32, 32, 320, 1280), (2, 128, 128, 64, 256), (4, 64, 64, 128, 192),
-                                  (8, 16, 16, 256, 1024)])
-def test_conv_with_group_norm_folded_input(hip, case):
-    """GroupNorm(1, C) folded into the A operand of the pre-split-weight x6 kernel (vrnet_conv_gn_input): the conv on the RAW
-    tensor must give the very bits of GroupNorm-as-its-own-launch followed by the conv, and the same (mean, rstd)."""
-    B, H, W, Ci, Co = case
-    HW = H * W
-    assert hip.conv2d_gn_fold_ok(B * HW, Co, Ci, HW)
-    g = torch.Generator().manual_seed(7)
-    x = (torch.randn(B, H, W, Ci, generator=g) * 1.3 + 0.4).cuda()
-    gamma, beta = (torch.rand(Ci, generator=g) + 0.5).cuda(), torch.randn(Ci, generator=g).cuda()
-    w, b = (torch.randn(Co, Ci, generator=g) * 0.05).cuda(), torch.randn(Co, generator=g).cuda()
-    # the (sum, sum of squares) pairs per 32 x 32 tile, as the producing conv's epilogue leaves them
-    nb = (Ci + 31) // 32
-    xd = torch.zeros(B * HW, nb * 32, dtype=torch.float64, device="cuda")
-    xd[:, :Ci] = x.view(B * HW, Ci).double()
-    t = xd.view(B * HW // 32, 32, nb, 32)
-    pairs = torch.stack([t.sum((1, 3)), (t * t).sum((1, 3))], -1).contiguous()       # [B*HW/32][nb][2]
-    per = (HW // 32) * nb
-    pf = _planes(hip, w, Co, Ci, Ci, 1)
-    xn, ms0 = torch.empty_like(x), torch.empty(B, 2, device="cuda")
-    hip.gn_apply_fwd(x, Ci, pairs, per, gamma, beta, 1e-5, B, HW, Ci, xn, Ci, ms0)
-    y0, u0 = torch.empty(B, H, W, Co, device="cuda"), torch.empty(B, H, W, Co, device="cuda")
-    hip.conv2d(xn, Ci, w, b, y0, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, act=2, ypre=u0, ldypre=Co, precision=2, w_planes=pf)
-    assert hip.last_kernel() == 9
-    y1, u1, ms1 = torch.empty_like(y0), torch.empty_like(u0), torch.zeros(B, 2, device="cuda")
-    hip.conv2d(x, Ci, w, b, y1, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, act=2, ypre=u1, ldypre=Co, precision=2, w_planes=pf,
-               gn_input=(pairs, per, gamma, beta, 1e-5, HW, ms1))
-    assert hip.last_kernel() == 9
-    assert torch.equal(ms0, ms1)
-    assert torch.equal(u0, u1) and torch.equal(y0, y1)
-    # and against fp64 ATen
-    xr = x.double()
-    mu, var = xr.mean((1, 2, 3), keepdim=True), xr.var((1, 2, 3), unbiased=False, keepdim=True)
-    ref = F.linear((xr - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double(), w.double(), b.double())
-    close(u1, ref, 2e-5, what="conv(GroupNorm(x))")
-    # launches that cannot take it are refused, not silently run on the raw tensor
-    assert not hip.conv2d_gn_fold_ok(B * HW, Co, Ci, HW - 32)
-    with pytest.raises(RuntimeError, match="GroupNorm-folded"):
-        hip.conv2d(x, Ci, w, b, y1, Co, B, H, W, Ci, H, W, Co, 1, 1, 1, 0, 1, precision=0, w_planes=pf,
-                   gn_input=(pairs, per, gamma, beta, 1e-5, HW, ms1))
-
-
 @pytest.mark.parametrize("interleave", [False, True])
 @pytest.mark.parametrize("case", [(37, 8, 8), (1024, 64, 64), (200, 12, 20)])
 def test_cat2_and_adjoint(hip, case, interleave):
