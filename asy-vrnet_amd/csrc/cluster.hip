@@ -281,7 +281,7 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
         f32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = wg[s] * sm[SM_AFIN + kk[s] * 32 + 4 * sub + q];
-        *reinterpret_cast<f32x4*>(p.out + row[s] * p.ldo + e * D + 4 * sub) = o;
+        if (p.out) *reinterpret_cast<f32x4*>(p.out + row[s] * p.ldo + e * D + 4 * sub) = o;
         cl_planes(p.outp, row[s], e * D + 4 * sub, o);
       }
       if (sub == 0) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
           for (int q = 0; q < 4; ++q) o[q] += pw * atq[m][q];
         }
         if (ok[s] && dim_ok) {
-          *reinterpret_cast<f32x4*>(p.dv + row[s] * p.lddf + e * D + 4 * sub) = o;
+          if (p.dv) *reinterpret_cast<f32x4*>(p.dv + row[s] * p.lddf + e * D + 4 * sub) = o;
           cl_planes(p.dfvp, row[s], p.E * D + e * D + 4 * sub, o);
         }
       }
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
       for (int q = 0; q < 4; ++q) o[q] += pw * dcen[m][q];
     }
     if (ok[s] && dim_ok) {
-      *reinterpret_cast<f32x4*>(p.df + row[s] * p.lddf + e * D + 4 * sub) = o;
+      if (p.df) *reinterpret_cast<f32x4*>(p.df + row[s] * p.lddf + e * D + 4 * sub) = o;
       cl_planes(p.dfvp, row[s], e * D + 4 * sub, o);
     }
   }
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
         f32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = wg * sm[SM_AFIN + k * 32 + 4 * sub + q];
-        *reinterpret_cast<f32x4*>(p.out + row * p.ldo + coff) = o;
+        if (p.out) *reinterpret_cast<f32x4*>(p.out + row * p.ldo + coff) = o;
         cl_planes(p.outp, row, coff, o);
       }
     }
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
 #pragma unroll
               for (int q = 0; q < 4; ++q) o[q] += invq * sm[SM_T1 + m * 32 + 4 * sub + q];
             }
-          *reinterpret_cast<f32x4*>(p.dv + row * p.lddf + coff) = o;
+          if (p.dv) *reinterpret_cast<f32x4*>(p.dv + row * p.lddf + coff) = o;
           cl_planes(p.dfvp, row, p.E * p.D + coff, o);
         }
         const float dcn = dc * nf;
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] += invq * dcen[m][q];
       }
-    *reinterpret_cast<f32x4*>(p.df + row * p.lddf + coff) = o;
+    if (p.df) *reinterpret_cast<f32x4*>(p.df + row * p.lddf + coff) = o;
     cl_planes(p.dfvp, row, coff, o);
   }
   {
@@ -811,7 +811,8 @@ static int cluster_fwd_impl(const float* f, const float* v, long ld, const float
   int T, npt;
   int rc = cluster_check("cluster_fwd", f, v, ld, B, H, W, E, D, fold, &T, &npt, 0);
   if (rc) return rc;
-  VR_CHECK_ARG(out && idx && alpha && beta && ldo % 4 == 0 && vr_aligned16(out) && vr_planes_out_ok(outp, E * D), "cluster_fwd: bad output");
+  VR_CHECK_ARG((out || outp) && idx && alpha && beta && (!out || (ldo % 4 == 0 && vr_aligned16(out))) && vr_planes_out_ok(outp, E * D),
+               "cluster_fwd: bad output (the fp32 output may be NULL only with a plane output)");
   VR_CHECK_ARG(T != 0 || wgt, "cluster_fwd: regions of more than 256 points need the similarity map `wgt` (B,H,W,E)");
   VR_CHECK_ARG((!alpha2 == !beta2) && (!alpha2 || B % 2 == 0), "cluster_fwd: a two-stream launch needs alpha2, beta2 and an even batch");
   ClusterArgs p{};
@@ -862,8 +863,9 @@ static int cluster_bwd_impl(const float* f, const float* v, long ld, const float
   int T, npt;
   int rc = cluster_check("cluster_bwd", f, v, ld, B, H, W, E, D, fold, &T, &npt, 1);
   if (rc) return rc;
-  VR_CHECK_ARG(idx && dout && df && dv && dalpha && dbeta && workspace, "cluster_bwd: null tensor");
-  VR_CHECK_ARG(lddo % 4 == 0 && lddf % 4 == 0 && vr_aligned16(dout) && vr_aligned16(df) && vr_aligned16(dv) &&
+  VR_CHECK_ARG(idx && dout && ((df && dv) || (dfvp && !df && !dv)) && dalpha && dbeta && workspace,
+               "cluster_bwd: null tensor (df / dv may both be NULL only with a plane output)");
+  VR_CHECK_ARG(lddo % 4 == 0 && vr_aligned16(dout) && (!df || (lddf % 4 == 0 && vr_aligned16(df) && vr_aligned16(dv))) &&
                    vr_planes_out_ok(dfvp, 2 * E * D),
                "cluster_bwd: rows must be 16-byte aligned");
   const long blocks = (long)B * E * fold * fold;

@@ -957,15 +957,15 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
                    precision=rt.prec_fwd(C, C, 2 * ED), w_planes=rt.planes(wcat, 0, 2 * ED, C, M))
     # ---- Cluster core -> proj
     f_t, v_t = fv.t, fv.t[..., ED:]
-    o = f32(ED)
     o_p = P(ED) if (proj[0] or (rec and proj[2])) else None
+    o = f32(ED) if (not proj[0] or (rec and not proj[2])) else None      # the fp32 form only while a consumer still wants it
     idx = rt.buf(B, H, W, E, dtype=torch.uint8)
     big = (H // max(fold, 1)) * (W // max(fold, 1)) > 256
     forced = rt.forced_idx is not None and name is not None and name in rt.forced_idx
     if forced:
         idx.copy_(rt.forced_idx[name])
-    hip.cluster_fwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, o.t, ED, idx, rt.buf(B, H, W, E) if big else None,
-                    B, H, W, E, Dh, fold, forced=forced, planes=o_p)
+    hip.cluster_fwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, None if o is None else o.t, ED, idx,
+                    rt.buf(B, H, W, E) if big else None, B, H, W, E, Dh, fold, forced=forced, planes=o_p)
     if name is not None:
         rt.idx_maps[name] = idx
     x1 = f32(C)
@@ -1126,12 +1126,12 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
             wd, ks, prec = rt.dgrad_operands(tm.fc2, tm.fc2.weight, tm.fc2.weight, C, ED, 1, 1, ls1, C, M)
             hip.conv2d(dx1, C, wd, None, do.t, ED, B, H, W, ED, H, W, C, 1, 1, 1, 0, 1, mode=1, kscale=ks, precision=prec,
                        w_planes=rt.planes(tm.fc2.weight, 1, ED, C, M, kscale=ks) if prec == 2 else None)
-        wgrad(o.t, o_p, dx1, dx1_p, tm.fc2, ED, C, proj[2], row_scale=ls1, ls=ls1)
-        dfv = f32(2 * ED)
+        wgrad(None if o is None else o.t, o_p, dx1, dx1_p, tm.fc2, ED, C, proj[2], row_scale=ls1, ls=ls1)
         dfv_p = P(2 * ED) if (fcfv[1] or fcfv[2]) else None
+        dfv = f32(2 * ED) if (not fcfv[1] or not fcfv[2]) else None
         (ga, gb_), acca = _pgrads_or_scratch(rt, (tm.sim_alpha, tm.sim_beta), (1, 1))
-        hip.cluster_bwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, idx, do.t, ED, dfv.t, dfv.t[..., ED:], 2 * ED, ga, gb_,
-                        acca, B, H, W, E, Dh, fold, planes=dfv_p)
+        hip.cluster_bwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, idx, do.t, ED, None if dfv is None else dfv.t,
+                        None if dfv is None else dfv.t[..., ED:], 2 * ED, ga, gb_, acca, B, H, W, E, Dh, fold, planes=dfv_p)
         if rt.on_param_grad:
             rt.on_param_grad(tm.sim_alpha)
             rt.on_param_grad(tm.sim_beta)

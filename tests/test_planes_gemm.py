@@ -308,6 +308,9 @@ def test_producers_write_the_planes_of_what_they_store(hip, case, np_):
     hip.cluster_fwd(f, v, C, al, be, out0, C, idx, wgt, B, H, W, E, D, fold)
     assert torch.equal(out, out0)
     check(op, out, "cluster_fwd planes")
+    op2 = hip.Planes.empty(np_, (B, H, W, C), "cuda")
+    hip.cluster_fwd(f, v, C, al, be, None, C, idx, wgt, B, H, W, E, D, fold, planes=op2)         # planes only
+    assert torch.equal(op2.t, op.t)
     go = rnd(B, H, W, C, seed=8).cuda()
     dfv, dfv0 = torch.empty(B, H, W, 2 * C, device="cuda"), torch.empty(B, H, W, 2 * C, device="cuda")
     dab = torch.zeros(2, device="cuda")
@@ -316,3 +319,6 @@ def test_producers_write_the_planes_of_what_they_store(hip, case, np_):
     hip.cluster_bwd(f, v, C, al, be, idx, go, C, dfv0, dfv0[..., C:], 2 * C, dab[0:1], dab[1:2], 0, B, H, W, E, D, fold)
     assert torch.equal(dfv, dfv0)
     check(dfvp, dfv, "cluster_bwd planes [df | dv]")
+    dfvp2 = hip.Planes.empty(np_, (B, H, W, 2 * C), "cuda")
+    hip.cluster_bwd(f, v, C, al, be, idx, go, C, None, None, 2 * C, dab[0:1], dab[1:2], 0, B, H, W, E, D, fold, planes=dfvp2)   # planes only
+    assert torch.equal(dfvp2.t, dfvp.t)

@@ -22,13 +22,18 @@ def main():
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
-    # steps are separated by the largest gaps; take the tail after the last big gaps
+    # a step begins with the once-per-forward weight split (planes_pack_kernel / planes_split_kernel): take the last `nsteps`
+    # whole steps (tracing stretches a step; host-side gaps are not a reliable boundary)
     nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-    gaps = sorted(((rows[i + 1][0] - max(r[1] for r in rows[max(0, i - 50):i + 1]), i) for i in range(len(rows) - 1)), reverse=True)
-    cuts = sorted(i for g, i in gaps[:40] if g > 200000)          # > 0.2 ms idle = host-side step boundary
-    if len(cuts) >= nsteps:
-        rows = rows[cuts[-nsteps] + 1:]
-        # drop trailing non-step kernels after the last cut? keep: they belong to the last step
+    marks = [i for i, r in enumerate(rows) if r[2].startswith(("planes_pack_kernel", "planes_split_kernel"))]
+    # (in eager runs the marker also fires at first-use registrations: keep marks that are >= 5 ms apart)
+    steps = [m for k, m in enumerate(marks) if k == 0 or rows[m][0] - rows[marks[k - 1]][0] > 5_000_000]
+    if len(steps) > nsteps:
+        # the last marker opens the final step, which ends with the trace: use the nsteps steps before it
+        rows = rows[steps[-nsteps - 1]:steps[-1]]
+    elif len(steps) >= 2:
+        nsteps = len(steps) - 1
+        rows = rows[steps[0]:steps[-1]]
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     ev = []
     for s, e, n in rows:
