@@ -58,12 +58,18 @@ constexpr int PG_PLANE = 128 * 64;                      // one plane image of a 
 // DBG (diagnostic build only): bit 0 = no MFMAs, bit 1 = no DMA inside the loop (the ring keeps the prologue's stages),
 // bit 2 = no fragment reads inside the loop: timing ablations, results garbage.
 template <int NP, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void pgemm_kernel(const IgemmArgs p, const PlaneOps o, int MT, int NT) {
+__global__ __launch_bounds__(512, NP == 1 ? 4 : 2) void pgemm_kernel(const IgemmArgs p, const PlaneOps o, int MT, int NT) {
   constexpr int OPER = NP * PG_PLANE;                  // one operand of a stage
   constexpr int ST_BYTES = 2 * OPER;                   // 48 KB (NP = 3) / 16 KB (NP = 1)
   constexpr int P = 2 * NP;                            // DMA pieces per wave and stage
   constexpr int XCH = 4 * 2 * 32 * 256;                // K-half exchange: 4 wave pairs x 2 directions x 32 registers x 256 B
-  constexpr int LDS_BYTES = (PG_NST * ST_BYTES > XCH + 8 * 32 * STAGE_LD * 4) ? PG_NST * ST_BYTES : XCH + 8 * 32 * STAGE_LD * 4;
+  // np = 3: the ring (144 KB) covers exchange + staging.  np = 1: the ring is 48 KB; the staging tiles REUSE the exchange area
+  // (one more barrier) so that a workgroup holds 64 KB and two fit a CU: with bf16 operands a tile is a few microseconds of
+  // matrix work, and a second workgroup is what covers its prologue and its store-heavy epilogue.
+  constexpr int STG = 8 * 32 * STAGE_LD * 4;
+  constexpr int LDS_BYTES = NP == 1 ? (XCH > PG_NST * ST_BYTES ? XCH : PG_NST * ST_BYTES)
+                                    : ((PG_NST * ST_BYTES > XCH + STG) ? PG_NST * ST_BYTES : XCH + STG);
+  static_assert(STG <= XCH, "staging tiles must fit the exchange area");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -249,7 +255,8 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const IgemmArgs p, const 
 #pragma unroll
         for (int e = 0; e < 4; ++e) fin[j][r + e] = (wk ? acc[1][j][r + e] : acc[0][j][r + e]) + v[e];
       }
-    float* stage = reinterpret_cast<float*>(smem + XCH) + wave * (32 * STAGE_LD);
+    if constexpr (NP == 1) __syncthreads();      // every wave has read its partner's half: the exchange area becomes the staging tiles
+    float* stage = reinterpret_cast<float*>(smem + (NP == 1 ? 0 : XCH)) + wave * (32 * STAGE_LD);
     const int row0 = m0 + wm * 64 + wk * 32, col0 = n0 + wn * 64;
     igemm_epilogue_tile(p, fin[0], stage, row0, col0);
     igemm_epilogue_tile(p, fin[1], stage, row0, col0 + 32);
@@ -276,7 +283,7 @@ struct PwgradArgs {
 };
 
 template <int NP>
-__global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradArgs p) {
+__global__ __launch_bounds__(512, NP == 1 ? 4 : 2) void pwgrad_kernel(const PwgradArgs p) {
   constexpr int PLANE = 32 * 256;                      // one plane image of a stage: 32 rows x 256 bytes
   constexpr int OPER = NP * PLANE, ST_BYTES = 2 * OPER, P = 2 * NP;
   constexpr int XCH = 4 * 2 * 32 * 256;
@@ -330,6 +337,8 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradArgs p) {
     if (++ld_buf == PG_NST) ld_buf = 0;
   };
 
+  // bacc: the bias gradient of ONE 32-channel block per wave -- wave (wm, wn, wk) takes block wn of its 64 output channels
+  // (both fragments are in its registers anyway) over its half wk of the rows
   f32x16 acc[2][2], bacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -365,6 +374,36 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradArgs p) {
   const __bf16 one = (__bf16)1.0f;
   const vr_bf16x8 ones = {one, one, one, one, one, one, one, one};
 
+  if constexpr (NP == 1) {
+    // bf16 tensors: a stage is 8 MFMAs per SIMD -- two workgroups per CU (64 KB of LDS, <= 128 registers) cover each other's
+    // waits, so the loop is the plain ring: wait for stage s, ONE barrier, refill the slot read last time, fragments, MFMAs
+#pragma unroll
+    for (int st = 0; st < PG_NST - 1; ++st)
+      if (st < nsteps) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) issue_piece(i);
+        issue_end();
+      }
+    PFrag<NP> F;
+    int cur = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0x0F72);      // vmcnt(P): stage s + 1 may still be in flight
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const bool more = s + PG_NST - 1 < nsteps;
+      read_frags(F, cur);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = t >> 1, jj = t & 1;
+        acc[i][jj] = vp_products<NP>(F.a[i], F.b[jj], acc[i][jj]);
+        if (more && t < P) issue_piece(t);
+      }
+      if (more) issue_end();
+      if (do_bias) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wn ? F.a[1][0] : F.a[0][0], ones, bacc, 0, 0, 0);
+      if (++cur == PG_NST) cur = 0;
+    }
+  } else {
 #pragma unroll
   for (int st = 0; st < PG_NST; ++st)
     if (st < nsteps) {
@@ -397,21 +436,10 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradArgs p) {
       }
     }
     if (more) issue_end();
-    if (do_bias && wn == 0) {      // column sums of dy: every plane times ones, small planes first (exact products)
+    if (do_bias) {      // column sums of dy: every plane times ones, small planes first (exact products)
 #pragma unroll
-      for (int q = NP - 1; q >= 0; --q) {
-        bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Fc.a[0][q], ones, bacc, 0, 0, 0);
-      }
-    }
-  };
-  // (the second 32-column block of the bias goes through a second accumulator only when needed: see below)
-  f32x16 bacc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) bacc1[r] = 0.f;
-  auto bias1 = [&](PFrag<NP>& Fc) {
-    if (do_bias && wn == 0) {
-#pragma unroll
-      for (int q = NP - 1; q >= 0; --q) bacc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Fc.a[1][q], ones, bacc1, 0, 0, 0);
+      for (int q = NP - 1; q >= 0; --q)
+        bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wn ? Fc.a[1][q] : Fc.a[0][q], ones, bacc, 0, 0, 0);
     }
   };
   auto step_main = [&](PFrag<NP>& Fc, PFrag<NP>& Fn) {
@@ -419,7 +447,6 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradArgs p) {
     read_frags(Fn, rd_buf);
     __builtin_amdgcn_sched_barrier(0);
     mfmas(Fc, true);
-    bias1(Fc);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(W_LGKM0_VM_P);
     __builtin_amdgcn_s_barrier();
@@ -434,7 +461,6 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     mfmas(Fc, more);
-    bias1(Fc);
     __builtin_amdgcn_sched_barrier(0);
     if (s + 2 < nsteps && !more) __builtin_amdgcn_s_waitcnt(W_LGKM0_VM0);
     else if (more) __builtin_amdgcn_s_waitcnt(W_LGKM0_VM_P);
@@ -452,6 +478,7 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradArgs p) {
     step_tail(F1, F0, s + 1);
   }
   if (s < nsteps) step_tail(F0, F1, s);
+  }
   __syncthreads();
 
   // ---- the two halves of the contraction meet (as in pgemm_kernel); wave (wk = 0) stores n-block 0, its partner n-block 1
@@ -468,13 +495,9 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradArgs p) {
       *reinterpret_cast<f32x4*>(mine + ((jj * 4 + (r >> 2)) * 64 + lane) * 4) = v;
     }
   float* bx = reinterpret_cast<float*>(smem + XCH);      // bias partials of the wk = 1 waves: [pair][2 blocks][32 rows... via acc map]
-  if (do_bias && wn == 0 && wk == 1 && (lane & 31) == 0) {
+  if (do_bias && wk == 1 && (lane & 31) == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      bx[wm * 64 + row] = bacc[r];
-      bx[wm * 64 + 32 + row] = bacc1[r];
-    }
+    for (int r = 0; r < 16; ++r) bx[(wm * 2 + wn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = bacc[r];
   }
   __syncthreads();
   float* slab = p.slab + (long)split * p.Cout * p.Cin;
@@ -492,13 +515,12 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradArgs p) {
       }
     }
   }
-  if (do_bias && wn == 0 && wk == 0 && (lane & 31) == 0) {      // every column of the ones product holds the same sums
+  if (do_bias && wk == 0 && (lane & 31) == 0) {      // every column of the ones product holds the same sums
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int na = n0 + wm * 64 + row, nb = na + 32;
-      if (na < p.Cout) p.bslab[(long)split * p.Cout + na] = bacc[r] + bx[wm * 64 + row];
-      if (nb < p.Cout) p.bslab[(long)split * p.Cout + nb] = bacc1[r] + bx[wm * 64 + 32 + row];
+      const int n = n0 + (wm * 2 + wn) * 32 + row;
+      if (n < p.Cout) p.bslab[(long)split * p.Cout + n] = bacc[r] + bx[(wm * 2 + wn) * 32 + row];
     }
   }
 }
@@ -664,10 +686,11 @@ int vr_wgrad_reduce_launch(float* slab, float* bslab, float* ls_part, long ls_st
                            const float* row_scale2, float* dw2, float* dbias2, const float* w, const float* w2,
                            const float* bias, const float* bias2, float* dls, float* dls2, hipStream_t st);
 
-static void pwgrad_plan(long M, int Cin, int Cout, int* nt, int* ct, int* S, int* rows) {
+static void pwgrad_plan(long M, int Cin, int Cout, int np, int* nt, int* ct, int* S, int* rows) {
   *nt = (int)vr_cdiv(Cout, 128); *ct = (int)vr_cdiv(Cin, 128);
   const long tiles = (long)*nt * *ct;
-  static const int target = vr_tune("VRNET_PWGRAD_WGS", 256);      // one workgroup per CU
+  static const int wgs = vr_tune("VRNET_PWGRAD_WGS", 256);
+  const int target = np == 1 ? 2 * wgs : wgs;                      // workgroups per CU: one (np = 3), two (np = 1)
   long s = 8 * (target / (8 * tiles));                             // multiples of 8: a split's tiles share an XCD
   if (s < 8) s = vr_cdiv(target, tiles);
   const long smax = vr_cdiv(M, 128), sbytes = (48L << 20) / ((long)Cout * Cin * 4);
@@ -686,7 +709,7 @@ extern "C" int vrnet_wgrad_planes_ok(long M, int Cin, int Cout) {
 
 extern "C" long vrnet_wgrad_planes_workspace(long M, int Cin, int Cout) {
   int nt, ct, S, rows;
-  pwgrad_plan(M, Cin, Cout, &nt, &ct, &S, &rows);
+  pwgrad_plan(M, Cin, Cout, 1, &nt, &ct, &S, &rows);      // (the np = 1 plan has the most splits)
   return ((long)S * ((long)Cout * Cin + Cout) + (long)Cout * Cin + Cout) * 4 + 256;
 }
 
@@ -706,7 +729,7 @@ extern "C" int vrnet_wgrad_planes_f32(const void* x, long ldx, long x_plane, con
   VR_CHECK_ARG(!dls || (w && (!bias || dbias)), "wgrad_planes: the layer-scale gradient needs the weights and (with a bias) the bias gradient");
   if (vr_ablated("wgrad")) return VR_OK;
   int nt, ct, S, rows;
-  pwgrad_plan(M, Cin, Cout, &nt, &ct, &S, &rows);
+  pwgrad_plan(M, Cin, Cout, np, &nt, &ct, &S, &rows);
   const long need = vrnet_wgrad_planes_workspace(M, Cin, Cout);
   if (workspace_bytes < need) {
     vr_set_error("wgrad_planes: workspace %ld < %ld bytes", workspace_bytes, need);
