@@ -26,7 +26,13 @@ struct ClusterArgs {
   int forced;          // forward: idx is an INPUT (teacher-forced assignment: parity tests), not computed here
   // optional bf16-plane copies (csrc/pgemm.hip): forward `out`; backward [df | dv] as ONE tensor of 2 E D columns (df first)
   vrnet_planes_out outp, dfvp;
+  int in_bf16;         // f, v (and, backward, g) are bf16 tensors (row strides in elements): compute_dtype "bf16" with bf16 tensors
 };
+__device__ __forceinline__ f32x4 cl_ld4(const float* base, long off, int bf16) {
+  if (!bf16) return *reinterpret_cast<const f32x4*>(base + off);
+  const vr_bf16x4 v = *reinterpret_cast<const vr_bf16x4*>(reinterpret_cast<const unsigned short*>(base) + off);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
 __device__ __forceinline__ void cl_planes(const vrnet_planes_out& o, long row, int col, const f32x4 v) {
   if (o.p) vr_store_planes4(reinterpret_cast<unsigned short*>(o.p) + row * o.ld + col, o.plane, o.np, v);
 }
@@ -172,8 +178,8 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
     inq[s] = ok[s] ? ((r0 & c0) | ((r0 & c1) << 1) | ((r1 & c0) << 2) | ((r1 & c1) << 3)) : 0u;
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
     if (ok[s] && dim_ok) {
-      a = *reinterpret_cast<const f32x4*>(p.f + row[s] * p.ld + e * D + 4 * sub);
-      c = *reinterpret_cast<const f32x4*>(p.v + row[s] * p.ld + e * D + 4 * sub);
+      a = cl_ld4(p.f, row[s] * p.ld + e * D + 4 * sub, p.in_bf16);
+      c = cl_ld4(p.v, row[s] * p.ld + e * D + 4 * sub, p.in_bf16);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(MAXT) void cluster_kernel(const ClusterArgs p) {
 #pragma unroll
   for (int s = 0; s < NPT; ++s) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    if (ok[s] && dim_ok) a = *reinterpret_cast<const f32x4*>(p.g + row[s] * p.ldg + e * D + 4 * sub);
+    if (ok[s] && dim_ok) a = cl_ld4(p.g, row[s] * p.ldg + e * D + 4 * sub, p.in_bf16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) g[s][q] = a[q];
   }
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
   };
   auto load4 = [&](const float* base, long ld, long row, bool ok, float (&o)[4]) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    if (ok && dim_ok) a = *reinterpret_cast<const f32x4*>(base + row * ld + coff);
+    if (ok && dim_ok) a = cl_ld4(base, row * ld + coff, p.in_bf16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = a[q];
   };
@@ -789,10 +795,12 @@ extern "C" int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, co
 }
 /* The same with a second copy of `out` as bf16 planes (the A operand of the proj conv's plane GEMM and the x operand of its
  * weight gradient); forced != 0: the teacher-forced form. */
-extern "C" int vrnet_cluster_fwd_planes_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
-                                            float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E,
-                                            int D, int fold, int forced, const vrnet_planes_out* outp, void* stream) {
-  return cluster_fwd_impl(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, D, fold, nullptr, nullptr, forced ? 1 : 0, outp, stream);
+extern "C" int vrnet_cluster_fwd_planes_f32(const void* f, const void* v, long ld, int in_bf16, const float* alpha,
+                                            const float* beta, float* out, long ldo, unsigned char* idx, float* wgt, int B,
+                                            int H, int W, int E, int D, int fold, int forced, const vrnet_planes_out* outp,
+                                            void* stream) {
+  return cluster_fwd_impl(reinterpret_cast<const float*>(f), reinterpret_cast<const float*>(v), ld, alpha, beta, out, ldo, idx, wgt,
+                          B, H, W, E, D, fold, nullptr, nullptr, (forced ? 1 : 0) | (in_bf16 ? 2 : 0), outp, stream);
 }
 
 /* The same forward with the hard assignment GIVEN (idx is read, not written): every point goes to the centre idx names,
@@ -819,7 +827,8 @@ static int cluster_fwd_impl(const float* f, const float* v, long ld, const float
   p.alpha2 = alpha2; p.beta2 = beta2;
   p.f = f; p.v = v; p.ld = ld; p.alpha = alpha; p.beta = beta; p.out = out; p.ldo = ldo; p.idx = idx; p.wgt = wgt;
   p.B = B; p.H = H; p.W = W; p.E = E; p.D = D; p.fold = fold;
-  p.forced = forced;
+  p.forced = forced & 1;
+  p.in_bf16 = (forced >> 1) & 1;
   if (outp) p.outp = *outp;
   cluster_launch<false>(p, T, npt, (long)B * E * fold * fold, vr_stream(stream));
   VR_LAUNCH_CHECK("cluster_fwd");
@@ -847,19 +856,22 @@ extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, co
 }
 /* The same with a second copy of [df | dv] (one tensor of 2 E D columns, df first) as bf16 planes: the dy operand of the
  * fc1 | fc_v data- and weight-gradient plane GEMMs. */
-extern "C" int vrnet_cluster_bwd_planes_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
-                                            const unsigned char* idx, const float* dout, long lddo, float* df, float* dv,
-                                            long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
-                                            int E, int D, int fold, const vrnet_planes_out* dfvp, void* workspace,
+extern "C" int vrnet_cluster_bwd_planes_f32(const void* f, const void* v, long ld, int in_bf16, const float* alpha,
+                                            const float* beta, const unsigned char* idx, const void* dout, long lddo, float* df,
+                                            float* dv, long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H,
+                                            int W, int E, int D, int fold, const vrnet_planes_out* dfvp, void* workspace,
                                             long workspace_bytes, void* stream) {
-  return cluster_bwd_impl(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, dbeta, accumulate_ab, B, H, W, E, D, fold,
-                          nullptr, nullptr, nullptr, nullptr, dfvp, workspace, workspace_bytes, stream);
+  return cluster_bwd_impl(reinterpret_cast<const float*>(f), reinterpret_cast<const float*>(v), ld, alpha, beta, idx,
+                          reinterpret_cast<const float*>(dout), lddo, df, dv, lddf, dalpha, dbeta, (accumulate_ab ? 1 : 0) | (in_bf16 ? 2 : 0),
+                          B, H, W, E, D, fold, nullptr, nullptr, nullptr, nullptr, dfvp, workspace, workspace_bytes, stream);
 }
 static int cluster_bwd_impl(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                             const unsigned char* idx, const float* dout, long lddo, float* df, float* dv,
                             long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
                             int E, int D, int fold, const float* alpha2, const float* beta2, float* dalpha2,
                             float* dbeta2, const vrnet_planes_out* dfvp, void* workspace, long workspace_bytes, void* stream) {
+  const int in_bf16 = (accumulate_ab >> 1) & 1;      // (bit 1: set by vrnet_cluster_bwd_planes_f32 only)
+  accumulate_ab &= 1;
   int T, npt;
   int rc = cluster_check("cluster_bwd", f, v, ld, B, H, W, E, D, fold, &T, &npt, 1);
   if (rc) return rc;
@@ -880,6 +892,7 @@ static int cluster_bwd_impl(const float* f, const float* v, long ld, const float
   p.alpha2 = alpha2; p.beta2 = beta2;
   p.f = f; p.v = v; p.ld = ld; p.alpha = alpha; p.beta = beta; p.idx = const_cast<unsigned char*>(idx);
   p.g = dout; p.ldg = lddo; p.df = df; p.dv = dv; p.lddf = lddf;
+  p.in_bf16 = in_bf16;
   if (dfvp) p.dfvp = *dfvp;
   p.ab_partial = reinterpret_cast<float*>(workspace);
   p.wgt = p.ab_partial + ((blocks * 2 + 63) / 64) * 64;       // streaming kernel: per-point d cos scratch

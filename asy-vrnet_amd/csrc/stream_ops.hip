@@ -14,13 +14,18 @@ namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p);
 __device__ __forceinline__ double block_sum(double v, double* red);
+// The pre-activation of a normalisation apply, A (x - S) + D, as ONE fused multiply-add everywhere it is evaluated: the
+// backward kernels that recompute a ReLU mask from z get the forward's bits.
+__device__ __forceinline__ float bn_pre(float A, float x, float S, float D) { return __builtin_fmaf(A, x - S, D); }
 
 // ------------------------------------------------------------------------------------------ moments
 template <int VEC>
 __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, const float* x2, long ldx2,
                                                       const float* mask, long ldm, long HW, int C, int TPR,
                                                       long rows_per_chunk, int nchunks, double* partial, int total_only,
-                                                      const float* gamma = nullptr, double* gtot = nullptr) {
+                                                      const float* gamma = nullptr, double* gtot = nullptr,
+                                                      const float* mA = nullptr, const float* mD = nullptr,
+                                                      const float* mS = nullptr) {
   extern __shared__ double sm[];   // [256][2*VEC]
   const int tid = threadIdx.x;
   const int tx = tid % TPR, ty = tid / TPR, RP = 256 / TPR;
@@ -34,11 +39,21 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, long ldx, 
   for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0;
   if (cv < CV) {
     const long base = (long)b * HW;
+    // mA: the ReLU mask is not read but recomputed from x2 = z with the forward coefficients -- bn_pre() is the expression
+    // the forward apply evaluated, so the bits agree
+    float fa[VEC], fd[VEC], fs[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      fa[j] = mA ? mA[cv * VEC + j] : 0.f;
+      fd[j] = mA ? mD[cv * VEC + j] : 0.f;
+      fs[j] = mA ? mS[cv * VEC + j] : 0.f;
+    }
     auto accum = [&](const float (&a)[VEC], const float (&c2)[VEC], const float (&mk)[VEC]) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         float v = a[j];
         if (mask && !(mk[j] > 0.f)) v = 0.f;
+        if (mA && !(bn_pre(fa[j], c2[j], fs[j], fd[j]) > 0.f)) v = 0.f;
         s1[j] += (double)v;
         s2[j] += (double)v * (double)(x2 ? c2[j] : v);
       }
@@ -268,6 +283,7 @@ struct AffineArgs {
   float* out; long ldo;
   long HW; int C; long bstride; int pre; int accumulate;
   const float* add; long ldadd;      // plain addend (out-of-place accumulate); accumulate = 1 is add == out
+  const float* mA; const float* mD; const float* mS;   // pre == 3: ReLU mask = [mA (x2 - mS) + mD > 0], per channel
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -286,7 +302,11 @@ __device__ __forceinline__ void affine_one(const AffineArgs& p, long row, long c
     if (p.pre == 2) mk = ld4(p.masky + row * p.ldm + c);
     float* o = p.out + row * p.ldo + c;
     if (p.add) acc = ld4(p.add + row * p.ldadd + c);
-    if (p.x1) v += (p.A ? ld4(p.A + cb + c) : one) * (a - (p.S1 ? ld4(p.S1 + cb + c) : zero));
+    if (p.x1) {
+      const f32x4 Aq = p.A ? ld4(p.A + cb + c) : one, Sq = p.S1 ? ld4(p.S1 + cb + c) : zero;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = bn_pre(Aq[j], a[j], Sq[j], v[j]);
+    }
     if (p.pre == 1) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -294,6 +314,11 @@ __device__ __forceinline__ void affine_one(const AffineArgs& p, long row, long c
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (!(mk[j] > 0.f)) v[j] = 0.f;
+    } else if (p.pre == 3) {
+      const f32x4 fa = ld4(p.mA + c), fd = ld4(p.mD + c), fs = ld4(p.mS + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!(bn_pre(fa[j], x2[j], fs[j], fd[j]) > 0.f)) v[j] = 0.f;
     }
     if (p.x2) v += (p.E ? ld4(p.E + cb + c) : one) * (x2 - (p.S2 ? ld4(p.S2 + cb + c) : zero));
     if (p.D2) v += ld4(p.D2 + cb + c);
@@ -301,9 +326,10 @@ __device__ __forceinline__ void affine_one(const AffineArgs& p, long row, long c
     *reinterpret_cast<f32x4*>(o) = v;
   } else {
     float v = p.D1 ? p.D1[cb + c] : 0.f;
-    if (p.x1) v += (p.A ? p.A[cb + c] : 1.f) * (p.x1[row * p.ld1 + c] - (p.S1 ? p.S1[cb + c] : 0.f));
+    if (p.x1) v = bn_pre(p.A ? p.A[cb + c] : 1.f, p.x1[row * p.ld1 + c], p.S1 ? p.S1[cb + c] : 0.f, v);
     if (p.pre == 1) v = fmaxf(v, 0.f);
     else if (p.pre == 2 && !(p.masky[row * p.ldm + c] > 0.f)) v = 0.f;
+    else if (p.pre == 3 && !(bn_pre(p.mA[c], p.x2[row * p.ld2 + c], p.mS[c], p.mD[c]) > 0.f)) v = 0.f;
     if (p.x2) v += (p.E ? p.E[cb + c] : 1.f) * (p.x2[row * p.ld2 + c] - (p.S2 ? p.S2[cb + c] : 0.f));
     if (p.D2) v += p.D2[cb + c];
     float* o = p.out + row * p.ldo + c;
@@ -791,7 +817,8 @@ extern "C" long vrnet_moments_workspace(int B, long HW, int C) {
 
 static int moments_launch(const float* x, long ldx, const float* x2, long ldx2, const float* mask, long ldm, int B,
                           long HW, int C, void* workspace, long workspace_bytes, hipStream_t st, int* nchunks_out,
-                          int total_only = 0, const float* gamma = nullptr, double* gtot = nullptr, int* ncb_out = nullptr) {
+                          int total_only = 0, const float* gamma = nullptr, double* gtot = nullptr, int* ncb_out = nullptr,
+                          const float* mA = nullptr, const float* mD = nullptr, const float* mS = nullptr) {
   if (vr_ablated("moments")) { if (nchunks_out) *nchunks_out = 1; return VR_OK; }
   VR_CHECK_ARG(x && workspace, "moments: null tensor");
   VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && ldx >= C, "moments: bad shape");
@@ -809,10 +836,10 @@ static int moments_launch(const float* x, long ldx, const float* x2, long ldx2, 
   dim3 grid(nchunks, B, ncb), block(256);
   if (vec)
     hipLaunchKernelGGL((moments_kernel<4>), grid, block, 256 * 8 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
-                       TPR, rows, nchunks, partial, total_only, gamma, gtot);
+                       TPR, rows, nchunks, partial, total_only, gamma, gtot, mA, mD, mS);
   else
     hipLaunchKernelGGL((moments_kernel<1>), grid, block, 256 * 2 * sizeof(double), st, x, ldx, x2, ldx2, mask, ldm, HW, C,
-                       TPR, rows, nchunks, partial, total_only, gamma, gtot);
+                       TPR, rows, nchunks, partial, total_only, gamma, gtot, mA, mD, mS);
   VR_LAUNCH_CHECK("moments");
   if (ncb_out) *ncb_out = ncb;
   *nchunks_out = total_only ? nchunks * ncb : nchunks;
@@ -860,22 +887,24 @@ extern "C" int vrnet_gn_stats_fwd(const float* x, long ldx, const float* gamma, 
   return VR_OK;
 }
 
-extern "C" int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1, const float* S1, int pre,
-                                const float* masky, long ldm, const float* x2, long ld2, const float* E,
-                                const float* D2, const float* S2, long coef_bstride, float* out, long ldo, int B,
-                                long HW, int C, int accumulate, const float* add, long ldadd, void* stream) {
+static int affine_impl(const float* x1, long ld1, const float* A, const float* D1, const float* S1, int pre,
+                       const float* masky, long ldm, const float* x2, long ld2, const float* E, const float* D2,
+                       const float* S2, long coef_bstride, float* out, long ldo, int B, long HW, int C, int accumulate,
+                       const float* add, long ldadd, const float* mA, const float* mD, const float* mS, void* stream) {
   VR_CHECK_ARG(out && B > 0 && HW > 0 && C > 0, "affine: bad arguments");
   if (vr_ablated("affine")) return VR_OK;
   VR_CHECK_ARG(pre != 2 || masky, "affine: mask mode without mask tensor");
+  VR_CHECK_ARG(pre != 3 || (mA && mD && mS && x2), "affine: recomputed-mask mode needs z (x2) and the forward coefficients");
   VR_CHECK_ARG(!(accumulate && add), "affine: accumulate (in place) and add (out of place) are exclusive");
   if (accumulate) { add = out; ldadd = ldo; }
-  AffineArgs p{x1, ld1, A, D1, S1, masky, ldm, x2, ld2, E, D2, S2, out, ldo, HW, C, coef_bstride, pre, accumulate, add, ldadd};
+  AffineArgs p{x1, ld1, A, D1, S1, masky, ldm, x2, ld2, E, D2, S2, out, ldo, HW, C, coef_bstride, pre, accumulate, add, ldadd,
+               mA, mD, mS};
   bool vec = (C % 4 == 0) && (ldo % 4 == 0) && vr_aligned16(out) && (coef_bstride % 4 == 0);
   if (x1) vec = vec && (ld1 % 4 == 0) && vr_aligned16(x1);
   if (x2) vec = vec && (ld2 % 4 == 0) && vr_aligned16(x2);
   if (pre == 2) vec = vec && (ldm % 4 == 0) && vr_aligned16(masky);
   if (add) vec = vec && (ldadd % 4 == 0) && vr_aligned16(add);
-  for (const float* c : {A, D1, S1, E, D2, S2}) vec = vec && (!c || vr_aligned16(c));
+  for (const float* c : {A, D1, S1, E, D2, S2, mA, mD, mS}) vec = vec && (!c || vr_aligned16(c));
   long blocks = vr_cdiv(HW * (C / (vec ? 4 : 1)), 256 * 4);
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
@@ -884,6 +913,15 @@ extern "C" int vrnet_affine_f32(const float* x1, long ld1, const float* A, const
   else hipLaunchKernelGGL((affine_kernel<1>), grid, block, 0, vr_stream(stream), p);
   VR_LAUNCH_CHECK("affine");
   return VR_OK;
+}
+
+extern "C" int vrnet_affine_f32(const float* x1, long ld1, const float* A, const float* D1, const float* S1, int pre,
+                                const float* masky, long ldm, const float* x2, long ld2, const float* E,
+                                const float* D2, const float* S2, long coef_bstride, float* out, long ldo, int B,
+                                long HW, int C, int accumulate, const float* add, long ldadd, void* stream) {
+  VR_CHECK_ARG(pre >= 0 && pre <= 2, "affine: pre 0 (none), 1 (ReLU) or 2 (mask by a ReLU output)");
+  return affine_impl(x1, ld1, A, D1, S1, pre, masky, ldm, x2, ld2, E, D2, S2, coef_bstride, out, ldo, B, HW, C, accumulate, add,
+                     ldadd, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int vrnet_gn_coef_fwd(const double* mom, const float* gamma, const float* beta, float eps, int B, long HW,
@@ -1083,6 +1121,39 @@ extern "C" int vrnet_bn_stats_bwd(const float* dy, long lddy, const float* z, lo
                      nchunks, mean_rstd, gamma, training, B, HW, C, A, E, D, S, dgamma, dbeta, accumulate);
   VR_LAUNCH_CHECK("bn_stats_bwd");
   return VR_OK;
+}
+
+/* BatchNorm backward of y = ReLU(BN(z)) WITHOUT reading y (round 4): the mask [y > 0] is recomputed from z with the forward
+ * coefficients fwd_A (z - fwd_S) + fwd_D -- the single fused multiply-add the forward apply evaluated, so the bits are the
+ * forward's -- which takes one of the three tensor reads out of the moments pass and one of three out of the apply pass.
+ * vrnet_bn_stats_bwd_zmask = vrnet_bn_stats_bwd; vrnet_bn_apply_bwd_zmask: dz = [mask] (A dy) + E (z - S) + D. */
+extern "C" int vrnet_bn_stats_bwd_zmask(const float* dy, long lddy, const float* z, long ldz, const float* fwd_A,
+                                        const float* fwd_D, const float* fwd_S, const float* mean_rstd, const float* gamma,
+                                        int training, int B, long HW, int C, float* A, float* E, float* D, float* S,
+                                        float* dgamma, float* dbeta, int accumulate, void* workspace, long workspace_bytes,
+                                        void* stream) {
+  VR_CHECK_ARG(dy && z && fwd_A && fwd_D && fwd_S && mean_rstd && gamma && A && E && D && S && dgamma && dbeta,
+               "bn_stats_bwd_zmask: null tensor");
+  VR_CHECK_ARG(C % 4 != 0 || (vr_aligned16(fwd_A) && vr_aligned16(fwd_D) && vr_aligned16(fwd_S)),
+               "bn_stats_bwd_zmask: coefficient vectors must be 16-byte aligned");
+  hipStream_t st = vr_stream(stream);
+  int nchunks;
+  int rc = moments_launch(dy, lddy, z, ldz, nullptr, 0, B, HW, C, workspace, workspace_bytes, st, &nchunks, 0, nullptr, nullptr,
+                          nullptr, fwd_A, fwd_D, fwd_S);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_coef_bwd_partial_kernel, dim3(vr_cdiv(C, 4)), dim3(256), 0, st, reinterpret_cast<double*>(workspace),
+                     nchunks, mean_rstd, gamma, training, B, HW, C, A, E, D, S, dgamma, dbeta, accumulate);
+  VR_LAUNCH_CHECK("bn_stats_bwd_zmask");
+  return VR_OK;
+}
+
+extern "C" int vrnet_bn_apply_bwd_zmask(const float* dy, long lddy, const float* z, long ldz, const float* fwd_A,
+                                        const float* fwd_D, const float* fwd_S, const float* A, const float* E,
+                                        const float* D, const float* S, float* dz, long lddz, int B, long HW, int C,
+                                        void* stream) {
+  VR_CHECK_ARG(dy && z && fwd_A && fwd_D && fwd_S && A && E && D && S && dz, "bn_apply_bwd_zmask: null tensor");
+  return affine_impl(dy, lddy, A, nullptr, nullptr, 3, nullptr, 0, z, ldz, E, D, S, 0, dz, lddz, B, HW, C, 0, nullptr, 0, fwd_A,
+                     fwd_D, fwd_S, stream);
 }
 
 extern "C" int vrnet_bn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int training, int B,

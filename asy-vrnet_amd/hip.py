@@ -59,8 +59,8 @@ _SIGS = {
     "vrnet_gn_apply_fwd": ([P, L, P, L, P, P, F, I, L, I, P, L, P, P], I),
     "vrnet_gn_apply_fwd_planes": ([P, L, P, L, P, P, F, I, L, I, P, L, P, P, P], I),
     "vrnet_gn_apply_bwd_planes": ([P, L, P, L, P, P, I, L, I, P, L, P, L, P, P, I, P, P, L, P], I),
-    "vrnet_cluster_fwd_planes_f32": ([P, P, L, P, P, P, L, P, P, I, I, I, I, I, I, I, P, P], I),
-    "vrnet_cluster_bwd_planes_f32": ([P, P, L, P, P, P, P, L, P, P, L, P, P, I, I, I, I, I, I, I, P, P, L, P], I),
+    "vrnet_cluster_fwd_planes_f32": ([P, P, L, I, P, P, P, L, P, P, I, I, I, I, I, I, I, P, P], I),
+    "vrnet_cluster_bwd_planes_f32": ([P, P, L, I, P, P, P, P, L, P, P, L, P, P, I, I, I, I, I, I, I, P, P, L, P], I),
     "vrnet_gn_bwd_workspace": ([I, L, I], L),
     "vrnet_gn_apply_bwd_from_partials": ([P, L, P, L, P, P, P, P, I, L, I, P, L, P, L, P, P, I, P], I),
     "vrnet_bn_coef_fwd_from_partials": ([P, P, P, F, F, P, P, P, I, L, I, P, P, P, P, P], I),
@@ -68,6 +68,8 @@ _SIGS = {
     "vrnet_bn_coef_fwd": ([P, P, P, F, F, P, P, P, I, I, L, I, P, P, P, P, P], I),
     "vrnet_bn_coef_bwd": ([P, P, P, I, I, L, I, P, P, P, P, P, P, I, P], I),
     "vrnet_bn_stats_fwd": ([P, L, P, P, F, F, P, P, P, I, L, I, P, P, P, P, P, L, P], I),
+    "vrnet_bn_stats_bwd_zmask": ([P, L, P, L, P, P, P, P, P, I, I, L, I, P, P, P, P, P, P, I, P, L, P], I),
+    "vrnet_bn_apply_bwd_zmask": ([P, L, P, L, P, P, P, P, P, P, P, P, L, I, L, I, P], I),
     "vrnet_bn_stats_bwd": ([P, L, P, L, P, L, P, P, I, I, L, I, P, P, P, P, P, P, I, P, L, P], I),
     "vrnet_eca_coef_fwd": ([P, P, I, I, L, I, P, P], I),
     "vrnet_eca_coef_bwd": ([P, P, P, P, I, I, L, I, P, P, I, P], I),
@@ -486,6 +488,19 @@ def bn_stats_bwd(dy, lddy, z, ldz, mask, ldm, mean_rstd, gamma, training, B, HW,
                                    ws.numel(), stream()), "bn_stats_bwd")
 
 
+def bn_stats_bwd_zmask(dy, lddy, z, ldz, fwd, mean_rstd, gamma, training, B, HW, C, A, E, Dc, S, dgamma, dbeta, accumulate):
+    """bn_stats_bwd with the ReLU mask recomputed from z: fwd = the forward apply's (A, D, S)."""
+    ws = _ws.get(_lib.vrnet_moments_workspace(B, HW, C), dy.device)
+    _check(_lib.vrnet_bn_stats_bwd_zmask(ptr(dy), lddy, ptr(z), ldz, ptr(fwd[0]), ptr(fwd[1]), ptr(fwd[2]), ptr(mean_rstd),
+                                         ptr(gamma), int(training), B, HW, C, ptr(A), ptr(E), ptr(Dc), ptr(S), ptr(dgamma),
+                                         ptr(dbeta), accumulate, ptr(ws), ws.numel(), stream()), "bn_stats_bwd_zmask")
+
+
+def bn_apply_bwd_zmask(dy, lddy, z, ldz, fwd, A, E, Dc, S, dz, lddz, B, HW, C):
+    _check(_lib.vrnet_bn_apply_bwd_zmask(ptr(dy), lddy, ptr(z), ldz, ptr(fwd[0]), ptr(fwd[1]), ptr(fwd[2]), ptr(A), ptr(E),
+                                         ptr(Dc), ptr(S), ptr(dz), lddz, B, HW, C, stream()), "bn_apply_bwd_zmask")
+
+
 def eca_coef_fwd(mom, wk, k, B, HW, C, gate):
     _check(_lib.vrnet_eca_coef_fwd(ptr(mom), ptr(wk), k, B, HW, C, ptr(gate), stream()), "eca_coef_fwd")
 
@@ -546,11 +561,13 @@ def fill_(dst, value):
 def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold, alpha2=None, beta2=None, forced=False,
                 planes=None):
     """forced: idx is given (read), not computed (teacher-forced assignment for parity comparisons).
-    planes (Planes): a second copy of `out` as bf16 planes (single-stream launches)."""
-    if planes is not None:
-        assert alpha2 is None
-        _check(_lib.vrnet_cluster_fwd_planes_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(out), ldo, ptr(idx), ptr(wgt), B, H,
-                                                 W, E, Dh, fold, 1 if forced else 0, _planes_out(planes), stream()), "cluster_fwd_planes")
+    planes (Planes): `out` as bf16 planes, beside the fp32 `out` or instead of it (out None); single-stream launches.
+    f / v may then be bfloat16 tensors (ld in elements)."""
+    if planes is not None or f.dtype == torch.bfloat16:
+        assert alpha2 is None and f.dtype == v.dtype
+        _check(_lib.vrnet_cluster_fwd_planes_f32(ptr(f), ptr(v), ld, 1 if f.dtype == torch.bfloat16 else 0, ptr(alpha), ptr(beta),
+                                                 ptr(out), ldo, ptr(idx), ptr(wgt), B, H, W, E, Dh, fold, 1 if forced else 0,
+                                                 _planes_out(planes), stream()), "cluster_fwd_planes")
         return
     fn = _lib.vrnet_cluster_fwd_forced_f32 if forced else _lib.vrnet_cluster_fwd_f32
     _check(fn(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(out), ldo, ptr(idx), ptr(wgt), B, H,
@@ -561,11 +578,12 @@ def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, db
                 fold, alpha2=None, beta2=None, dalpha2=None, dbeta2=None, planes=None):
     """planes (Planes of 2 E Dh columns): a second copy of [df | dv] as bf16 planes (single-stream launches)."""
     ws = _ws.get(_lib.vrnet_cluster_bwd_workspace2(B, H, W, E, fold), f.device)
-    if planes is not None:
-        assert alpha2 is None
-        _check(_lib.vrnet_cluster_bwd_planes_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(idx), ptr(dout), lddo, ptr(df),
-                                                 ptr(dv), lddf, ptr(dalpha), ptr(dbeta), accumulate_ab, B, H, W, E, Dh, fold,
-                                                 _planes_out(planes), ptr(ws), ws.numel(), stream()), "cluster_bwd_planes")
+    if planes is not None or f.dtype == torch.bfloat16:
+        assert alpha2 is None and f.dtype == v.dtype == dout.dtype
+        _check(_lib.vrnet_cluster_bwd_planes_f32(ptr(f), ptr(v), ld, 1 if f.dtype == torch.bfloat16 else 0, ptr(alpha), ptr(beta),
+                                                 ptr(idx), ptr(dout), lddo, ptr(df), ptr(dv), lddf, ptr(dalpha), ptr(dbeta),
+                                                 accumulate_ab, B, H, W, E, Dh, fold, _planes_out(planes), ptr(ws), ws.numel(),
+                                                 stream()), "cluster_bwd_planes")
         return
     _check(_lib.vrnet_cluster_bwd_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(idx), ptr(dout), lddo, ptr(df),
                                       ptr(dv), lddf, ptr(dalpha), ptr(dbeta), accumulate_ab, B, H, W, E, Dh, fold,

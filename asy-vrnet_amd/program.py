@@ -621,19 +621,21 @@ def bn_forward(rt, z, bn, relu, out=None, residual=None):
                x2=None if residual is None else residual.t, ld2=0 if residual is None else residual.ld)
     if relu and rt.relu_masks is not None:
         rt.relu_masks[bn] = y
+    if relu and residual is None:
+        ms.fwd_coef = (A, D, S)      # bn_backward recomputes the ReLU mask from z with these instead of reading y
     return y, ms
 
 
 def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
     """dz of y = [relu](BN(z)); mask = the ReLU output (None: no ReLU).  Returns contiguous dz tensor."""
     B, HW, C = z.B, z.HW, z.C
-    A, E, D, S = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C)
     gw, accw = rt.pgrad(bn.weight)
     gb, accb = rt.pgrad(bn.bias)
     if gw is None:
         gw, accw = rt.buf(C), 0
     if gb is None:
         gb = rt.buf(C)
+    A, E, D, S = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C)
     if rt.training and rt.sync_bn is not None:
         # the two gradient sums over all ranks for dz; d gamma / d beta from the LOCAL sums (as SyncBatchNorm: the gradient
         # all-reduce averages them afterwards)
@@ -643,6 +645,16 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
         hip.bn_coef_bwd(tot2, ms, bn.weight, True, 1, rt.sync_bn.count(B, HW), C, A, E, D, S, rt.buf(C), rt.buf(C), 0)
         hip.bn_coef_bwd(mom2, ms, bn.weight, True, B, HW, C, rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C), gw, gb, accw)
     else:
+        fwd = getattr(ms, "fwd_coef", None) if mask is not None else None
+        if fwd is not None:
+            # y = ReLU(BN(z)): neither pass reads y -- two tensor reads each where there were three
+            hip.bn_stats_bwd_zmask(dy, lddy, z.t, z.ld, fwd, ms, bn.weight, rt.training, B, HW, C, A, E, D, S, gw, gb, accw)
+            if rt.on_param_grad:
+                rt.on_param_grad(bn.weight)
+                rt.on_param_grad(bn.bias)
+            dz = dz_out if dz_out is not None else rt.buf(z.B, z.H, z.W, C)
+            hip.bn_apply_bwd_zmask(dy, lddy, z.t, z.ld, fwd, A, E, D, S, dz, C, B, HW, C)
+            return dz
         hip.bn_stats_bwd(dy, lddy, z.t, z.ld, None if mask is None else mask.t, 0 if mask is None else mask.ld, ms, bn.weight,
                          rt.training, B, HW, C, A, E, D, S, gw, gb, accw)
     if rt.on_param_grad:
@@ -949,14 +961,18 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
         xn_f, ms1 = gn_forward(rt, x, m.norm1)
         if xn_p is not None:
             hip.planes_from_f32(xn_f.t, C, M, C, xn_p)
+    # (f | v and d(out) stay fp32 in bf16 mode too: bf16 tensors for them -- the Cluster kernels take either,
+    # vrnet_cluster_*_planes_f32(in_bf16) -- measured 34.0 against 33.7 ms per step at batch 16: those kernels are not bound
+    # by the bytes they read)
     fv = f32(2 * ED)
+    fv_t = fv.t
     if fcfv[0]:
         hip.gemm_planes(xn_p, pw.fwd(wcat), M, 2 * ED, C, bias=bcat, y=fv.t, ldy=2 * ED)
     else:
         hip.conv2d(xn_f.t, C, wcat, bcat, fv.t, 2 * ED, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=0,
                    precision=rt.prec_fwd(C, C, 2 * ED), w_planes=rt.planes(wcat, 0, 2 * ED, C, M))
     # ---- Cluster core -> proj
-    f_t, v_t = fv.t, fv.t[..., ED:]
+    f_t, v_t = fv_t, fv_t[..., ED:]
     o_p = P(ED) if (proj[0] or (rec and proj[2])) else None
     o = f32(ED) if (not proj[0] or (rec and not proj[2])) else None      # the fp32 form only while a consumer still wants it
     idx = rt.buf(B, H, W, E, dtype=torch.uint8)
@@ -1120,6 +1136,7 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
             rt.on_param_grad(m.norm2.bias)
         # ---- Cluster branch
         do = f32(ED)
+        do_t = do.t
         if proj[1]:
             hip.gemm_planes(dx1_p, pw.dgrad(tm.fc2.weight, ls1), M, ED, C, y=do.t, ldy=ED)
         else:
@@ -1130,7 +1147,7 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
         dfv_p = P(2 * ED) if (fcfv[1] or fcfv[2]) else None
         dfv = f32(2 * ED) if (not fcfv[1] or not fcfv[2]) else None
         (ga, gb_), acca = _pgrads_or_scratch(rt, (tm.sim_alpha, tm.sim_beta), (1, 1))
-        hip.cluster_bwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, idx, do.t, ED, None if dfv is None else dfv.t,
+        hip.cluster_bwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, idx, do_t, ED, None if dfv is None else dfv.t,
                         None if dfv is None else dfv.t[..., ED:], 2 * ED, ga, gb_, acca, B, H, W, E, Dh, fold, planes=dfv_p)
         if rt.on_param_grad:
             rt.on_param_grad(tm.sim_alpha)

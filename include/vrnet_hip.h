@@ -149,8 +149,11 @@ typedef struct vrnet_planes_out {
 /* Producers with a plane output (same arguments as the functions they extend, plus the planes):
  *   vrnet_gn_apply_fwd_planes    GroupNorm(1, C) output (vr_coc.py:264, 268) -- y may be NULL (planes only);
  *   vrnet_gn_apply_bwd_planes    its input gradient: the block's outgoing gradient as the next GEMMs' dy operand;
- *   vrnet_cluster_fwd_planes_f32 the Cluster core's output (vr_coc.py:158-186), forced != 0 = the teacher-forced form;
- *   vrnet_cluster_bwd_planes_f32 [df | dv] as ONE plane tensor of 2 E D columns (df first). */
+ *   vrnet_cluster_fwd_planes_f32 the Cluster core's output (vr_coc.py:158-186), forced != 0 = the teacher-forced form; the fp32
+ *     `out` may be NULL (planes only); in_bf16 != 0: f and v are bf16 tensors (ld in elements) -- what the reference's
+ *     autocast hands its Cluster (train.py:345-350): the fc1 | fc_v GEMM then writes 2 bytes per element and nothing else;
+ *   vrnet_cluster_bwd_planes_f32 [df | dv] as ONE plane tensor of 2 E D columns (df first); df / dv may both be NULL (planes
+ *     only); in_bf16 != 0: f, v AND dout are bf16 tensors. */
 int vrnet_gn_apply_fwd_planes(const float* x, long ldx, const double* pairs, long pairs_per_sample, const float* gamma,
                               const float* beta, float eps, int B, long HW, int C, float* y, long ldy, float* mean_rstd,
                               const vrnet_planes_out* yp, void* stream);
@@ -158,11 +161,11 @@ int vrnet_gn_apply_bwd_planes(const float* dy, long lddy, const float* x, long l
                               int B, long HW, int C, const float* add, long ldadd, float* out, long ldo, float* dgamma,
                               float* dbeta, int accumulate_params, const vrnet_planes_out* outp, void* workspace,
                               long workspace_bytes, void* stream);
-int vrnet_cluster_fwd_planes_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta, float* out,
-                                 long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E, int D, int fold,
-                                 int forced, const vrnet_planes_out* outp, void* stream);
-int vrnet_cluster_bwd_planes_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
-                                 const unsigned char* idx, const float* dout, long lddo, float* df, float* dv, long lddf,
+int vrnet_cluster_fwd_planes_f32(const void* f, const void* v, long ld, int in_bf16, const float* alpha, const float* beta,
+                                 float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E, int D,
+                                 int fold, int forced, const vrnet_planes_out* outp, void* stream);
+int vrnet_cluster_bwd_planes_f32(const void* f, const void* v, long ld, int in_bf16, const float* alpha, const float* beta,
+                                 const unsigned char* idx, const void* dout, long lddo, float* df, float* dv, long lddf,
                                  float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W, int E, int D, int fold,
                                  const vrnet_planes_out* dfvp, void* workspace, long workspace_bytes, void* stream);
 int vrnet_wgrad_planes_ok(long M, int Cin, int Cout);
@@ -315,6 +318,17 @@ int vrnet_bn_stats_bwd(const float* dy, long lddy, const float* z, long ldz, con
                        const float* mean_rstd, const float* gamma, int training, int B, long HW, int C, float* A, float* E,
                        float* D, float* S, float* dgamma, float* dbeta, int accumulate, void* workspace,
                        long workspace_bytes, void* stream);
+/* BatchNorm backward of y = ReLU(BN(z)) WITHOUT reading y (round 4; BaseConv, normal_conv.py:36-49): the mask [y > 0] is
+ * recomputed from z with the forward coefficients, fwd_A (z - fwd_S) + fwd_D evaluated as the single fused multiply-add
+ * the forward apply used (same bits), which removes one of three tensor reads from the moments pass and from the apply
+ * pass.  vrnet_bn_stats_bwd_zmask: as vrnet_bn_stats_bwd;  vrnet_bn_apply_bwd_zmask: dz = [mask] (A dy) + E (z - S) + D. */
+int vrnet_bn_stats_bwd_zmask(const float* dy, long lddy, const float* z, long ldz, const float* fwd_A, const float* fwd_D,
+                             const float* fwd_S, const float* mean_rstd, const float* gamma, int training, int B, long HW,
+                             int C, float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,
+                             void* workspace, long workspace_bytes, void* stream);
+int vrnet_bn_apply_bwd_zmask(const float* dy, long lddy, const float* z, long ldz, const float* fwd_A, const float* fwd_D,
+                             const float* fwd_S, const float* A, const float* E, const float* D, const float* S, float* dz,
+                             long lddz, int B, long HW, int C, void* stream);
 /* mom2 = moments(dy, x2 = z, mask = relu output): dz = A*dy' + E*(z - S) + D with A,E,D,S [C]. */
 int vrnet_bn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int training, int B, long HW,
                       int C, float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,

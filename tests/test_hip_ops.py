@@ -265,6 +265,16 @@ def test_batch_norm_relu_chain(hip, training, shape):
     hip.bn_stats_bwd(gg, C, zg, C, out, C, ms, gam.detach().cuda(), training, B, H * W, C, A4, E4, D4, S4, dg4, db4, 1)
     for a_, b_, nm in ((A4, A2, "A"), (E4, E2, "E"), (D4, D2, "D"), (S4, S2, "S"), (dg4, dgam + 3, "dgamma"), (db4, dbet + 3, "dbeta")):
         close(a_, b_, 1e-5, what="bn_stats_bwd " + nm, floor=1e-3)
+    # round 4: the same backward WITHOUT reading the ReLU output -- the mask is recomputed from z with the forward
+    # coefficients, and must be the forward's mask bit for bit: identical results, not merely close ones
+    A5, E5, D5, S5 = (torch.empty(C, device="cuda") for _ in range(4))
+    dg5, db5 = torch.full((C,), 3.0, device="cuda"), torch.full((C,), 3.0, device="cuda")
+    hip.bn_stats_bwd_zmask(gg, C, zg, C, (A, D, S), ms, gam.detach().cuda(), training, B, H * W, C, A5, E5, D5, S5, dg5, db5, 1)
+    for a_, b_, nm in ((A5, A4, "A"), (E5, E4, "E"), (D5, D4, "D"), (S5, S4, "S"), (dg5, dg4, "dgamma"), (db5, db4, "dbeta")):
+        assert torch.equal(a_, b_), "bn_stats_bwd_zmask " + nm
+    dz5 = torch.empty(B, H, W, C, device="cuda")
+    hip.bn_apply_bwd_zmask(gg, C, zg, C, (A, D, S), A2, E2, D2, S2, dz5, C, B, H * W, C)
+    assert torch.equal(dz5, dz), "bn_apply_bwd_zmask"
 
 
 CLUSTER_CASES = [

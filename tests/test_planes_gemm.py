@@ -322,3 +322,21 @@ def test_producers_write_the_planes_of_what_they_store(hip, case, np_):
     dfvp2 = hip.Planes.empty(np_, (B, H, W, 2 * C), "cuda")
     hip.cluster_bwd(f, v, C, al, be, idx, go, C, None, None, 2 * C, dab[0:1], dab[1:2], 0, B, H, W, E, D, fold, planes=dfvp2)   # planes only
     assert torch.equal(dfvp2.t, dfvp.t)
+    # ---- bf16 f | v and d(out) tensors (round 4, bf16 mode): the kernels widen on load, so the results are those of the
+    # fp32 copies of the same values, bit for bit
+    if np_ == 1:
+        fvh = torch.cat([f, v], -1).to(torch.bfloat16)
+        fh, vh, gh = fvh, fvh[..., C:], go.to(torch.bfloat16)
+        fw, vw, gw = fvh[..., :C].float().contiguous(), vh.float().contiguous(), gh.float()
+        oa, ob = torch.empty(B, H, W, C, device="cuda"), torch.empty(B, H, W, C, device="cuda")
+        ia, ib = torch.empty_like(idx), torch.empty_like(idx)
+        pa, pb = hip.Planes.empty(1, (B, H, W, C), "cuda"), hip.Planes.empty(1, (B, H, W, C), "cuda")
+        hip.cluster_fwd(fh, vh, 2 * C, al, be, oa, C, ia, wgt, B, H, W, E, D, fold, planes=pa)
+        hip.cluster_fwd(fw, vw, C, al, be, ob, C, ib, wgt, B, H, W, E, D, fold, planes=pb)
+        assert torch.equal(ia, ib) and torch.equal(oa, ob) and torch.equal(pa.t, pb.t), "cluster_fwd bf16 inputs"
+        da, db_ = torch.empty(B, H, W, 2 * C, device="cuda"), torch.empty(B, H, W, 2 * C, device="cuda")
+        aba, abb = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
+        qa, qb = hip.Planes.empty(1, (B, H, W, 2 * C), "cuda"), hip.Planes.empty(1, (B, H, W, 2 * C), "cuda")
+        hip.cluster_bwd(fh, vh, 2 * C, al, be, ia, gh, C, da, da[..., C:], 2 * C, aba[0:1], aba[1:2], 0, B, H, W, E, D, fold, planes=qa)
+        hip.cluster_bwd(fw, vw, C, al, be, ia, gw, C, db_, db_[..., C:], 2 * C, abb[0:1], abb[1:2], 0, B, H, W, E, D, fold, planes=qb)
+        assert torch.equal(da, db_) and torch.equal(qa.t, qb.t) and torch.equal(aba, abb), "cluster_bwd bf16 inputs"
