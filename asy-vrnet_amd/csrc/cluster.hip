@@ -816,6 +816,7 @@ extern "C" int vrnet_cluster_fwd_forced_f32(const float* f, const float* v, long
 static int cluster_fwd_impl(const float* f, const float* v, long ld, const float* alpha, const float* beta, float* out, long ldo,
                             unsigned char* idx, float* wgt, int B, int H, int W, int E, int D, int fold, const float* alpha2,
                             const float* beta2, int forced, const vrnet_planes_out* outp, void* stream) {
+  if (vr_ablated("cluster")) return VR_OK;
   int T, npt;
   int rc = cluster_check("cluster_fwd", f, v, ld, B, H, W, E, D, fold, &T, &npt, 0);
   if (rc) return rc;
@@ -870,6 +871,7 @@ static int cluster_bwd_impl(const float* f, const float* v, long ld, const float
                             long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
                             int E, int D, int fold, const float* alpha2, const float* beta2, float* dalpha2,
                             float* dbeta2, const vrnet_planes_out* dfvp, void* workspace, long workspace_bytes, void* stream) {
+  if (vr_ablated("cluster")) return VR_OK;
   const int in_bf16 = (accumulate_ab >> 1) & 1;      // (bit 1: set by vrnet_cluster_bwd_planes_f32 only)
   accumulate_ab &= 1;
   int T, npt;

@@ -311,7 +311,9 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
   asm volatile("" : "+s"(zero_page));
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int L = blockIdx.x, jj = L >> 3;
+  const int GT = 8 * ((MT + 7) >> 3) * NT;            // workgroups per split (the tile map pads row tiles to eights)
+  const int split = __builtin_amdgcn_readfirstlane(p_in.ksplit > 1 ? (int)blockIdx.x / GT : 0);
+  const int L = blockIdx.x - split * GT, jj = L >> 3;
   const int nt = jj % NT, mt = (jj / NT) * 8 + (L & 7);
   if (mt >= MT) return;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -386,7 +388,10 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     for (int i = tid; i < nkb * BK; i += 256) ks_s[i] = i < p.CK ? p.kscale[i] : 0.f;   // padded: the loop reads it unguarded
     __syncthreads();     // ordinary loads retire here, before the first DMA is issued
   }
-  const int nsteps = ntaps * nkb;
+  // split contraction: this workgroup runs steps [s_begin, s_begin + nsteps) of the tile's ntaps * nkb
+  const int nsteps_all = ntaps * nkb;
+  const int s_begin = p.ksplit > 1 ? (int)((long)split * nsteps_all / p.ksplit) : 0;
+  const int nsteps = (p.ksplit > 1 ? (int)((long)(split + 1) * nsteps_all / p.ksplit) : nsteps_all) - s_begin;
 
   // Per tap: a running source pointer and a per-stage advance for each of the thread's four DMA slots.  Slots that
   // are masked for the whole tap (row outside the tile / image, padded tap, channel quad beyond CK or CN) point at
@@ -426,7 +431,14 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
     }
   };
 
-  int ld_ti = 0, ld_kb = 0, ld_buf = 0;       // (tap index, k block, ring slot) of the NEXT stage to issue
+  int ld_ti = s_begin / nkb, ld_kb = s_begin - (s_begin / nkb) * nkb, ld_buf = 0;       // (tap index, k block, ring slot) of the NEXT stage to issue
+  if (ld_kb != 0 && nsteps > 0) {      // a split that starts inside a tap: set the tap up and advance to its k block
+    setup_tap(use_list ? (int)taps_s[ld_ti] : ld_ti);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_run[i] += (long)ld_kb * a_inc[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_run[i] += (long)ld_kb * b_inc[i];
+  }
   // The four DMA instructions of a stage are issued one by one (piece 0, 1 = A, 2, 3 = B): in the main loop each one
   // goes behind a group of MFMAs, whose 64-cycle execution hides the DMA's issue cost (60-185 cycles per piece when
   // issued back to back in front of the fragment reads).
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
 #pragma unroll
   for (int st = 0; st < NST - 1; ++st)
     if (st < nsteps) issue();
-  int cur = 0, kb = 0;
+  int cur = 0, kb = s_begin - (s_begin / nkb) * nkb;
 #ifdef VR_IGEMM_STAMP
   unsigned long long* stamp = reinterpret_cast<unsigned long long*>(p.stats);     // diagnostic build: 64 x 4 stamps
 #endif
@@ -654,7 +666,8 @@ __global__ __launch_bounds__(256, NST <= 3 ? 3 : (NST <= 4 ? 2 : 1)) void igemm_
   q.stats = nullptr;
   igemm_epilogue<TM, TN, 2, 2>(q, acc, smem, m0, n0);
 #else
-  igemm_epilogue<TM, TN, 2, 2>(p, acc, smem, m0, n0);
+  if (p.ksplit > 1) igemm_splitk_store<TM, TN>(p, acc, GT, L, split);
+  else igemm_epilogue<TM, TN, 2, 2>(p, acc, smem, m0, n0);
 #endif
 }
 
@@ -689,11 +702,15 @@ __global__ __launch_bounds__(256, (NST * (8192 + TN * 6144) <= 49152) ? 3 : 2) v
   const float* zero_page = vr_zero_page;
   asm volatile("" : "+s"(zero_page));
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = blockIdx.x, jj = L >> 3;
+  const int GT = 8 * ((MT + 7) >> 3) * NT;
+  const int split = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? (int)blockIdx.x / GT : 0);
+  const int L = blockIdx.x - split * GT, jj = L >> 3;
   const int nt = jj % NT, mt = (jj / NT) * 8 + (L & 7);
   if (mt >= MT) return;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int nsteps = p.CK / BK;
+  const int nsteps_all = p.CK / BK;
+  const int s_begin = p.ksplit > 1 ? (int)((long)split * nsteps_all / p.ksplit) : 0;
+  const int nsteps = (p.ksplit > 1 ? (int)((long)(split + 1) * nsteps_all / p.ksplit) : nsteps_all) - s_begin;
   const int NBW = TN == 2 ? 3 : (wave < 2 ? 2 : 1);      // this wave's B pieces per stage (wave-uniform)
 
   // ---- A loader roles (as igemm_dma_kernel with QPR = 4): slot (row, quad) of a 128 x 16 fp32 image, XOR-swizzled
@@ -705,11 +722,11 @@ __global__ __launch_bounds__(256, (NST * (8192 + TN * 6144) <= 49152) ? 3 : 2) v
     const int q = (sl & 3) ^ ((r >> 2) & 3);
     const int m = m0 + r;
     const bool ok = m < p.M;
-    a_run[i] = ok ? p.a + (long)m * p.lda + 4 * q : zero_page;
+    a_run[i] = ok ? p.a + (long)m * p.lda + 4 * q + (long)s_begin * BK : zero_page;
     a_inc[i] = ok ? BK : 0;
   }
-  const unsigned char* b_src = planes + ((long)(n0 >> 6)) * 6144 + (long)lane * 16;       // + kb * JB * 6144
   const long b_step = (long)JB * 6144;
+  const unsigned char* b_src = planes + ((long)(n0 >> 6)) * 6144 + (long)lane * 16 + s_begin * b_step;       // + kb * JB * 6144
   int ld_buf = 0;
   // one DMA piece of the stage being issued: 0 .. NA - 1 = A, then this wave's B pieces
   auto issue_piece = [&](int i) {
@@ -794,7 +811,8 @@ __global__ __launch_bounds__(256, (NST * (8192 + TN * 6144) <= 49152) ? 3 : 2) v
     if (++cur == NST) cur = 0;
   }
   __syncthreads();
-  igemm_epilogue<TM, TNW, 4, 1>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
+  if (p.ksplit > 1) igemm_splitk_store<TM, TNW>(p, acc, GT, L, split);
+  else igemm_epilogue<TM, TNW, 4, 1>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
 }
 
 // Multi-tensor weight split: one launch for every eligible weight of a step.  Table entry e (8 longs): source address,
@@ -1413,6 +1431,45 @@ static int vr_dma_tile(long M, int CN) {
   return tile;
 }
 
+// Split contraction (round 4) for the layers the rule above turns away for lack of tiles (16 x 16 maps: 2048 rows x 256-512
+// columns = 64-128 tiles of 128 x 64 on 256 CUs, which then ran on 64 x 64 fp32-MFMA tiles at 40-70 TFLOP/s): `S` workgroups
+// per tile each take 1/S of the K loop and leave raw accumulators in a slab, igemm_splitk_finish_kernel adds the slabs in
+// order and runs the epilogue.  Returns the tile (21) and S, or the unsplit tile of vr_dma_tile with S = 1, or 0.
+static int vr_dma_plan(long M, int CN, long ktot, long ws_bytes, int* S_out) {
+  *S_out = 1;
+  const int tile = vr_dma_tile(M, CN);
+  if (tile || CN <= 32 || ws_bytes <= 0) return tile;
+  static const int on = vr_tune("VRNET_SPLITK", 1);
+  static const int target = vr_tune("VRNET_SPLITK_TARGET", 512);         // workgroups wanted (2 per CU)
+  static const int min_steps = vr_tune("VRNET_SPLITK_MIN_STEPS", 8);     // K16 steps per split at least
+  if (!on) return 0;
+  const long mt = vr_cdiv(M, 128), nt21 = vr_cdiv(CN, 64), tiles = mt * nt21, steps = ktot / 16;
+  long S = vr_cdiv(target, tiles);
+  if (S > steps / min_steps) S = steps / min_steps;
+  if (S > 8) S = 8;
+  if (S < 2 || tiles * S < 192) return 0;
+  const long need = S * (8 * vr_cdiv(mt, 8) * nt21) * 8192 * 4;
+  if (need > ws_bytes) return 0;
+  *S_out = (int)S;
+  return 21;
+}
+
+/* Tile and split count vrnet_conv2d_f32 uses at precision 2 / 3 when it is given a workspace (ktot = contraction length
+ * Cin * kh * kw resp. Cout * kh * kw): the unsplit tile of vrnet_conv2d_dma_tile with *splits = 1, or 21 with *splits >= 2
+ * for the small maps; vrnet_conv2d_splitk_workspace: the bytes that split needs (0: none). */
+extern "C" int vrnet_conv2d_dma_plan(long rows, int cols, long ktot, int* splits) {
+  int S = 1;
+  const int tile = vr_dma_plan(rows, cols, ktot, 1L << 40, &S);
+  if (splits) *splits = S;
+  return tile;
+}
+
+extern "C" long vrnet_conv2d_splitk_workspace(long rows, int cols, long ktot) {
+  int S = 1;
+  if (vr_dma_plan(rows, cols, ktot, 1L << 40, &S) == 0 || S < 2) return 0;
+  return (long)S * (8 * vr_cdiv(vr_cdiv(rows, 128), 8) * vr_cdiv(cols, 64)) * 8192 * 4;
+}
+
 /* Which LDS-DMA tile vrnet_conv2d_f32 would use at precision 2 / 3 for B*MH*MW GEMM rows and CN GEMM columns (mode 0:
  * output pixels x Cout; mode 1: input pixels x Cin): 22, 21 or 0 = none (precision 3 is then rejected, precision 2 falls
  * back to the fp32 MFMA).  Alignment requirements (16-byte rows, channel counts % 4) are the caller's, as for precision 1. */
@@ -1425,7 +1482,7 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
                                 long ldaux, int out_nchw, int out_ctot, int out_coff, int accumulate,
                                 double* stats, int precision, int pair_rows, const float* w2, const float* bias2,
                                 const float* res_scale2, const float* kscale2, const void* w_planes,
-                                const vrnet_conv_colstats* colstats, void* stream) {
+                                const vrnet_conv_colstats* colstats, void* workspace, long workspace_bytes, void* stream) {
   VR_CHECK_ARG(a && w && y, "conv2d: null tensor");
   if (vr_ablated("igemm")) return VR_OK;
   {   // finer timing ablations by output-row class (diagnostic): stage-0/1 maps, stage-2 maps, neck / head maps
@@ -1579,7 +1636,10 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
   const bool bf16_tiles = precision == 3 || (precision == 1 && mode == 0);   // (mode 1 at precision 1 brings the transposed pack)
   if ((precision == 2 || bf16_tiles) && dma_ok && (!pair_rows || p.pair_rows % 128 == 0)) {
     const long mt = vr_cdiv(M, 128), nt22 = vr_cdiv(p.CN, 128), nt21 = vr_cdiv(p.CN, 64);
-    const int tile = vr_dma_tile(M, p.CN);
+    int S = 1;
+    // (the bf16-rounded tiles of precision 1 / 3 keep the unsplit rule: their callers asked vrnet_conv2d_dma_tile)
+    const int tile = precision == 2 ? vr_dma_plan(M, p.CN, ktot, workspace ? workspace_bytes : 0, &S) : vr_dma_tile(M, p.CN);
+    if (S > 1) { p.ksplit = S; p.kslab = reinterpret_cast<float*>(workspace); }
 #define VR_TILE_LAUNCH(PR)                                                                                              \
   do {                                                                                                                  \
     if (tile == 22) {                                                                                                   \
@@ -1587,9 +1647,12 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
       if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 2, 2, PR>), grid, block, 0, st, p, (int)mt, (int)nt22); \
       else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 2, 2, PR>), grid, block, 0, st, p, (int)mt, (int)nt22);           \
     } else {                                                                                                            \
-      dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt21));                                                                 \
+      dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt21 * S));                                                             \
       if (mode == 0) hipLaunchKernelGGL((igemm_dma_kernel<0, 3, 2, 1, PR>), grid, block, 0, st, p, (int)mt, (int)nt21); \
       else hipLaunchKernelGGL((igemm_dma_kernel<1, 3, 2, 1, PR>), grid, block, 0, st, p, (int)mt, (int)nt21);           \
+      if (S > 1)                                                                                                        \
+        hipLaunchKernelGGL((igemm_splitk_finish_kernel<2, 1, 2, 2>), dim3((unsigned)(8 * vr_cdiv(mt, 8) * nt21)), block, 0, st, \
+                           p, (int)mt, (int)nt21);                                                                      \
     }                                                                                                                   \
   } while (0)
     if (tile && precision == 2 && w_planes && kh == 1 && kw == 1 && stride == 1 && pad == 0 && !pair_rows && p.CK % 16 == 0 &&
@@ -1608,9 +1671,12 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
           hipLaunchKernelGGL((igemm_planes_kernel<2, 3>), grid, block, 0, st, q, reinterpret_cast<const unsigned char*>(w_planes), JB,
                              (int)mt, (int)nt22);
       } else {
-        dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt21));
+        dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt21 * S));
         hipLaunchKernelGGL((igemm_planes_kernel<1, 3>), grid, block, 0, st, q, reinterpret_cast<const unsigned char*>(w_planes), JB,
                            (int)mt, (int)nt21);
+        if (S > 1)
+          hipLaunchKernelGGL((igemm_splitk_finish_kernel<1, 2, 4, 1>), dim3((unsigned)(8 * vr_cdiv(mt, 8) * nt21)), block, 0, st, q,
+                             (int)mt, (int)nt21);
       }
       vr_note_kernel(9);
       VR_LAUNCH_CHECK("conv2d(x6, pre-split weights)");

@@ -49,6 +49,11 @@ struct IgemmArgs {
   // the operand format of the next x6 GEMM, which then splits nothing; yp_np = 1: the value rounded to bf16.  `y` may be
   // null when only the planes are wanted.
   unsigned short* yp; long ldyp; long yp_plane; int yp_np;
+  // Split contraction (round 4; the tile kernels of igemm.hip): workgroup (tile, split) runs steps [split, split + 1) * nsteps
+  // / ksplit of the tile's K loop and stores its raw accumulators into slab `split` of kslab ([ksplit][grid tiles][4 waves]
+  // [accumulators of the wave][64 lanes][16] floats); igemm_splitk_finish_kernel adds the slabs in order (deterministic) and
+  // runs the epilogue.  For the small-M layers (16 x 16 maps: 2048 rows) whose tile grid leaves most CUs empty.
+  int ksplit; float* kslab;
 };
 
 // The argument block a workgroup whose first row is m0 works with: the second stream's parameters behind pair_rows.
@@ -290,6 +295,55 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f32x16 (&acc)
     igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[1][0], m0, n0, 1, 0);
     if constexpr (TN > 1) igemm_epilogue_scalar<TM, TN, WM, WN>(p, acc[1][1], m0, n0, 1, 1);
   }
+}
+
+// ---- split contraction: raw accumulator slabs and the finishing kernel
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_splitk_store(const IgemmArgs& p, const f32x16 (&acc)[TM][TN], long grid_tiles, int tile,
+                                                   int split) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* dst = p.kslab + (((long)split * grid_tiles + tile) * 4 + wave) * (TM * TN * 1024) + lane * 16;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(dst + (i * TN + j) * 1024 + 4 * q) = v;
+      }
+}
+
+// One workgroup per tile (same tile map as the main kernel): sums the ksplit slabs in order and runs the fused epilogue.
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_splitk_finish_kernel(const IgemmArgs p_in, int MT, int NT) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * 32 * STAGE_LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = blockIdx.x, jj = L >> 3;
+  const int nt = jj % NT, mt = (jj / NT) * 8 + (L & 7);
+  if (mt >= MT) return;
+  const int m0 = mt * (WM * TM * 32), n0 = nt * (WN * TN * 32);
+  const IgemmArgs p = igemm_select_stream(p_in, m0);
+  const long grid_tiles = gridDim.x;
+  f32x16 acc[TM][TN];
+  const float* src = p.kslab + ((long)L * 4 + wave) * (TM * TN * 1024) + lane * 16;
+  const long sstride = grid_tiles * 4 * (TM * TN * 1024);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f32x4 t[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const f32x4*>(src + (i * TN + j) * 1024 + 4 * q);
+      for (int sp = 1; sp < p.ksplit; ++sp)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] += *reinterpret_cast<const f32x4*>(src + sp * sstride + (i * TN + j) * 1024 + 4 * q);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = t[q][e];
+    }
+  igemm_epilogue<TM, TN, WM, WN>(p, acc, smem, m0, n0);
 }
 
 // Weight gradient: dW[t][n][c] = sum_m dy[m, n] * x[src(m, t), c], contraction over output pixels, split over row

@@ -738,6 +738,7 @@ void sa_plan(long HW, int C, int* TPR, int* ncb, int* nchunks, long* rows) {
 
 extern "C" int vrnet_dwconv3x3_f32(const float* x, long ldx, const float* w, float* y, long ldy, int B, int H, int W,
                                    int C, int flip, int accumulate, void* stream) {
+  if (vr_ablated("dwconv")) return VR_OK;
   VR_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && C > 0, "dwconv3x3: bad arguments");
   VR_CHECK_ARG((long)B * H * W * C < (1L << 31), "dwconv3x3: tensor too large");
   const bool vec = C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && ldx % 4 == 0 && ldy % 4 == 0 && vr_aligned16(x) &&
@@ -783,6 +784,7 @@ extern "C" long vrnet_dwconv3x3_wgrad_workspace(int B, int H, int W, int C) {
 extern "C" int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* dy, long lddy, float* dw, int B, int H,
                                          int W, int C, int accumulate, void* workspace, long workspace_bytes,
                                          void* stream) {
+  if (vr_ablated("dwconv")) return VR_OK;
   VR_CHECK_ARG(x && dy && dw && workspace, "dwconv3x3_wgrad: null tensor");
   int nchunks;
   long ppc;
@@ -812,6 +814,7 @@ extern "C" int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* 
 
 extern "C" int vrnet_upsample_bilinear_f32(const float* x, long ldx, float* y, long ldy, int B, int H, int W, int C,
                                            int scale, int out_nchw, void* stream) {
+  if (vr_ablated("misc")) return VR_OK;
   VR_CHECK_ARG(x && y && scale >= 1 && B > 0 && H > 0 && W > 0 && C > 0, "upsample: bad arguments");
   hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long)B * H * W * scale * scale * C)), dim3(256), 0,
                      vr_stream(stream), x, ldx, y, ldy, B, H, W, C, H * scale, W * scale, out_nchw);
@@ -821,6 +824,7 @@ extern "C" int vrnet_upsample_bilinear_f32(const float* x, long ldx, float* y, l
 
 extern "C" int vrnet_upsample_bilinear_bwd_f32(const float* dy, long lddy, int dy_nchw, float* dx, long lddx, int B,
                                                int H, int W, int C, int scale, int accumulate, void* stream) {
+  if (vr_ablated("misc")) return VR_OK;
   VR_CHECK_ARG(dy && dx && scale >= 1, "upsample_bwd: bad arguments");
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((long)B * H * W * C, 256)), dim3(256), 0, vr_stream(stream), dy,
                      lddy, dy_nchw, dx, lddx, B, H, W, C, H * scale, W * scale, accumulate);
@@ -882,6 +886,7 @@ extern "C" int vrnet_sa_coef_fwd(const double* mom, const float* cw, const float
 
 extern "C" int vrnet_sa_apply_f32(const float* x, long ldx, const float* P, const float* Q, const float* Mn, float* y,
                                   long ldy, int B, long HW, int C, void* stream) {
+  if (vr_ablated("misc")) return VR_OK;
   VR_CHECK_ARG(x && P && Q && Mn && y && C % 2 == 0, "sa_apply: bad arguments");
   hipLaunchKernelGGL(sa_apply_kernel, dim3(grid_for(HW * C), B), dim3(256), 0, vr_stream(stream), x, ldx, P, Q, Mn, y, ldy,
                      HW, C);
@@ -902,6 +907,7 @@ extern "C" int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long
                                 float* dsw, float* dsb, float* dgnw, float* dgnb, float* EF /*[2][B][C] scratch*/, int B,
                                 long HW, int C, int G, int accumulate_dx, int accumulate_params, void* workspace,
                                 long workspace_bytes, void* stream) {
+  if (vr_ablated("misc")) return VR_OK;
   VR_CHECK_ARG(dy && x && P && Q && Mn && mom && dx && EF && workspace, "sa_bwd: null tensor");
   VR_CHECK_ARG(workspace_bytes >= vrnet_sa_bwd_workspace(B, HW, C), "sa_bwd: workspace too small");
   int TPR, ncb, nchunks;

@@ -997,6 +997,7 @@ static int gn_apply_bwd_impl(const float* dy, long lddy, const float* x, long ld
                              const float* gamma, int B, long HW, int C, const float* add, long ldadd, float* out, long ldo,
                              float* dgamma, float* dbeta, int accumulate_params, const vrnet_planes_out* outp, void* workspace,
                              long workspace_bytes, void* stream) {
+  if (vr_ablated("affine") || vr_ablated("gnbwd")) return VR_OK;
   VR_CHECK_ARG(dy && x && mean_rstd && gamma && out && dgamma && dbeta && workspace && vr_planes_out_ok(outp, C), "gn_apply_bwd: null tensor");
   VR_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (!add || ldadd % 4 == 0) &&
                    vr_aligned16(dy) && vr_aligned16(x) && vr_aligned16(out) && vr_aligned16(gamma) && (!add || vr_aligned16(add)),
@@ -1208,6 +1209,7 @@ extern "C" int vrnet_moments_to_float(const double* mom, float* out, long n, dou
 
 extern "C" int vrnet_copy_channels_f32(const float* src, long lds, int scs, float* dst, long ldd, int dcs, long rows,
                                        int C, int accumulate, void* stream) {
+  if (vr_ablated("misc")) return VR_OK;
   VR_CHECK_ARG(src && dst && rows > 0 && C > 0, "copy_channels: bad arguments");
   long blocks = vr_cdiv(rows * C, 1024);
   if (blocks > 8192) blocks = 8192;
@@ -1219,6 +1221,7 @@ extern "C" int vrnet_copy_channels_f32(const float* src, long lds, int scs, floa
 
 extern "C" int vrnet_cat2_f32(float* a, long lda, int Ca, float* b, long ldb, int Cb, float* cat, long ldc, long rows,
                               int interleave, int dir, int accumulate_a, int accumulate_b, void* stream) {
+  if (vr_ablated("misc")) return VR_OK;
   VR_CHECK_ARG(cat && rows > 0 && Ca > 0 && Cb > 0 && (a || b) && (dir == 0 || dir == 1), "cat2: bad arguments");
   VR_CHECK_ARG(dir == 1 || (a && b), "cat2: the forward direction needs both sources");
   VR_CHECK_ARG(!interleave || Ca == Cb, "cat2: the channel shuffle needs halves of equal width");
@@ -1249,6 +1252,7 @@ extern "C" int vrnet_nhwc_to_nchw_f32(const float* src, long lds, float* dst, in
 }
 
 extern "C" int vrnet_add_f32(float* dst, const float* src, long n, void* stream) {
+  if (vr_ablated("misc")) return VR_OK;
   VR_CHECK_ARG(dst && src && n >= 0, "add: bad arguments");
   if (n == 0) return VR_OK;
   long blocks = vr_cdiv(n, 1024);

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VRNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libvrnet_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -28,7 +28,9 @@ _SIGS = {
     "vrnet_tuning_build": ([], I),
     "vrnet_kernel_launches": ([I], L),
     "vrnet_device_arch": ([ctypes.c_char_p, I], I),
-    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P, P, P], I),
+    "vrnet_conv2d_f32": ([P, L, P, P, P, L] + [I] * 14 + [P, L, P, L, P, P, P, L, I, I, I, I, P, I, I, P, P, P, P, P, P, P, L, P], I),
+    "vrnet_conv2d_dma_plan": ([L, I, L, P], I),
+    "vrnet_conv2d_splitk_workspace": ([L, I, L], L),
     "vrnet_conv_planes_bytes": ([I, I], L),
     "vrnet_conv_planes_pack_f32": ([P, I, L, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
@@ -219,10 +221,17 @@ def conv2d(a, lda, w, bias, y, ldy, B, H, W, Cin, OH, OW, Cout, kh, kw, stride, 
     if colstats is not None:
         part, x2, ldx2, gam, tot = colstats
         cs = ctypes.byref(ConvColStats(ptr(part), ptr(x2), ldx2, ptr(gam), ptr(tot)))
+    # split contraction of the small maps (precision 2): slabs of raw accumulators in this stream's scratch arena
+    ws, wsb = None, 0
+    if precision == 2:
+        rows, cols, ktot = (B * OH * OW, Cout, Cin * kh * kw) if mode == 0 else (B * H * W, Cin, Cout * kh * kw)
+        wsb = _lib.vrnet_conv2d_splitk_workspace(rows, cols, ktot)
+        if wsb:
+            ws = _ws.get(wsb, a.device)
     _check(_lib.vrnet_conv2d_f32(ptr(a), lda, ptr(w), ptr(bias), ptr(y), ldy, B, H, W, Cin, OH, OW, Cout, kh, kw,
                                  stride, pad, dil, mode, act, ptr(ypre), ldypre, ptr(res), ldres, ptr(res_scale),
                                  ptr(kscale), ptr(aux), ldaux, out_nchw, out_ctot, out_coff, accumulate, ptr(stats),
-                                 precision, pair_rows, ptr(w2), ptr(bias2), ptr(res_scale2), ptr(kscale2), ptr(w_planes), cs, stream()),
+                                 precision, pair_rows, ptr(w2), ptr(bias2), ptr(res_scale2), ptr(kscale2), ptr(w_planes), cs, ptr(ws), wsb, stream()),
            "conv2d")
 
 
@@ -314,6 +323,14 @@ def bf16_conv_ok(lda, Cin, Cout, mode):
 def conv2d_dma_tile(rows, cols):
     """22 / 21 / 0: tile of the LDS-DMA x6 / bf16 kernels for a GEMM of rows x cols (0 = no such kernel)."""
     return _lib.vrnet_conv2d_dma_tile(rows, cols)
+
+
+def conv2d_dma_plan(rows, cols, ktot):
+    """(tile, splits) of conv2d at precision 2 for a GEMM of rows x cols with a contraction of ktot: the unsplit tile with
+    splits = 1, or tile 21 with the K loop split over `splits` workgroups per tile (small maps), or (0, 1)."""
+    s = ctypes.c_int(1)
+    t = _lib.vrnet_conv2d_dma_plan(rows, cols, ktot, ctypes.byref(s))
+    return t, s.value
 
 
 def pack_weight_t(w_oihw, kscale, out, Cout, Cin, kh, kw):

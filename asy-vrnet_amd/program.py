@@ -316,7 +316,7 @@ class RT:
     def planes(self, w, mode, J, K, rows, kscale=None):
         """bf16 planes of a 1x1 weight for a launch of `rows` GEMM rows and J columns (None: the launch does not run on
         an x6 tile kernel, or the planes are switched off).  mode 0: w is [J = Cout][K = Cin]; mode 1: [K = Cout][J = Cin]."""
-        if self.wplanes is None or self.bf16 or self.fp32_precision != 2 or K % 16 or not hip.conv2d_dma_tile(rows, J):
+        if self.wplanes is None or self.bf16 or self.fp32_precision != 2 or K % 16 or not hip.conv2d_dma_plan(rows, J, K)[0]:
             return None
         sj, sk = (K, 1) if mode == 0 else (1, J)
         return self.wplanes.get((id(w), mode), w, J, K, sj, sk, kscale)
@@ -645,7 +645,7 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
         hip.bn_coef_bwd(tot2, ms, bn.weight, True, 1, rt.sync_bn.count(B, HW), C, A, E, D, S, rt.buf(C), rt.buf(C), 0)
         hip.bn_coef_bwd(mom2, ms, bn.weight, True, B, HW, C, rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C), gw, gb, accw)
     else:
-        fwd = getattr(ms, "fwd_coef", None) if mask is not None else None
+        fwd = getattr(ms, "fwd_coef", None) if (mask is not None and BN_ZMASK) else None
         if fwd is not None:
             # y = ReLU(BN(z)): neither pass reads y -- two tensor reads each where there were three
             hip.bn_stats_bwd_zmask(dy, lddy, z.t, z.ld, fwd, ms, bn.weight, rt.training, B, HW, C, A, E, D, S, gw, gb, accw)
@@ -1687,6 +1687,7 @@ class WeightPlanes:
         hip.conv_planes_pack(self.table, len(self.ents), self.nblocks)
 
 
+BN_ZMASK = os.environ.get("VRNET_BN_ZMASK", "1") != "0"      # (diagnostic A/B switch)
 PG_MAX_ROWS = int(os.environ.get("VRNET_PG_MAX_ROWS", "1000000000"))      # plane GEMMs only for maps of at most this many pixels (diagnostic override)
 # which GEMM kinds of the ClusterBlocks run on plane operands by default, per compute_dtype (measured: DESIGN 3.6)
 PLANE_GEMMS_DEFAULT = {"f32": False, "bf16": "fwd+wgrad", "off": False}

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------- */
-int vrnet_abi_version(void);                 /* == 6 */
+int vrnet_abi_version(void);                 /* == 7 */
 /* Kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to: 1 fp32 MFMA
  * (register-staged), 2 fp32 MFMA (LDS-DMA ring), 3 bf16-rounded operands, 4 direct kernels for tiny channel counts,
  * 5 direct HBM-streaming kernels for 1x1 convs with <= 16 output channels over wide inputs (head predictions, seg logits),
@@ -93,7 +93,17 @@ int vrnet_conv2d_f32(const float* a, long lda, const float* w, const float* bias
                      const float* res_scale, const float* kscale, const float* aux, long ldaux, int out_nchw,
                      int out_ctot, int out_coff, int accumulate, double* stats, int precision, int pair_rows,
                      const float* w2, const float* bias2, const float* res_scale2, const float* kscale2,
-                     const void* w_planes, const vrnet_conv_colstats* colstats, void* stream);
+                     const void* w_planes, const vrnet_conv_colstats* colstats, void* workspace, long workspace_bytes,
+                     void* stream);
+/* Split contraction (round 4): a 2048-row map (16 x 16 at batch 8) has 64-128 tiles of 128 x 64 for 256 CUs, so at
+ * precision 2 such layers ran on 64 x 64 fp32-MFMA tiles at 40-70 TFLOP/s.  With a `workspace` of
+ * vrnet_conv2d_splitk_workspace(rows, cols, ktot) bytes (rows x cols = the GEMM: B*OH*OW x Cout forward, B*H*W x Cin data
+ * gradient; ktot = contraction length incl. taps; 0 = the shape is not split) the x6 tile kernels take them: `splits`
+ * workgroups per tile each run a share of the K loop and leave raw accumulators in the workspace, a finishing launch adds
+ * the slabs in order (deterministic) and runs the usual fused epilogue.  workspace NULL: never split.
+ * vrnet_conv2d_dma_plan: the tile (as vrnet_conv2d_dma_tile, or 21 for a split launch) and *splits. */
+long vrnet_conv2d_splitk_workspace(long rows, int cols, long ktot);
+int vrnet_conv2d_dma_plan(long rows, int cols, long ktot, int* splits);
 /* Pre-split weights for the x6 kernels (precision 2, 1x1 convs, contraction % 16 == 0): the six-product scheme spends its
  * VALU time on splitting fragments into bf16 planes; weights are the same for every row tile of a step, so they can be
  * split ONCE per step.  vrnet_conv_planes_pack_f32 does that for a whole table of weights in one launch (round-to-nearest-

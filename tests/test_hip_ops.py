@@ -914,6 +914,13 @@ X6_CASES = [
     (2, 32, 32, 320, 320, 3, 1, 1, 1),
     (2, 16, 16, 512, 512, 3, 1, 1, 1),
     (2, 64, 64, 128, 1024, 1, 1, 0, 1),
+    # round 4, split contraction: 16 x 16 maps at batch 8 (2048 rows) -- S workgroups per 128 x 64 tile share the K loop
+    (8, 16, 16, 2048, 512, 1, 1, 0, 1),     # stage-3 Mlp.fc2: forward split; the data gradient has 2048 columns (unsplit)
+    (8, 16, 16, 512, 2048, 1, 1, 0, 1),     # stage-3 Mlp.fc1: data gradient split
+    (8, 16, 16, 512, 512, 3, 1, 1, 1),      # 3x3: the split may start inside a tap
+    (8, 16, 16, 512, 512, 3, 1, 12, 12),    # dilated: most taps dead for most rows, per-tile live-tap lists
+    (8, 16, 16, 320, 512, 3, 1, 1, 1),
+    (8, 16, 16, 520, 264, 1, 1, 0, 1),      # ragged columns and a contraction that is no multiple of 16
 ]
 
 
@@ -951,6 +958,16 @@ def _conv_suite(hip, case, prec):
     hip.conv2d_wgrad(x, Ci, g, Co, dw_nb, None, None, B, H, W, Ci, OH, OW, Co, k, k, s, p, d, accumulate=1, precision=prec)
     return (y, ypre, st.view(B, -1, 2).sum(1) if st is not None else None, dx, dw, db, dl if k == 1 else None,
             (fam_f, fam_d, fam_w), dw_nb)
+
+
+def test_split_contraction_plan(hip):
+    """Which shapes the library splits: small maps with a long contraction; never a shape that fills the chip unsplit."""
+    assert hip.conv2d_dma_plan(2048, 512, 2048) == (21, 4)
+    assert hip.conv2d_dma_plan(2048, 512, 512 * 9)[1] >= 2
+    assert hip.conv2d_dma_plan(2048, 2048, 512) == (21, 1)          # 512 tiles already
+    assert hip.conv2d_dma_plan(8192, 320, 1280)[1] == 1
+    assert hip.conv2d_dma_plan(2048, 256, 64) == (0, 1)             # too short to split
+    assert hip.conv2d_dma_plan(2048, 32, 4096) == (0, 1)
 
 
 @pytest.mark.parametrize("case", X6_CASES)
@@ -1466,7 +1483,8 @@ def _planes(hip, w2d, J, K, sj, sk, kscale=None):
 
 
 @pytest.mark.parametrize("case", [(2, 128, 128, 64, 128), (2, 128, 128, 64, 512), (2, 128, 128, 512, 64), (8, 32, 32, 320, 1280),
-                                  (8, 32, 32, 1280, 320), (4, 64, 64, 128, 96), (8, 64, 64, 256, 192), (2, 128, 128, 80, 64)])
+                                  (8, 32, 32, 1280, 320), (4, 64, 64, 128, 96), (8, 64, 64, 256, 192), (2, 128, 128, 80, 64),
+                                  (8, 16, 16, 2048, 512), (8, 16, 16, 512, 2048), (8, 16, 16, 512, 512)])      # split contraction
 def test_x6_conv_with_presplit_weights(hip, case):
     """precision 2 with `w_planes` (weights split once into bf16 planes by vrnet_conv_planes_pack_f32, kernel family 9):
     forward with the full epilogue and data gradient with the layer scale folded into the pack, against fp64 ATen."""
