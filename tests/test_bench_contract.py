@@ -107,7 +107,7 @@ def test_roofline_families_follow_the_rocprof_summary_of_the_same_round():
     """The per-family rates in the committed headline line (HIP events, gated replay) against FLOPs / rocprofv3 serial
     duration of the same round's refresh call (profiles/rNN_kernel_stats_*_serial.csv), for every family that carries >= 5 % of
     the FLOPs: the line may read LOW by the dispatch gap + event packets an event pair adds (2.5-7 us per launch: 3-7 % on
-    these 36-155 us launches) and never high.  (Round 3's driver line read family 9 27 % low: the event pairs had included
+    these 36-155 us launches; up to 9 % where split contractions put two launches into one timed call) and never high.  (Round 3's driver line read family 9 27 % low: the event pairs had included
     the host's launch latency; from round 4 the instrumented replay is issued behind a device-side gate.)"""
     import csv
     benches = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_phi-l_bs8_512.json")))
@@ -122,6 +122,8 @@ def test_roofline_families_follow_the_rocprof_summary_of_the_same_round():
               ("igemm_dma_kernel<0, 3, 2, 1, 6>", "x6: six exact"), ("igemm_dma_kernel<1, 3, 2, 1, 6>", "x6: six exact"),
               ("igemm_dma_kernel<0, 3, 2, 2, 6>", "x6: six exact"), ("igemm_dma_kernel<1, 3, 2, 2, 6>", "x6: six exact"),
               ("igemm_dma_kernel<0, 3, 1, 1, 0>", "fp32 MFMA, LDS-DMA"), ("igemm_dma_kernel<1, 3, 1, 1, 0>", "fp32 MFMA, LDS-DMA")]
+    # the finishing launch of a split contraction belongs to the conv call the line timed (its time counts, it is no call)
+    aux_of = [("igemm_splitk_finish_kernel<2, 1, 2, 2>", "x6: six exact"), ("igemm_splitk_finish_kernel<1, 2, 4, 1>", "x6 with weights pre-split")]
     total_gf = roof["avg_launch_gflop"] * roof["launches_per_step"]
     checked = 0
     for fam, v in roof["families"].items():
@@ -132,12 +134,16 @@ def test_roofline_families_follow_the_rocprof_summary_of_the_same_round():
             if any(k in r["Name"] and fam.startswith(f) for k, f in fam_of):
                 ns += int(r["TotalDurationNs"])
                 calls += int(r["Calls"])
+            elif any(k in r["Name"] and fam.startswith(f) for k, f in aux_of):
+                ns += int(r["TotalDurationNs"])
         assert calls and calls % v["launches_per_step"] == 0, (fam, calls, v["launches_per_step"])
         steps = calls // v["launches_per_step"]
         rate = v["share_of_flops"] * total_gf / (ns / steps * 1e-9) / 1e3          # TFLOP/s by rocprofv3
         us_prof = ns / calls / 1e3                                                  # average launch by rocprofv3
         us_line = us_prof * rate / v["achieved"]                                    # ... by the line's event pairs
         assert -0.5 < us_line - us_prof < 8.0, (fam, "rocprofv3", round(rate, 1), "line", v["achieved"], us_prof, us_line)
-        assert abs(rate - v["achieved"]) < 0.08 * rate, (fam, "rocprofv3", round(rate, 1), "line", v["achieved"])
+        # (a split contraction is two launches inside one timed call: one more dispatch gap that rocprofv3's durations do not
+        #  contain -- 3.6 us on the 41 us average launch of the pre-split family from round 4 on)
+        assert abs(rate - v["achieved"]) < 0.10 * rate, (fam, "rocprofv3", round(rate, 1), "line", v["achieved"])
         checked += 1
     assert checked >= 2

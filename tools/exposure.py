@@ -26,8 +26,11 @@ def main():
     # whole steps (tracing stretches a step; host-side gaps are not a reliable boundary)
     nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     marks = [i for i, r in enumerate(rows) if r[2].startswith(("planes_pack_kernel", "planes_split_kernel"))]
-    # (in eager runs the marker also fires at first-use registrations: keep marks that are >= 5 ms apart)
-    steps = [m for k, m in enumerate(marks) if k == 0 or rows[m][0] - rows[marks[k - 1]][0] > 5_000_000]
+    # (in eager runs the marker also fires at first-use registrations: keep marks that are >= 5 ms after the last KEPT one)
+    steps = []
+    for m in marks:
+        if not steps or rows[m][0] - rows[steps[-1]][0] > 5_000_000:
+            steps.append(m)
     if len(steps) > nsteps:
         # the last marker opens the final step, which ends with the trace: use the nsteps steps before it
         rows = rows[steps[-nsteps - 1]:steps[-1]]

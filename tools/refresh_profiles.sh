@@ -25,7 +25,11 @@ export VRNET_HIP_LIB=$PWD/asy-vrnet_amd/csrc/libvrnet_hip_tuning.so
 (echo "# VRNET_PGEMM_DBG bits: 1 no MFMAs, 2 no DMA inside the loop, 4 no fragment reads (timing ablations of pgemm_kernel<3>, results garbage)"
  for d in 0 1 2 3 4 5 6 7; do echo "== VRNET_PGEMM_DBG=$d"; VRNET_PGEMM_DBG=$d timeout 300 python3 tools/pgemm_probe.py 8192 320 1280 8192 1280 320 32768 1024 256 131072 256 64 2>&1 | grep "np=3  "; done) > $out/pgemm_ablation.txt
 tools/sweep_env.sh "" "VRNET_ABLATE=igemm" "VRNET_ABLATE=wgrad" "VRNET_ABLATE=igemm,wgrad" "VRNET_ABLATE=moments,affine" \
-    "VRNET_ABLATE=igemm,wgrad,moments,affine" > $out/ablation_ms_per_step.txt 2>&1
+    "VRNET_ABLATE=cluster" "VRNET_ABLATE=misc,dwconv" "VRNET_ABLATE=igemm,wgrad,moments,affine,cluster,misc,dwconv" \
+    "VRNET_ABLATE=igemm_small,wgrad_small" "VRNET_ABLATE=igemm_mid,wgrad_mid" "VRNET_ABLATE=igemm_big,wgrad_big" \
+    "VRNET_SPLITK=0" "VRNET_BN_ZMASK=0" "" > $out/ablation_ms_per_step.txt 2>&1
+FLAGS="--dtype bf16 --batch 16" tools/sweep_env.sh "" "VRNET_ABLATE=igemm" "VRNET_ABLATE=wgrad" "VRNET_ABLATE=igemm,wgrad" \
+    "VRNET_ABLATE=moments,affine" "VRNET_ABLATE=cluster" "VRNET_ABLATE=misc,dwconv" > $out/ablation_ms_per_step_bf16_bs16.txt 2>&1
 unset VRNET_HIP_LIB
 # ---- rocprofv3: per-kernel totals (serial = the condition of bench.py's HIP-event measurement; hipgraph = the replayed step)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/graph -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > $out/graph.log 2>&1
