@@ -737,6 +737,56 @@ __global__ void cat2_kernel(float* a, long lda, int Ca, float* b, long ldb, int 
   }
 }
 
+// The same on 16-byte accesses (channel counts and row strides % 4, aligned bases): a thread moves four consecutive source
+// channels; with the 2-group shuffle it takes the quad of BOTH halves and writes the eight interleaved outputs.  (Round 4: the
+// scalar kernel above spent 24 us per launch on a 64-bit division per element; 20 launches per step on the chain.)
+__global__ __launch_bounds__(256) void cat2_vec_kernel(float* a, long lda, int Ca, float* b, long ldb, int Cb, float* cat,
+                                                       long ldc, long rows, int interleave, int dir, int acc_a, int acc_b) {
+  const int qa = Ca >> 2, qb = Cb >> 2;
+  const int per_row = interleave ? qa : qa + qb;
+  const long total = rows * per_row;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / per_row;
+    const int q = (int)(e - r * per_row);
+    if (interleave) {
+      float* w = cat + r * ldc + 8 * q;
+      if (dir == 0) {
+        const f32x4 u = ld4(a + r * lda + 4 * q), v = ld4(b + r * ldb + 4 * q);
+        const f32x4 lo = {u[0], v[0], u[1], v[1]}, hi = {u[2], v[2], u[3], v[3]};
+        *reinterpret_cast<f32x4*>(w) = lo;
+        *reinterpret_cast<f32x4*>(w + 4) = hi;
+      } else {
+        const f32x4 lo = ld4(w), hi = ld4(w + 4);
+        if (a) {
+          f32x4 u = {lo[0], lo[2], hi[0], hi[2]};
+          f32x4* d = reinterpret_cast<f32x4*>(a + r * lda + 4 * q);
+          if (acc_a) u += *d;
+          *d = u;
+        }
+        if (b) {
+          f32x4 v = {lo[1], lo[3], hi[1], hi[3]};
+          f32x4* d = reinterpret_cast<f32x4*>(b + r * ldb + 4 * q);
+          if (acc_b) v += *d;
+          *d = v;
+        }
+      }
+    } else {
+      const bool second = q >= qa;
+      float* src = second ? b : a;
+      if (!src) continue;
+      float* sp = second ? b + r * ldb + 4 * (q - qa) : a + r * lda + 4 * q;
+      float* w = cat + r * ldc + (second ? Ca + 4 * (q - qa) : 4 * q);
+      if (dir == 0) {
+        *reinterpret_cast<f32x4*>(w) = ld4(sp);
+      } else {
+        f32x4 t = ld4(w);
+        if (second ? acc_b : acc_a) t += ld4(sp);
+        *reinterpret_cast<f32x4*>(sp) = t;
+      }
+    }
+  }
+}
+
 // 32x32 LDS-tiled transpose between [B][C][HW] and [B][HW][ld]
 __global__ void nchw_to_nhwc_kernel(const float* src, float* dst, long ldd, int C, long HW) {
   __shared__ float tile[32][33];
@@ -1226,6 +1276,17 @@ extern "C" int vrnet_cat2_f32(float* a, long lda, int Ca, float* b, long ldb, in
   VR_CHECK_ARG(dir == 1 || (a && b), "cat2: the forward direction needs both sources");
   VR_CHECK_ARG(!interleave || Ca == Cb, "cat2: the channel shuffle needs halves of equal width");
   VR_CHECK_ARG((!a || lda >= Ca) && (!b || ldb >= Cb) && ldc >= Ca + Cb, "cat2: row strides");
+  const bool vec = Ca % 4 == 0 && Cb % 4 == 0 && ldc % 4 == 0 && vr_aligned16(cat) && (!a || (lda % 4 == 0 && vr_aligned16(a))) &&
+                   (!b || (ldb % 4 == 0 && vr_aligned16(b)));
+  if (vec) {
+    long vblocks = vr_cdiv(rows * (interleave ? Ca / 4 : (Ca + Cb) / 4), 256 * 2);
+    if (vblocks > 8192) vblocks = 8192;
+    if (vblocks < 1) vblocks = 1;
+    hipLaunchKernelGGL(cat2_vec_kernel, dim3(vblocks), dim3(256), 0, vr_stream(stream), a, lda, Ca, b, ldb, Cb, cat, ldc, rows,
+                       interleave, dir, accumulate_a, accumulate_b);
+    VR_LAUNCH_CHECK("cat2");
+    return VR_OK;
+  }
   long blocks = vr_cdiv(rows * (Ca + Cb), 1024);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(cat2_kernel, dim3(blocks), dim3(256), 0, vr_stream(stream), a, lda, Ca, b, ldb, Cb, cat, ldc, rows,

@@ -1517,7 +1517,7 @@ def test_x6_conv_with_presplit_weights(hip, case):
 
 
 @pytest.mark.parametrize("interleave", [False, True])
-@pytest.mark.parametrize("case", [(37, 8, 8), (1024, 64, 64), (200, 12, 20)])
+@pytest.mark.parametrize("case", [(37, 8, 8), (1024, 64, 64), (200, 12, 20), (50, 6, 10), (33, 6, 6), (4096, 128, 128)])      # (6, .): scalar kernel
 def test_cat2_and_adjoint(hip, case, interleave):
     """torch.cat([a, b], channels) (+ shuffle_channels(groups=2)) in one launch, and its adjoint with per-source accumulate
     flags and an absent source (vr_coc.py:70-80, coc_fpn_dual.py:120-130)."""
