@@ -378,6 +378,83 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* x, long ldx,
   }
 }
 
+// NHWC output on 16-byte accesses: a thread interpolates four consecutive channels of one output pixel (index arithmetic
+// once per quad; the same expression per component as the scalar kernel).
+__global__ __launch_bounds__(256) void upsample_vec_kernel(const float* x, long ldx, float* y, long ldy, int B, int H, int W,
+                                                           int C, int OH, int OW) {
+  const float ry = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float rx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const int CQ = C >> 2;
+  const long total = (long)B * OH * OW * CQ;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int cq = e % CQ;
+    long q = e / CQ;
+    const int ox = q % OW; q /= OW;
+    const int oy = q % OH;
+    const long b = q / OH;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(ry, oy, H, &y0, &y1, &ly);
+    src_index(rx, ox, W, &x0, &x1, &lx);
+    const float* base = x + (b * H * W) * ldx + 4 * cq;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((long)y0 * W + x0) * ldx);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((long)y0 * W + x1) * ldx);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((long)y1 * W + x0) * ldx);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((long)y1 * W + x1) * ldx);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (1.f - ly) * ((1.f - lx) * v00[j] + lx * v01[j]) + ly * ((1.f - lx) * v10[j] + lx * v11[j]);
+    *reinterpret_cast<f32x4*>(y + ((b * OH + oy) * OW + ox) * ldy + 4 * cq) = v;
+  }
+}
+
+// The adjoint for NHWC dy on 16-byte accesses (same gather, four channels per thread).
+__global__ __launch_bounds__(256) void upsample_bwd_vec_kernel(const float* dy, long lddy, float* dx, long lddx, int B, int H,
+                                                               int W, int C, int OH, int OW, int accumulate) {
+  const float ry = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float rx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const int CQ = C >> 2;
+  const long total = (long)B * H * W * CQ;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int cq = e % CQ;
+    long q = e / CQ;
+    const int ix = q % W; q /= W;
+    const int iy = q % H;
+    const long b = q / H;
+    int oy_lo = 0, oy_hi = OH - 1, ox_lo = 0, ox_hi = OW - 1;
+    if (ry > 0.f) {
+      oy_lo = max(0, (int)floorf((float)(iy - 1) / ry) - 1);
+      oy_hi = min(OH - 1, (int)ceilf((float)(iy + 1) / ry) + 1);
+    }
+    if (rx > 0.f) {
+      ox_lo = max(0, (int)floorf((float)(ix - 1) / rx) - 1);
+      ox_hi = min(OW - 1, (int)ceilf((float)(ix + 1) / rx) + 1);
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly;
+      src_index(ry, oy, H, &y0, &y1, &ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx;
+        src_index(rx, ox, W, &x0, &x1, &lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx == 0.f) continue;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + ((b * OH + oy) * (long)OW + ox) * lddy + 4 * cq);
+        const float w = wy * wx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += w * g[j];
+      }
+    }
+    f32x4* d = reinterpret_cast<f32x4*>(dx + ((b * H + iy) * (long)W + ix) * lddx + 4 * cq);
+    if (accumulate) s += *d;
+    *d = s;
+  }
+}
+
 // gather form of the adjoint: deterministic, no atomics
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* dy, long lddy, int dy_nchw, float* dx, long lddx,
                                                            int B, int H, int W, int C, int OH, int OW, int accumulate) {
@@ -816,8 +893,12 @@ extern "C" int vrnet_upsample_bilinear_f32(const float* x, long ldx, float* y, l
                                            int scale, int out_nchw, void* stream) {
   if (vr_ablated("misc")) return VR_OK;
   VR_CHECK_ARG(x && y && scale >= 1 && B > 0 && H > 0 && W > 0 && C > 0, "upsample: bad arguments");
-  hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long)B * H * W * scale * scale * C)), dim3(256), 0,
-                     vr_stream(stream), x, ldx, y, ldy, B, H, W, C, H * scale, W * scale, out_nchw);
+  if (!out_nchw && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && vr_aligned16(x) && vr_aligned16(y))
+    hipLaunchKernelGGL(upsample_vec_kernel, dim3(grid_for((long)B * H * W * scale * scale * (C / 4))), dim3(256), 0,
+                       vr_stream(stream), x, ldx, y, ldy, B, H, W, C, H * scale, W * scale);
+  else
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long)B * H * W * scale * scale * C)), dim3(256), 0,
+                       vr_stream(stream), x, ldx, y, ldy, B, H, W, C, H * scale, W * scale, out_nchw);
   VR_LAUNCH_CHECK("upsample");
   return VR_OK;
 }
@@ -826,8 +907,12 @@ extern "C" int vrnet_upsample_bilinear_bwd_f32(const float* dy, long lddy, int d
                                                int H, int W, int C, int scale, int accumulate, void* stream) {
   if (vr_ablated("misc")) return VR_OK;
   VR_CHECK_ARG(dy && dx && scale >= 1, "upsample_bwd: bad arguments");
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((long)B * H * W * C, 256)), dim3(256), 0, vr_stream(stream), dy,
-                     lddy, dy_nchw, dx, lddx, B, H, W, C, H * scale, W * scale, accumulate);
+  if (!dy_nchw && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && vr_aligned16(dy) && vr_aligned16(dx))
+    hipLaunchKernelGGL(upsample_bwd_vec_kernel, dim3(grid_for((long)B * H * W * (C / 4), 256)), dim3(256), 0, vr_stream(stream),
+                       dy, lddy, dx, lddx, B, H, W, C, H * scale, W * scale, accumulate);
+  else
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((long)B * H * W * C, 256)), dim3(256), 0, vr_stream(stream), dy,
+                       lddy, dy_nchw, dx, lddx, B, H, W, C, H * scale, W * scale, accumulate);
   VR_LAUNCH_CHECK("upsample_bwd");
   return VR_OK;
 }

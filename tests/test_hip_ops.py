@@ -392,8 +392,9 @@ def test_depthwise_wgrad_sliding_window(hip, shape):
 
 
 @pytest.mark.parametrize("scale,nchw_out", [(2, 0), (4, 0), (4, 1), (2, 1)])
-def test_upsample(hip, scale, nchw_out):
-    B, H, W, C = 2, 6, 5, 9
+@pytest.mark.parametrize("C", [9, 8, 128])      # 9: scalar kernels; 8 / 128: four channels per thread (NHWC)
+def test_upsample(hip, scale, nchw_out, C):
+    B, H, W = 2, 6, 5
     x = rnd(B, C, H, W, seed=1).requires_grad_(True)
     y = F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=True)
     g = rnd(*y.shape, seed=2)
@@ -413,6 +414,9 @@ def test_upsample(hip, scale, nchw_out):
     dx = torch.empty(B, H, W, C, device="cuda")
     hip.upsample_bwd(gg, C, nchw_out, dx, C, B, H, W, C, scale)
     close(nchw(dx), x.grad, what="up bwd")
+    dx2 = torch.full((B, H, W, C), 2.0, device="cuda")
+    hip.upsample_bwd(gg, C, nchw_out, dx2, C, B, H, W, C, scale, accumulate=1)
+    assert torch.equal(dx2, dx + 2.0)
 
 
 def test_image_gain(hip):
