@@ -1441,7 +1441,9 @@ static int vr_dma_plan(long M, int CN, long ktot, long ws_bytes, int* S_out) {
   if (tile || CN <= 32 || ws_bytes <= 0) return tile;
   static const int on = vr_tune("VRNET_SPLITK", 1);
   static const int target = vr_tune("VRNET_SPLITK_TARGET", 512);         // workgroups wanted (2 per CU)
-  static const int min_steps = vr_tune("VRNET_SPLITK_MIN_STEPS", 8);     // K16 steps per split at least
+  // K16 steps per split at least (measured in the step: with 8 the 2 048 x 512 x 512 layers went 21.8 -> 30 us per call --
+  // the finishing launch costs more than eight-step splits save; 2 048 x 512 x 2 048: 61.6 -> 46.8 us)
+  static const int min_steps = vr_tune("VRNET_SPLITK_MIN_STEPS", 32);
   if (!on) return 0;
   const long mt = vr_cdiv(M, 128), nt21 = vr_cdiv(CN, 64), tiles = mt * nt21, steps = ktot / 16;
   long S = vr_cdiv(target, tiles);
@@ -1638,7 +1640,30 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
     const long mt = vr_cdiv(M, 128), nt22 = vr_cdiv(p.CN, 128), nt21 = vr_cdiv(p.CN, 64);
     int S = 1;
     // (the bf16-rounded tiles of precision 1 / 3 keep the unsplit rule: their callers asked vrnet_conv2d_dma_tile)
-    const int tile = precision == 2 ? vr_dma_plan(M, p.CN, ktot, workspace ? workspace_bytes : 0, &S) : vr_dma_tile(M, p.CN);
+    // contraction length that counts for the split: only taps that reach the image for at least one row (a 3 x 3 conv with
+    // dilation 18 on a 16 x 16 map is its centre tap)
+    long k_live = ktot;
+    if (kh * kw > 1) {
+      auto live = [&](int k, int n_m, int n_s) {
+        int c = 0;
+        for (int t = 0; t < k; ++t) {
+          bool any = false;
+          for (int o = 0; o < n_m && !any; ++o) {
+            if (mode == 0) {
+              const int sidx = o * stride - pad + t * dil;
+              any = sidx >= 0 && sidx < n_s;
+            } else {
+              const int tt = o + pad - t * dil;
+              any = tt >= 0 && tt % stride == 0 && tt / stride < n_s;
+            }
+          }
+          c += any;
+        }
+        return c;
+      };
+      k_live = (long)p.CK * live(kh, p.MH, p.SH) * live(kw, p.MW, p.SW);
+    }
+    const int tile = precision == 2 ? vr_dma_plan(M, p.CN, k_live, workspace ? workspace_bytes : 0, &S) : vr_dma_tile(M, p.CN);
     if (S > 1) { p.ksplit = S; p.kslab = reinterpret_cast<float*>(workspace); }
 #define VR_TILE_LAUNCH(PR)                                                                                              \
   do {                                                                                                                  \

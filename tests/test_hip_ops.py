@@ -970,6 +970,7 @@ def test_split_contraction_plan(hip):
     assert hip.conv2d_dma_plan(2048, 512, 512 * 9)[1] >= 2
     assert hip.conv2d_dma_plan(2048, 2048, 512) == (21, 1)          # 512 tiles already
     assert hip.conv2d_dma_plan(8192, 320, 1280)[1] == 1
+    assert hip.conv2d_dma_plan(2048, 512, 512) == (0, 1)            # 32 K16 steps: a split of fewer does not pay for its finishing launch
     assert hip.conv2d_dma_plan(2048, 256, 64) == (0, 1)             # too short to split
     assert hip.conv2d_dma_plan(2048, 32, 4096) == (0, 1)
 
@@ -1488,7 +1489,7 @@ def _planes(hip, w2d, J, K, sj, sk, kscale=None):
 
 @pytest.mark.parametrize("case", [(2, 128, 128, 64, 128), (2, 128, 128, 64, 512), (2, 128, 128, 512, 64), (8, 32, 32, 320, 1280),
                                   (8, 32, 32, 1280, 320), (4, 64, 64, 128, 96), (8, 64, 64, 256, 192), (2, 128, 128, 80, 64),
-                                  (8, 16, 16, 2048, 512), (8, 16, 16, 512, 2048), (8, 16, 16, 512, 512)])      # split contraction
+                                  (8, 16, 16, 2048, 512), (8, 16, 16, 512, 2048), (8, 16, 16, 1024, 512)])      # split contraction (4, 4, 2 splits)
 def test_x6_conv_with_presplit_weights(hip, case):
     """precision 2 with `w_planes` (weights split once into bf16 planes by vrnet_conv_planes_pack_f32, kernel family 9):
     forward with the full epilogue and data gradient with the layer scale folded into the pack, against fp64 ATen."""
