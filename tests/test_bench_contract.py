@@ -141,7 +141,10 @@ def test_roofline_families_follow_the_rocprof_summary_of_the_same_round():
         rate = v["share_of_flops"] * total_gf / (ns / steps * 1e-9) / 1e3          # TFLOP/s by rocprofv3
         us_prof = ns / calls / 1e3                                                  # average launch by rocprofv3
         us_line = us_prof * rate / v["achieved"]                                    # ... by the line's event pairs
-        assert -0.5 < us_line - us_prof < 8.0, (fam, "rocprofv3", round(rate, 1), "line", v["achieved"], us_prof, us_line)
+        # (the two numbers come from two runs of the refresh call: the 150-190 us fused-Mlp launches, HBM-bound, repeat to a
+        #  few per cent between runs, hence the relative terms beside the fixed 8 us)
+        assert -0.5 - 0.03 * us_prof < us_line - us_prof < max(8.0, 0.07 * us_prof), \
+            (fam, "rocprofv3", round(rate, 1), "line", v["achieved"], us_prof, us_line)
         # (a split contraction is two launches inside one timed call: one more dispatch gap that rocprofv3's durations do not
         #  contain -- 3.6 us on the 41 us average launch of the pre-split family from round 4 on)
         assert abs(rate - v["achieved"]) < 0.10 * rate, (fam, "rocprofv3", round(rate, 1), "line", v["achieved"])
