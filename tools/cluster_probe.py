@@ -20,8 +20,12 @@ def timeit(fn, n=50):
 
 tf = tb = 0.0
 # (B, H, W, E, D, fold, launches per step)
-for B, H, W, E, D, fold, cnt in ((8, 128, 128, 4, 32, 8, 4), (8, 64, 64, 4, 32, 4, 4), (8, 32, 32, 8, 32, 2, 12), (8, 16, 16, 8, 32, 1, 4),
-                                 (8, 64, 64, 4, 24, 2, 1), (8, 32, 32, 4, 24, 2, 1), (8, 16, 16, 4, 24, 2, 1)):
+SHAPES_512 = ((8, 128, 128, 4, 32, 8, 4), (8, 64, 64, 4, 32, 4, 4), (8, 32, 32, 8, 32, 2, 12), (8, 16, 16, 8, 32, 1, 4),
+              (8, 64, 64, 4, 24, 2, 1), (8, 32, 32, 4, 24, 2, 1), (8, 16, 16, 4, 24, 2, 1))
+# `python tools/cluster_probe.py 1024`: BASELINE configs[4] (1024 px, bs 4): every region has 1 024 points (neck p3: 4 096)
+SHAPES_1024 = ((4, 256, 256, 4, 32, 8, 4), (4, 128, 128, 4, 32, 4, 4), (4, 64, 64, 8, 32, 2, 12), (4, 32, 32, 8, 32, 1, 4),
+               (4, 128, 128, 4, 24, 2, 1), (4, 64, 64, 4, 24, 2, 1), (4, 32, 32, 4, 24, 2, 1))
+for B, H, W, E, D, fold, cnt in (SHAPES_1024 if "1024" in sys.argv[1:] else SHAPES_512):
     C = E * D
     f, v, g = (torch.randn(B, H, W, C, device="cuda") for _ in range(3))
     out, df, dv = (torch.empty(B, H, W, C, device="cuda") for _ in range(3))
