@@ -208,7 +208,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_slide_kernel(const float*
   const int quads = min(C / 4, 64), nseg = W / SEG;
   const int cq = threadIdx.x % quads, rest = threadIdx.x / quads;      // rest: (row lane, segment)
   const int groups = 256 / quads;
-  const int seg = rest % nseg, rl = rest / nseg, rpar = groups / nseg;
+  // nsegp of a row's 16-pixel runs are in flight at once (all of them where they fit the workgroup's groups; wider rows --
+  // 128-pixel maps at 1 024 px -- are walked in steps of nsegp), rpar rows side by side
+  const int nsegp = min(nseg, groups);
+  const int seg = rest % nsegp, rl = rest / nsegp, rpar = groups / nsegp;
   const int c = (blockIdx.y * quads + cq) * 4;
   const int nrows = B * H;
   const int r0 = blockIdx.x * rows_per_chunk, r1 = min(nrows, r0 + rows_per_chunk);
@@ -218,8 +221,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_slide_kernel(const float*
   for (int t = 0; t < 9; ++t) acc[t] = zero;
   const bool live = c < C && rl < rpar;
   if (live) {
-    const int x0 = seg * SEG;
-    for (int row = r0 + rl; row < r1; row += rpar) {
+    for (int row = r0 + rl; row < r1; row += rpar)
+    for (int sg = seg; sg < nseg; sg += nsegp) {
+      const int x0 = sg * SEG;
       const int b = row / H, yy = row - b * H;
       const float* xr[3];
       bool ok[3];
@@ -455,6 +459,38 @@ __global__ __launch_bounds__(256) void upsample_bwd_vec_kernel(const float* dy, 
   }
 }
 
+// NCHW output (the seg logits, C = num_seg_classes): a thread writes four consecutive ox of one (b, c, oy) row as one 16-byte
+// store; the row pair and its weight are found once per thread.  Same expression per output as upsample_kernel.
+__global__ __launch_bounds__(256) void upsample_nchw4_kernel(const float* x, long ldx, float* y, int B, int H, int W, int C,
+                                                             int OH, int OW) {
+  const float ry = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float rx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const int OQ = OW >> 2;
+  const long total = (long)B * C * OH * OQ;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int oq = e % OQ;
+    long q = e / OQ;
+    const int oy = q % OH; q /= OH;
+    const int c = q % C;
+    const long b = q / C;
+    int y0, y1;
+    float ly;
+    src_index(ry, oy, H, &y0, &y1, &ly);
+    const float* r0 = x + ((b * H + y0) * (long)W) * ldx + c;
+    const float* r1 = x + ((b * H + y1) * (long)W) * ldx + c;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int x0, x1;
+      float lx;
+      src_index(rx, 4 * oq + j, W, &x0, &x1, &lx);
+      const float v00 = r0[(long)x0 * ldx], v01 = r0[(long)x1 * ldx], v10 = r1[(long)x0 * ldx], v11 = r1[(long)x1 * ldx];
+      v[j] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    }
+    *reinterpret_cast<f32x4*>(y + ((b * C + c) * OH + oy) * (long)OW + 4 * oq) = v;
+  }
+}
+
 // gather form of the adjoint: deterministic, no atomics
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* dy, long lddy, int dy_nchw, float* dx, long lddx,
                                                            int B, int H, int W, int C, int OH, int OW, int accumulate) {
@@ -462,11 +498,21 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* dy, long
   const float rx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
   const long total = (long)B * H * W * C;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int c = e % C;
-    long q = e / C;
-    const int ix = q % W; q /= W;
-    const int iy = q % H;
-    const long b = q / H;
+    int c, ix, iy;
+    long b;
+    if (dy_nchw) {      // neighbouring threads = neighbouring ix of one channel plane: their dy reads share lines (round 4: with
+      ix = e % W;       // c fastest they came from planes megabytes apart -- 0.56 TB/s on the seg logits' gradient)
+      long q = e / W;
+      iy = q % H; q /= H;
+      c = q % C;
+      b = q / C;
+    } else {
+      c = e % C;
+      long q = e / C;
+      ix = q % W; q /= W;
+      iy = q % H;
+      b = q / H;
+    }
     int oy_lo = 0, oy_hi = OH - 1, ox_lo = 0, ox_hi = OW - 1;
     if (ry > 0.f) {
       oy_lo = max(0, (int)floorf((float)(iy - 1) / ry) - 1);
@@ -477,12 +523,37 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* dy, long
       ox_hi = min(OW - 1, (int)ceilf((float)(ix + 1) / rx) + 1);
     }
     float s = 0.f;
+    // the column weights do not depend on oy: found once (round 4; they were re-derived for every (oy, ox) pair -- 121 times
+    // per element at scale 4); the terms and their order are unchanged
+    constexpr int MAXR = 16;
+    const int nx = ox_hi - ox_lo + 1;
+    float wxs[MAXR];
+    if (nx <= MAXR) {
+#pragma unroll
+      for (int t = 0; t < MAXR; ++t) {
+        int x0, x1;
+        float lx;
+        src_index(rx, min(ox_lo + t, OW - 1), W, &x0, &x1, &lx);
+        wxs[t] = t < nx ? (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f) : 0.f;
+      }
+    }
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
       int y0, y1;
       float ly;
       src_index(ry, oy, H, &y0, &y1, &ly);
       const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
       if (wy == 0.f) continue;
+      if (nx <= MAXR) {
+        const float* grow = dy_nchw ? dy + ((b * C + c) * OH + oy) * (long)OW + ox_lo : dy + ((b * OH + oy) * (long)OW + ox_lo) * lddy + c;
+        const long gstep = dy_nchw ? 1 : lddy;
+#pragma unroll
+        for (int t = 0; t < MAXR; ++t) {
+          const float wx = wxs[t];
+          if (wx == 0.f) continue;
+          s += wy * wx * grow[t * gstep];
+        }
+        continue;
+      }
       for (int ox = ox_lo; ox <= ox_hi; ++ox) {
         int x0, x1;
         float lx;
@@ -841,8 +912,11 @@ extern "C" int vrnet_dwconv3x3_f32(const float* x, long ldx, const float* w, flo
 }
 
 static bool dw_wgrad_slide_ok(int W, int C, long ldx, long lddy, const void* x, const void* dy) {
-  return W % 16 == 0 && W <= 64 && C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && vr_aligned16(x) && vr_aligned16(dy) &&
-         (C / 4 <= 64 ? 256 % (C / 4) == 0 && (256 / (C / 4)) % (W / 16) == 0 : (C / 4) % 64 == 0);
+  if (!(W % 16 == 0 && W <= 512 && C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && vr_aligned16(x) && vr_aligned16(dy))) return false;
+  if (C / 4 > 64) return (C / 4) % 64 == 0 && (W / 16 <= 4 ? 4 % (W / 16) == 0 : (W / 16) % 4 == 0);
+  if (256 % (C / 4) != 0) return false;
+  const int groups = 256 / (C / 4), nseg = W / 16;      // runs of a row side by side, or the row in whole steps of `groups` runs
+  return nseg <= groups ? groups % nseg == 0 : nseg % groups == 0;
 }
 static void dw_wgrad_plan(long nrows, int W, int C, int* nchunks, long* rpc) {   // chunks of whole image rows
   long nc = vr_cdiv(nrows * W * C, 16384);
@@ -896,6 +970,9 @@ extern "C" int vrnet_upsample_bilinear_f32(const float* x, long ldx, float* y, l
   if (!out_nchw && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && vr_aligned16(x) && vr_aligned16(y))
     hipLaunchKernelGGL(upsample_vec_kernel, dim3(grid_for((long)B * H * W * scale * scale * (C / 4))), dim3(256), 0,
                        vr_stream(stream), x, ldx, y, ldy, B, H, W, C, H * scale, W * scale);
+  else if (out_nchw && (W * scale) % 4 == 0 && vr_aligned16(y))
+    hipLaunchKernelGGL(upsample_nchw4_kernel, dim3(grid_for((long)B * H * W * scale * scale * C / 4)), dim3(256), 0,
+                       vr_stream(stream), x, ldx, y, B, H, W, C, H * scale, W * scale);
   else
     hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long)B * H * W * scale * scale * C)), dim3(256), 0,
                        vr_stream(stream), x, ldx, y, ldy, B, H, W, C, H * scale, W * scale, out_nchw);

@@ -372,7 +372,8 @@ def test_depthwise(hip, C):
     close(dw, w.grad, what="dw wgrad")
 
 
-@pytest.mark.parametrize("shape", [(8, 64, 64, 256), (2, 32, 32, 256), (3, 16, 16, 256), (2, 16, 32, 64), (2, 48, 48, 32), (1, 64, 64, 512)])
+@pytest.mark.parametrize("shape", [(8, 64, 64, 256), (2, 32, 32, 256), (3, 16, 16, 256), (2, 16, 32, 64), (2, 48, 48, 32), (1, 64, 64, 512),
+                                   (2, 128, 128, 256), (1, 32, 128, 64), (1, 16, 256, 512)])      # rows wider than the workgroup's runs (1 024 px)
 def test_depthwise_wgrad_sliding_window(hip, shape):
     """The head's depthwise convs (decouplehead.py:23-34: 256 channels at 64 / 32 / 16 px) take the sliding-window weight-gradient
     kernel (four channels and a 16-pixel run per thread); against fp64 ATen, accumulate on and off, twice for bitwise equality."""
