@@ -27,7 +27,12 @@ struct ClusterArgs {
   // optional bf16-plane copies (csrc/pgemm.hip): forward `out`; backward [df | dv] as ONE tensor of 2 E D columns (df first)
   vrnet_planes_out outp, dfvp;
   int in_bf16;         // f, v (and, backward, g) are bf16 tensors (row strides in elements): compute_dtype "bf16" with bf16 tensors
+  // Streaming kernel (regions of more than 256 points), round 4: the forward may leave, per region-head, the centres, the
+  // aggregated values and the assignment counts (CL_STATE floats); given them and the forward's similarity map, the backward
+  // starts at its third pass: f is read twice instead of four times, v once instead of three times.
+  float* state; const float* wgt_fwd;
 };
+constexpr int CL_STATE = 264;      // [0,128) centres of f | [128,256) a_m = (sum w v + vc_m) / (cnt_m + 1) | [256,260) cnt_m
 __device__ __forceinline__ f32x4 cl_ld4(const float* base, long off, int bf16) {
   if (!bf16) return *reinterpret_cast<const f32x4*>(base + off);
   const vr_bf16x4 v = *reinterpret_cast<const vr_bf16x4*>(reinterpret_cast<const unsigned short*>(base) + off);
@@ -473,11 +478,25 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
     for (int q = 0; q < 4; ++q) o[q] = a[q];
   };
 
+  // backward with the forward's saved state: centres, aggregates and counts come from `state`, the weights from the forward's
+  // similarity map -- passes 1 and 2 shrink to one pass over g (da = sum w g); the values are the ones those passes would
+  // recompute, bit for bit (tests/test_hip_ops.py::test_cluster_core)
+  const bool saved = BWD && p.state != nullptr && p.wgt_fwd != nullptr;
+  if (saved) {
+    const float* stt = p.state + (long)blockIdx.x * CL_STATE;
+    for (int i = tid; i < 128; i += T) {
+      sm[SM_CEN + i] = stt[i];
+      sm[SM_AFIN + i] = stt[128 + i];
+      if (i < 4) sm[SM_MISC + i] = stt[256 + i];
+    }
+    __syncthreads();
+  }
   // ---- pass 1: centres of f and v
-  {
+  if (!saved) {
     float cs[16], vs[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) cs[i] = vs[i] = 0.f;
+#pragma unroll(BWD ? 1 : 4)      // forward: four points' loads in flight per lane group (1.50 -> 1.41 ms per step at 1 024 px); the backward spills with it
     for (int n0 = 0; n0 < N; n0 += PP) {
       long row; unsigned inq;
       const bool ok = locate(n0 + pip, row, inq);
@@ -535,11 +554,36 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
     return k;
   };
 
+  if (saved) {
+    float da[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) da[i] = 0.f;
+#pragma unroll 4
+    for (int n0 = 0; n0 < N; n0 += PP) {
+      long row; unsigned inq;
+      const bool ok = locate(n0 + pip, row, inq);
+      float g[4];
+      load4(p.g, p.ldg, row, ok, g);
+      const int k = ok ? (int)p.idx[row * p.E + e] : 0;
+      const float wg = ok ? p.wgt_fwd[row * p.E + e] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float wk = (ok && k == m) ? wg : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) da[m * 4 + q] += wk * g[q];
+      }
+    }
+    reduce_md(da, sm + SM_PART, sm + SM_T1, 1.f, tid, T);
+    for (int i = tid; i < 128; i += T) sm[SM_T1 + i] = sm[SM_T1 + i] / (sm[SM_MISC + (i >> 5)] + 1.f);
+    __syncthreads();
+  }
   // ---- pass 2: assignment, aggregate (and, backward, da = sum w g)
+  if (!saved) {
   {
     float ag[16], da[16], cnt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 16; ++i) ag[i] = da[i] = 0.f;
+#pragma unroll(BWD ? 1 : 4)      // forward: four points' loads in flight per lane group (1.50 -> 1.41 ms per step at 1 024 px); the backward spills with it
     for (int n0 = 0; n0 < N; n0 += PP) {
       long row; unsigned inq;
       const bool ok = locate(n0 + pip, row, inq);
@@ -568,11 +612,19 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
       const float den = sm[SM_MISC + (i >> 5)] + 1.f;
       sm[SM_AFIN + i] = (sm[SM_AGG + i] + sm[SM_VCEN + i]) / den;
       if (BWD) sm[SM_T1 + i] = sm[SM_T1 + i] / den;
+      if (!BWD && p.state) {
+        float* stt = p.state + (long)blockIdx.x * CL_STATE;
+        stt[i] = sm[SM_CEN + i];
+        stt[128 + i] = sm[SM_AFIN + i];
+        if (i < 4) stt[256 + i] = sm[SM_MISC + i];
+      }
     }
     __syncthreads();
   }
+  }
 
   if (!BWD) {   // ---- pass 3: dispatch
+#pragma unroll(BWD ? 1 : 4)      // forward: four points' loads in flight per lane group (1.50 -> 1.41 ms per step at 1 024 px); the backward spills with it
     for (int n0 = 0; n0 < N; n0 += PP) {
       long row; unsigned inq;
       const bool ok = locate(n0 + pip, row, inq);
@@ -595,6 +647,7 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
     float dch[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dch[i] = 0.f;
+#pragma unroll(BWD ? 1 : 4)      // forward: four points' loads in flight per lane group (1.50 -> 1.41 ms per step at 1 024 px); the backward spills with it
     for (int n0 = 0; n0 < N; n0 += PP) {
       long row; unsigned inq;
       const bool ok = locate(n0 + pip, row, inq);
@@ -657,6 +710,7 @@ __global__ __launch_bounds__(512) void cluster_stream_kernel(const ClusterArgs p
     for (int q = 0; q < 4; ++q) dcen[m][q] = clamped ? dh[q] * inv_cn[m] : (dh[q] - chat[m][q] * dot) * inv_cn[m];
   }
   // ---- backward pass 4: df
+#pragma unroll(BWD ? 1 : 4)
   for (int n0 = 0; n0 < N; n0 += PP) {
     long row; unsigned inq;
     const bool ok = locate(n0 + pip, row, inq);
@@ -786,7 +840,7 @@ int cluster_check(const char* name, const void* f, const void* v, long ld, int B
 
 static int cluster_fwd_impl(const float* f, const float* v, long ld, const float* alpha, const float* beta, float* out, long ldo,
                             unsigned char* idx, float* wgt, int B, int H, int W, int E, int D, int fold, const float* alpha2,
-                            const float* beta2, int forced, const vrnet_planes_out* outp, void* stream);
+                            const float* beta2, int forced, const vrnet_planes_out* outp, void* stream, float* state = nullptr);
 
 extern "C" int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                                      float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E,
@@ -798,9 +852,18 @@ extern "C" int vrnet_cluster_fwd_f32(const float* f, const float* v, long ld, co
 extern "C" int vrnet_cluster_fwd_planes_f32(const void* f, const void* v, long ld, int in_bf16, const float* alpha,
                                             const float* beta, float* out, long ldo, unsigned char* idx, float* wgt, int B,
                                             int H, int W, int E, int D, int fold, int forced, const vrnet_planes_out* outp,
-                                            void* stream) {
+                                            float* state, void* stream) {
   return cluster_fwd_impl(reinterpret_cast<const float*>(f), reinterpret_cast<const float*>(v), ld, alpha, beta, out, ldo, idx, wgt,
-                          B, H, W, E, D, fold, nullptr, nullptr, (forced ? 1 : 0) | (in_bf16 ? 2 : 0), outp, stream);
+                          B, H, W, E, D, fold, nullptr, nullptr, (forced ? 1 : 0) | (in_bf16 ? 2 : 0), outp, stream, state);
+}
+
+/* Floats of per-region state the forward of vrnet_cluster_fwd_planes_f32 leaves in `state` for regions of more than 256
+ * points (0: the region kernel keeps its points in registers and has no use for it). */
+extern "C" long vrnet_cluster_state_floats(int B, int H, int W, int E, int fold) {
+  if (B <= 0 || E <= 0 || fold <= 0 || H % fold || W % fold) return 0;
+  int T, npt;
+  if (cluster_plan((H / fold) * (W / fold), (long)B * E * fold * fold, &T, &npt, 1) != 0 || T != 0) return 0;
+  return (long)B * E * fold * fold * CL_STATE;
 }
 
 /* The same forward with the hard assignment GIVEN (idx is read, not written): every point goes to the centre idx names,
@@ -815,7 +878,7 @@ extern "C" int vrnet_cluster_fwd_forced_f32(const float* f, const float* v, long
 
 static int cluster_fwd_impl(const float* f, const float* v, long ld, const float* alpha, const float* beta, float* out, long ldo,
                             unsigned char* idx, float* wgt, int B, int H, int W, int E, int D, int fold, const float* alpha2,
-                            const float* beta2, int forced, const vrnet_planes_out* outp, void* stream) {
+                            const float* beta2, int forced, const vrnet_planes_out* outp, void* stream, float* state) {
   if (vr_ablated("cluster")) return VR_OK;
   int T, npt;
   int rc = cluster_check("cluster_fwd", f, v, ld, B, H, W, E, D, fold, &T, &npt, 0);
@@ -831,6 +894,7 @@ static int cluster_fwd_impl(const float* f, const float* v, long ld, const float
   p.forced = forced & 1;
   p.in_bf16 = (forced >> 1) & 1;
   if (outp) p.outp = *outp;
+  p.state = T == 0 ? state : nullptr;
   cluster_launch<false>(p, T, npt, (long)B * E * fold * fold, vr_stream(stream));
   VR_LAUNCH_CHECK("cluster_fwd");
   return VR_OK;
@@ -846,7 +910,8 @@ static int cluster_bwd_impl(const float* f, const float* v, long ld, const float
                             const unsigned char* idx, const float* dout, long lddo, float* df, float* dv,
                             long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
                             int E, int D, int fold, const float* alpha2, const float* beta2, float* dalpha2,
-                            float* dbeta2, const vrnet_planes_out* dfvp, void* workspace, long workspace_bytes, void* stream);
+                            float* dbeta2, const vrnet_planes_out* dfvp, void* workspace, long workspace_bytes, void* stream,
+                            const float* wgt_fwd = nullptr, const float* state = nullptr);
 extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                                      const unsigned char* idx, const float* dout, long lddo, float* df, float* dv,
                                      long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
@@ -860,17 +925,19 @@ extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, co
 extern "C" int vrnet_cluster_bwd_planes_f32(const void* f, const void* v, long ld, int in_bf16, const float* alpha,
                                             const float* beta, const unsigned char* idx, const void* dout, long lddo, float* df,
                                             float* dv, long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H,
-                                            int W, int E, int D, int fold, const vrnet_planes_out* dfvp, void* workspace,
-                                            long workspace_bytes, void* stream) {
+                                            int W, int E, int D, int fold, const vrnet_planes_out* dfvp, const float* wgt_fwd,
+                                            const float* state, void* workspace, long workspace_bytes, void* stream) {
+  VR_CHECK_ARG(!wgt_fwd == !state, "cluster_bwd: the forward's similarity map and region state come together");
   return cluster_bwd_impl(reinterpret_cast<const float*>(f), reinterpret_cast<const float*>(v), ld, alpha, beta, idx,
                           reinterpret_cast<const float*>(dout), lddo, df, dv, lddf, dalpha, dbeta, (accumulate_ab ? 1 : 0) | (in_bf16 ? 2 : 0),
-                          B, H, W, E, D, fold, nullptr, nullptr, nullptr, nullptr, dfvp, workspace, workspace_bytes, stream);
+                          B, H, W, E, D, fold, nullptr, nullptr, nullptr, nullptr, dfvp, workspace, workspace_bytes, stream, wgt_fwd, state);
 }
 static int cluster_bwd_impl(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                             const unsigned char* idx, const float* dout, long lddo, float* df, float* dv,
                             long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
                             int E, int D, int fold, const float* alpha2, const float* beta2, float* dalpha2,
-                            float* dbeta2, const vrnet_planes_out* dfvp, void* workspace, long workspace_bytes, void* stream) {
+                            float* dbeta2, const vrnet_planes_out* dfvp, void* workspace, long workspace_bytes, void* stream,
+                            const float* wgt_fwd, const float* state) {
   if (vr_ablated("cluster")) return VR_OK;
   const int in_bf16 = (accumulate_ab >> 1) & 1;      // (bit 1: set by vrnet_cluster_bwd_planes_f32 only)
   accumulate_ab &= 1;
@@ -898,6 +965,7 @@ static int cluster_bwd_impl(const float* f, const float* v, long ld, const float
   if (dfvp) p.dfvp = *dfvp;
   p.ab_partial = reinterpret_cast<float*>(workspace);
   p.wgt = p.ab_partial + ((blocks * 2 + 63) / 64) * 64;       // streaming kernel: per-point d cos scratch
+  if (T == 0 && wgt_fwd && state) { p.wgt_fwd = wgt_fwd; p.state = const_cast<float*>(state); }
   p.B = B; p.H = H; p.W = W; p.E = E; p.D = D; p.fold = fold;
   hipStream_t st = vr_stream(stream);
   cluster_launch<true>(p, T, npt, blocks, st);

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VRNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libvrnet_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -61,8 +61,9 @@ _SIGS = {
     "vrnet_gn_apply_fwd": ([P, L, P, L, P, P, F, I, L, I, P, L, P, P], I),
     "vrnet_gn_apply_fwd_planes": ([P, L, P, L, P, P, F, I, L, I, P, L, P, P, P], I),
     "vrnet_gn_apply_bwd_planes": ([P, L, P, L, P, P, I, L, I, P, L, P, L, P, P, I, P, P, L, P], I),
-    "vrnet_cluster_fwd_planes_f32": ([P, P, L, I, P, P, P, L, P, P, I, I, I, I, I, I, I, P, P], I),
-    "vrnet_cluster_bwd_planes_f32": ([P, P, L, I, P, P, P, P, L, P, P, L, P, P, I, I, I, I, I, I, I, P, P, L, P], I),
+    "vrnet_cluster_fwd_planes_f32": ([P, P, L, I, P, P, P, L, P, P, I, I, I, I, I, I, I, P, P, P], I),
+    "vrnet_cluster_state_floats": ([I, I, I, I, I], L),
+    "vrnet_cluster_bwd_planes_f32": ([P, P, L, I, P, P, P, P, L, P, P, L, P, P, I, I, I, I, I, I, I, P, P, P, P, L, P], I),
     "vrnet_gn_bwd_workspace": ([I, L, I], L),
     "vrnet_gn_apply_bwd_from_partials": ([P, L, P, L, P, P, P, P, I, L, I, P, L, P, L, P, P, I, P], I),
     "vrnet_bn_coef_fwd_from_partials": ([P, P, P, F, F, P, P, P, I, L, I, P, P, P, P, P], I),
@@ -575,16 +576,22 @@ def fill_(dst, value):
     _check(_lib.vrnet_fill_f32(ptr(dst), float(value), dst.numel(), stream()), "fill")
 
 
+def cluster_state_floats(B, H, W, E, fold):
+    """Floats of per-region forward state for regions of more than 256 points (0: none needed)."""
+    return _lib.vrnet_cluster_state_floats(B, H, W, E, fold)
+
+
 def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold, alpha2=None, beta2=None, forced=False,
-                planes=None):
+                planes=None, state=None):
     """forced: idx is given (read), not computed (teacher-forced assignment for parity comparisons).
     planes (Planes): `out` as bf16 planes, beside the fp32 `out` or instead of it (out None); single-stream launches.
-    f / v may then be bfloat16 tensors (ld in elements)."""
-    if planes is not None or f.dtype == torch.bfloat16:
+    f / v may then be bfloat16 tensors (ld in elements).  state (cluster_state_floats floats): the forward's per-region state
+    for cluster_bwd(saved=(wgt, state))."""
+    if planes is not None or f.dtype == torch.bfloat16 or state is not None:
         assert alpha2 is None and f.dtype == v.dtype
         _check(_lib.vrnet_cluster_fwd_planes_f32(ptr(f), ptr(v), ld, 1 if f.dtype == torch.bfloat16 else 0, ptr(alpha), ptr(beta),
                                                  ptr(out), ldo, ptr(idx), ptr(wgt), B, H, W, E, Dh, fold, 1 if forced else 0,
-                                                 _planes_out(planes), stream()), "cluster_fwd_planes")
+                                                 _planes_out(planes), ptr(state), stream()), "cluster_fwd_planes")
         return
     fn = _lib.vrnet_cluster_fwd_forced_f32 if forced else _lib.vrnet_cluster_fwd_f32
     _check(fn(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(out), ldo, ptr(idx), ptr(wgt), B, H,
@@ -592,15 +599,17 @@ def cluster_fwd(f, v, ld, alpha, beta, out, ldo, idx, wgt, B, H, W, E, Dh, fold,
 
 
 def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, dbeta, accumulate_ab, B, H, W, E, Dh,
-                fold, alpha2=None, beta2=None, dalpha2=None, dbeta2=None, planes=None):
-    """planes (Planes of 2 E Dh columns): a second copy of [df | dv] as bf16 planes (single-stream launches)."""
+                fold, alpha2=None, beta2=None, dalpha2=None, dbeta2=None, planes=None, saved=None):
+    """planes (Planes of 2 E Dh columns): a second copy of [df | dv] as bf16 planes (single-stream launches).
+    saved = (wgt, state) of the forward (regions of more than 256 points): the backward skips its first two passes."""
     ws = _ws.get(_lib.vrnet_cluster_bwd_workspace2(B, H, W, E, fold), f.device)
-    if planes is not None or f.dtype == torch.bfloat16:
+    if planes is not None or f.dtype == torch.bfloat16 or saved is not None:
         assert alpha2 is None and f.dtype == v.dtype == dout.dtype
+        wf, st = saved if saved is not None else (None, None)
         _check(_lib.vrnet_cluster_bwd_planes_f32(ptr(f), ptr(v), ld, 1 if f.dtype == torch.bfloat16 else 0, ptr(alpha), ptr(beta),
                                                  ptr(idx), ptr(dout), lddo, ptr(df), ptr(dv), lddf, ptr(dalpha), ptr(dbeta),
-                                                 accumulate_ab, B, H, W, E, Dh, fold, _planes_out(planes), ptr(ws), ws.numel(),
-                                                 stream()), "cluster_bwd_planes")
+                                                 accumulate_ab, B, H, W, E, Dh, fold, _planes_out(planes), ptr(wf), ptr(st),
+                                                 ptr(ws), ws.numel(), stream()), "cluster_bwd_planes")
         return
     _check(_lib.vrnet_cluster_bwd_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(idx), ptr(dout), lddo, ptr(df),
                                       ptr(dv), lddf, ptr(dalpha), ptr(dbeta), accumulate_ab, B, H, W, E, Dh, fold,

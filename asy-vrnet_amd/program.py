@@ -821,8 +821,14 @@ def cluster_block(rt, x, m, name=None):
     if rt.forced_idx is not None and not paired and name is not None and name in rt.forced_idx:
         idx.copy_(rt.forced_idx[name])                          # teacher-forced assignment (model.forced_idx_maps: parity tests)
         kwc["forced"] = True
-    hip.cluster_fwd(f_t, v_t, 2 * ED, tm0.sim_alpha, tm0.sim_beta, o.t, ED, idx, rt.buf(B, H, W, E) if big else None,
-                    B, H, W, E, Dh, fold, **kwc)
+    # regions of more than 256 points (streaming kernel): the forward keeps its similarity map and per-region state, the
+    # backward then skips the two passes that would recompute them
+    wgt = rt.buf(B, H, W, E) if big else None
+    nst = hip.cluster_state_floats(B, H, W, E, fold) if (big and not paired and rt.record) else 0
+    cstate = rt.buf(nst) if nst else None
+    if cstate is not None:
+        kwc["state"] = cstate
+    hip.cluster_fwd(f_t, v_t, 2 * ED, tm0.sim_alpha, tm0.sim_beta, o.t, ED, idx, wgt, B, H, W, E, Dh, fold, **kwc)
     if name is not None:
         n0, n1 = _pair(name)
         if paired:
@@ -884,6 +890,8 @@ def cluster_block(rt, x, m, name=None):
             (ga2, gb2), acca2 = _pgrads_or_scratch(rt, (tm1.sim_alpha, tm1.sim_beta), (1, 1))
             assert acca2 == acca
             kwb = dict(alpha2=tm1.sim_alpha, beta2=tm1.sim_beta, dalpha2=ga2, dbeta2=gb2)
+        if cstate is not None:
+            kwb["saved"] = (wgt, cstate)
         hip.cluster_bwd(f_t, v_t, 2 * ED, tm0.sim_alpha, tm0.sim_beta, idx, do.t, ED, dfv.t, dfv.t[..., ED:], 2 * ED, ga, gb,
                         acca, B, H, W, E, Dh, fold, **kwb)
         if rt.on_param_grad:
@@ -980,8 +988,11 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
     forced = rt.forced_idx is not None and name is not None and name in rt.forced_idx
     if forced:
         idx.copy_(rt.forced_idx[name])
-    hip.cluster_fwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, None if o is None else o.t, ED, idx,
-                    rt.buf(B, H, W, E) if big else None, B, H, W, E, Dh, fold, forced=forced, planes=o_p)
+    wgt = rt.buf(B, H, W, E) if big else None
+    nst = hip.cluster_state_floats(B, H, W, E, fold) if (big and rec) else 0
+    cstate = rt.buf(nst) if nst else None
+    hip.cluster_fwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, None if o is None else o.t, ED, idx, wgt, B, H, W, E, Dh, fold,
+                    forced=forced, planes=o_p, state=cstate)
     if name is not None:
         rt.idx_maps[name] = idx
     x1 = f32(C)
@@ -1148,7 +1159,8 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
         dfv = f32(2 * ED) if (not fcfv[1] or not fcfv[2]) else None
         (ga, gb_), acca = _pgrads_or_scratch(rt, (tm.sim_alpha, tm.sim_beta), (1, 1))
         hip.cluster_bwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, idx, do_t, ED, None if dfv is None else dfv.t,
-                        None if dfv is None else dfv.t[..., ED:], 2 * ED, ga, gb_, acca, B, H, W, E, Dh, fold, planes=dfv_p)
+                        None if dfv is None else dfv.t[..., ED:], 2 * ED, ga, gb_, acca, B, H, W, E, Dh, fold, planes=dfv_p,
+                        saved=None if cstate is None else (wgt, cstate))
         if rt.on_param_grad:
             rt.on_param_grad(tm.sim_alpha)
             rt.on_param_grad(tm.sim_beta)

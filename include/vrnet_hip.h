@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------- */
-int vrnet_abi_version(void);                 /* == 7 */
+int vrnet_abi_version(void);                 /* == 8 */
 /* Kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to: 1 fp32 MFMA
  * (register-staged), 2 fp32 MFMA (LDS-DMA ring), 3 bf16-rounded operands, 4 direct kernels for tiny channel counts,
  * 5 direct HBM-streaming kernels for 1x1 convs with <= 16 output channels over wide inputs (head predictions, seg logits),
@@ -171,13 +171,20 @@ int vrnet_gn_apply_bwd_planes(const float* dy, long lddy, const float* x, long l
                               int B, long HW, int C, const float* add, long ldadd, float* out, long ldo, float* dgamma,
                               float* dbeta, int accumulate_params, const vrnet_planes_out* outp, void* workspace,
                               long workspace_bytes, void* stream);
+/* Regions of more than 256 points (every backbone stage at 1 024 px, neck p3 at 512 px) run on a kernel that streams the
+ * points in chunks; its backward re-read f four times and v three times.  `state` (vrnet_cluster_state_floats(...) floats, 0 for
+ * the register-resident region sizes; NULL = not wanted): the forward leaves the region centres, aggregated values and
+ * assignment counts there; the backward, given that state and the forward's similarity map `wgt_fwd` (both or neither), starts
+ * at its third pass -- f twice, v once, the same bits (outp / dfvp may be NULL in both: no plane copies). */
+long vrnet_cluster_state_floats(int B, int H, int W, int E, int fold);
 int vrnet_cluster_fwd_planes_f32(const void* f, const void* v, long ld, int in_bf16, const float* alpha, const float* beta,
                                  float* out, long ldo, unsigned char* idx, float* wgt, int B, int H, int W, int E, int D,
-                                 int fold, int forced, const vrnet_planes_out* outp, void* stream);
+                                 int fold, int forced, const vrnet_planes_out* outp, float* state, void* stream);
 int vrnet_cluster_bwd_planes_f32(const void* f, const void* v, long ld, int in_bf16, const float* alpha, const float* beta,
                                  const unsigned char* idx, const void* dout, long lddo, float* df, float* dv, long lddf,
                                  float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W, int E, int D, int fold,
-                                 const vrnet_planes_out* dfvp, void* workspace, long workspace_bytes, void* stream);
+                                 const vrnet_planes_out* dfvp, const float* wgt_fwd, const float* state, void* workspace,
+                                 long workspace_bytes, void* stream);
 int vrnet_wgrad_planes_ok(long M, int Cin, int Cout);
 long vrnet_wgrad_planes_workspace(long M, int Cin, int Cout);
 int vrnet_wgrad_planes_f32(const void* x, long ldx, long x_plane, const void* dy, long lddy, long dy_plane, int np, long M, int Cin,

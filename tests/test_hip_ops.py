@@ -329,6 +329,23 @@ def test_cluster_core(hip, case):
     out2 = torch.empty_like(out)
     hip.cluster_fwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), out2, E * D, idx, wgt, B, H, W, E, D, fold)
     assert torch.equal(out, out2)
+    # round 4: regions of more than 256 points -- the forward leaves its per-region state, the backward starts from it (two
+    # passes fewer): every output bit for bit what the four-pass backward gives
+    nst = hip.cluster_state_floats(B, H, W, E, fold)
+    assert (nst > 0) == ((H // fold) * (W // fold) > 256)
+    if nst:
+        state = torch.full((nst,), float("nan"), device="cuda")
+        idx_s, wgt_s, out_s = torch.empty_like(idx), torch.empty_like(wgt), torch.empty_like(out)
+        hip.cluster_fwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), out_s, E * D, idx_s, wgt_s, B, H, W, E, D, fold,
+                        state=state)
+        assert torch.equal(out_s, out) and torch.equal(idx_s, idx) and not bool(torch.isnan(state.view(-1, 264)[:, :260]).any())
+        df_s, dv_s, dab_s = torch.empty_like(df), torch.empty_like(dv), torch.zeros(2, device="cuda")
+        hip.cluster_bwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), idx_s, nhwc(g), E * D, df_s, dv_s, E * D,
+                        dab_s[0:1], dab_s[1:2], 0, B, H, W, E, D, fold, saved=(wgt_s, state))
+        assert torch.equal(df_s, df) and torch.equal(dv_s, dv) and torch.equal(dab_s, dab)
+        with pytest.raises(RuntimeError, match="come together"):
+            hip.cluster_bwd(fg, vg, E * D, alpha.detach().cuda(), beta.detach().cuda(), idx_s, nhwc(g), E * D, df_s, dv_s, E * D,
+                            dab_s[0:1], dab_s[1:2], 0, B, H, W, E, D, fold, saved=(wgt_s, None))
     # teacher-forced forward (vrnet_cluster_fwd_forced_f32): its own assignment gives the same output; a different one (every
     # point to the next centre) gives what the oracle computes for that assignment
     out3 = torch.empty_like(out)

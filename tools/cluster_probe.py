@@ -36,7 +36,15 @@ for B, H, W, E, D, fold, cnt in (SHAPES_1024 if "1024" in sys.argv[1:] else SHAP
     fw = timeit(lambda: hip.cluster_fwd(f, v, C, al, be, out, C, idx, wgt, B, H, W, E, D, fold))
     bw = timeit(lambda: hip.cluster_bwd(f, v, C, al, be, idx, g, C, df, dv, C, dab[0:1], dab[1:2], 0, B, H, W, E, D, fold))
     byt = B * H * W * C * 4
-    print(f"{H}x{W} E{E} D{D} fold{fold} x{cnt}: fwd {fw:7.1f} us {3 * byt / fw * 1e-6:6.2f} TB/s   bwd (+ab reduce) {bw:7.1f} us {5 * byt / bw * 1e-6:6.2f} TB/s", flush=True)
+    extra = ""
+    nst = hip.cluster_state_floats(B, H, W, E, fold)
+    if nst:      # regions of more than 256 points: the backward from the forward's saved state (what the step program runs)
+        st = torch.empty(nst, device="cuda")
+        hip.cluster_fwd(f, v, C, al, be, out, C, idx, wgt, B, H, W, E, D, fold, state=st)
+        bw4, bw = bw, timeit(lambda: hip.cluster_bwd(f, v, C, al, be, idx, g, C, df, dv, C, dab[0:1], dab[1:2], 0, B, H, W, E, D, fold,
+                                                     saved=(wgt, st)))
+        extra = f"   (four-pass backward {bw4:7.1f} us)"
+    print(f"{H}x{W} E{E} D{D} fold{fold} x{cnt}: fwd {fw:7.1f} us {3 * byt / fw * 1e-6:6.2f} TB/s   bwd (+ab reduce) {bw:7.1f} us {5 * byt / bw * 1e-6:6.2f} TB/s{extra}", flush=True)
     tf += cnt * fw
     tb += cnt * bw
 print(f"per step: forward {tf * 1e-3:.3f} ms, backward {tb * 1e-3:.3f} ms")
