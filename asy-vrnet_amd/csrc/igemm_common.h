@@ -54,6 +54,10 @@ struct IgemmArgs {
   // [accumulators of the wave][64 lanes][16] floats); igemm_splitk_finish_kernel adds the slabs in order (deterministic) and
   // runs the epilogue.  For the small-M layers (16 x 16 maps: 2048 rows) whose tile grid leaves most CUs empty.
   int ksplit; float* kslab;
+  // bf16 side tensors of the plane GEMMs on bf16 tensors (pgemm.hip, compute_dtype "bf16"): the pre-activation copy `ypre` is
+  // STORED as bf16 and / or the GELU' argument `aux` is READ as bf16 (row strides in elements) -- the Mlp's u of the blocks whose
+  // fc1 / fc2 are two launches, as the fused Mlp kernels keep it at precision 4
+  int ypre_bf16, aux_bf16;
 };
 
 // The argument block a workgroup whose first row is m0 works with: the second stream's parameters behind pair_rows.
@@ -128,11 +132,20 @@ __device__ __forceinline__ void igemm_epilogue_tile(const IgemmArgs& p, const f3
       f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * STAGE_LD + c4]);
       if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
       if (p.aux) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + mo * p.ldaux + n);
+        f32x4 a;
+        if (p.aux_bf16) {
+          const vr_bf16x4 h = *reinterpret_cast<const vr_bf16x4*>(reinterpret_cast<const unsigned short*>(p.aux) + mo * p.ldaux + n);
+          a = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        } else {
+          a = *reinterpret_cast<const f32x4*>(p.aux + mo * p.ldaux + n);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= vr_gelu_grad(a[e]);
       }
-      if (p.ypre) *reinterpret_cast<f32x4*>(p.ypre + mo * p.ldypre + n) = v;
+      if (p.ypre) {
+        if (p.ypre_bf16) vr_store_planes4(reinterpret_cast<unsigned short*>(p.ypre) + mo * p.ldypre + n, 0, 1, v);
+        else *reinterpret_cast<f32x4*>(p.ypre + mo * p.ldypre + n) = v;
+      }
       if (p.act == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);

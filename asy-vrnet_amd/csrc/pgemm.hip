@@ -591,13 +591,14 @@ extern "C" int vrnet_gemm_planes_ok(long rows, int cols, int K) {
  * (header of this file).  np = 3: fp32 values as three planes each, six products; np = 1: bf16 tensors.  The epilogue is
  * vrnet_conv2d_f32's: bias, aux (x gelu'), ypre, act (0 none, 1 ReLU, 2 GELU), res (+ res_scale), accumulate, stats (fp64
  * (sum, sumsq) pairs per 32 x 32 tile), colstats; the result goes to `y` (fp32, may be null) and / or to `yp` as planes
- * (yp_np = 3: exact split, the next GEMM's operand; 1: bf16).  Replaces, for operands in plane form, the 1x1 launches of
+ * (yp_np = 3: exact split, the next GEMM's operand; 1: bf16).  half_side bit 0: `ypre` is a bf16 tensor (stored rounded), bit 1:
+ * `aux` is a bf16 tensor (row strides in elements) -- the Mlp's pre-activation u in bf16 mode.  Replaces, for operands in plane form, the 1x1 launches of
  * vrnet_conv2d_f32 (backbone/fusion/vr_coc.py:145-147, 187, 205-207 and their autograd). */
 extern "C" int vrnet_gemm_planes_f32(const void* a, long lda, long a_plane, const void* b, long ldb, long b_plane, int np,
                                      long M, int N, int K, const float* bias, float* y, long ldy, void* yp, long ldyp,
                                      long yp_plane, int yp_np, int act, float* ypre, long ldypre, const float* res, long ldres,
                                      const float* res_scale, const float* aux, long ldaux, int accumulate, double* stats,
-                                     long stats_hw, const vrnet_conv_colstats* colstats, void* stream) {
+                                     long stats_hw, const vrnet_conv_colstats* colstats, int half_side, void* stream) {
   VR_CHECK_ARG(a && b && (y || yp), "gemm_planes: null tensor");
   VR_CHECK_ARG(np == 1 || np == 3, "gemm_planes: np = 3 (fp32 as three bf16 planes) or 1 (bf16)");
   VR_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && K >= PG_BK && K % PG_BK == 0, "gemm_planes: bad shape (K %% 32 == 0)");
@@ -618,6 +619,7 @@ extern "C" int vrnet_gemm_planes_f32(const void* a, long lda, long a_plane, cons
   IgemmArgs p{};
   p.bias = bias; p.y = y; p.ldy = ldy; p.ypre = ypre; p.ldypre = ldypre; p.res = res; p.ldres = ldres; p.res_scale = res_scale;
   p.aux = aux; p.ldaux = ldaux; p.act = act; p.accumulate = accumulate; p.M = (int)M; p.CN = N; p.CK = K; p.e_vec = 1;
+  p.ypre_bf16 = half_side & 1; p.aux_bf16 = (half_side >> 1) & 1;      // (8-byte rows suffice for those: checked as 16-byte above)
   p.MH = 1; p.MW = (int)M; p.stats = stats; p.stats_nb = (int)vr_cdiv(N, 32);
   p.yp = reinterpret_cast<unsigned short*>(yp); p.ldyp = ldyp; p.yp_plane = yp_plane; p.yp_np = yp_np;
   if (colstats) {

@@ -35,7 +35,7 @@ _SIGS = {
     "vrnet_conv_planes_pack_f32": ([P, I, L, P], I),
     "vrnet_pack_weight_t_f32": ([P, P, P, I, I, I, I, P], I),
     "vrnet_gemm_planes_ok": ([L, I, I], I),
-    "vrnet_gemm_planes_f32": ([P, L, L, P, L, L, I, L, I, I, P, P, L, P, L, L, I, I, P, L, P, L, P, P, L, I, P, L, P, P], I),
+    "vrnet_gemm_planes_f32": ([P, L, L, P, L, L, I, L, I, I, P, P, L, P, L, L, I, I, P, L, P, L, P, P, L, I, P, L, P, I, P], I),
     "vrnet_planes_split_blocks": ([L, L], L),
     "vrnet_planes_split_f32": ([P, I, L, I, P], I),
     "vrnet_planes_from_f32": ([P, L, L, L, P, L, L, I, P], I),
@@ -275,8 +275,11 @@ def gemm_planes_ok(rows, cols, K):
 
 def gemm_planes(a, b, M, N, K, bias=None, y=None, ldy=0, yp=None, act=0, ypre=None, ldypre=0, res=None, ldres=0,
                 res_scale=None, aux=None, ldaux=0, accumulate=0, stats=None, stats_hw=0, colstats=None):
-    """y / yp = epilogue(A . B^T) on plane operands a, b (Planes, same np); y: fp32 tensor or None, yp: Planes or None."""
+    """y / yp = epilogue(A . B^T) on plane operands a, b (Planes, same np); y: fp32 tensor or None, yp: Planes or None.
+    ypre / aux may be bfloat16 tensors (the Mlp's pre-activation in bf16 mode; strides in elements)."""
     assert a.np == b.np
+    half_side = (1 if (ypre is not None and ypre.dtype == torch.bfloat16) else 0) | \
+        (2 if (aux is not None and aux.dtype == torch.bfloat16) else 0)
     cs = None
     if colstats is not None:
         part, x2, ldx2, gam, tot = colstats
@@ -285,7 +288,7 @@ def gemm_planes(a, b, M, N, K, bias=None, y=None, ldy=0, yp=None, act=0, ypre=No
                                       None if yp is None else ptr(yp.t), 0 if yp is None else yp.ld,
                                       0 if yp is None else yp.plane, 0 if yp is None else yp.np, act, ptr(ypre), ldypre,
                                       ptr(res), ldres, ptr(res_scale), ptr(aux), ldaux, accumulate, ptr(stats), stats_hw, cs,
-                                      stream()), "gemm_planes")
+                                      half_side, stream()), "gemm_planes")
 
 
 def planes_split_blocks(R, K):

@@ -1010,7 +1010,17 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
     # them as they are (hip.wgrad_planes, np = 1)
     mlp_hb = bool(pmlp) and np_ == 1 and rt.pg_wgrad and hip.wgrad_planes_ok(M, hid, C) and hip.wgrad_planes_ok(M, C, hid)
     u_b = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=x.t.device) if (mlp_hb and rec) else None
-    u = (f32(hid, False) if not mlp_hb else True) if rec else None
+    # two-launch Mlp on bf16 tensors with fc1 forward and fc2 data gradient both on plane GEMMs: u (the GELU' argument) as a
+    # bf16 tensor too, as the fused kernels keep it at precision 4
+    u_half = np_ == 1 and not pmlp and fc1[0] and fc2[1]
+    if not rec:
+        u = None
+    elif mlp_hb:
+        u = True
+    elif u_half:
+        u = Act(torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=x.t.device), False)
+    else:
+        u = f32(hid, False)
     x2 = f32(C)
     xn2_p = P(C) if (fc1[0] or (rec and (fc1[2] or mlp_hb))) else None
     xn2_f = f32(C) if (pmlp or not fc1[0] or (rec and not fc1[2])) else None

@@ -128,13 +128,15 @@ int vrnet_conv_planes_pack_f32(const long* table, int nentries, long total_block
  * A = dy, B = transposed weights with the layer scale folded in.  Epilogue as vrnet_conv2d_f32: bias, aux (x gelu'(aux)),
  * ypre, act (0 / 1 ReLU / 2 GELU), res (+ res_scale), accumulate, stats (fp64 (sum, sumsq) per 32 x 32 tile; stats_hw = rows
  * per sample), colstats.  The result goes to `y` (fp32; may be NULL) and / or to `yp` as planes (yp_np 3 or 1).
- * K % 32 == 0, N % 4 == 0; ask vrnet_gemm_planes_ok for shapes with too few 128 x 128 tiles.  Kernel families 10 (np 3), 11 (np 1). */
+ * K % 32 == 0, N % 4 == 0; ask vrnet_gemm_planes_ok for shapes with too few 128 x 128 tiles.  half_side: bit 0 = `ypre` is a bf16
+ * tensor (stored rounded), bit 1 = `aux` is a bf16 tensor (row strides in elements): the Mlp's pre-activation u in bf16 mode.
+ * Kernel families 10 (np 3), 11 (np 1). */
 int vrnet_gemm_planes_ok(long rows, int cols, int K);
 int vrnet_gemm_planes_f32(const void* a, long lda, long a_plane, const void* b, long ldb, long b_plane, int np, long M, int N,
                           int K, const float* bias, float* y, long ldy, void* yp, long ldyp, long yp_plane, int yp_np, int act,
                           float* ypre, long ldypre, const float* res, long ldres, const float* res_scale, const float* aux,
                           long ldaux, int accumulate, double* stats, long stats_hw, const vrnet_conv_colstats* colstats,
-                          void* stream);
+                          int half_side, void* stream);
 /* fp32 matrices -> planes in one launch for a table of matrices (the weights of a step).  Entry (10 longs): source address,
  * rows R, contraction K, source element strides (row, k), address of a scale per k or 0 (the layer scale of a data-gradient
  * pack), destination address, destination row stride, destination plane stride, first block (running sum of

@@ -123,6 +123,10 @@ def test_gemm_planes_against_fp64(hip, case):
         h1 = hip.Planes.empty(1, (M, N), "cuda")
         hip.gemm_planes(A, Bp, M, N, K, bias=bias, yp=h1, act=2)
         assert torch.equal(h1.t[0], y.to(torch.bfloat16)), "np = 1 output: the value rounded to bf16"
+        # bf16 pre-activation copy (the Mlp's u in bf16 mode): the fp32 value rounded once, everything else unchanged
+        ub, y2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), torch.empty_like(y)
+        hip.gemm_planes(A, Bp, M, N, K, bias=bias, y=y2, ldy=N, act=2, ypre=ub, ldypre=N)
+        assert torch.equal(ub, ypre.to(torch.bfloat16)) and torch.equal(y2, y)
     elif ep == "dgrad":
         hip.gemm_planes(A, Bp, M, N, K, y=y, ldy=N)
         close(y, z, 2e-5, what="dx")
@@ -132,6 +136,12 @@ def test_gemm_planes_against_fp64(hip, case):
         u = D(aux)
         gp = 0.5 * (1 + torch.erf(u / np.sqrt(2.0))) + u * torch.exp(-0.5 * u * u) / np.sqrt(2 * np.pi)
         close(dup.float(), z * gp, 2e-5, what="du")
+        # bf16 GELU' argument: the same as the fp32 copy of those bf16 values, bit for bit
+        ab = aux.to(torch.bfloat16)
+        d1, d2 = hip.Planes.empty(3, (M, N), "cuda"), hip.Planes.empty(3, (M, N), "cuda")
+        hip.gemm_planes(A, Bp, M, N, K, yp=d1, aux=ab, ldaux=N)
+        hip.gemm_planes(A, Bp, M, N, K, yp=d2, aux=ab.float(), ldaux=N)
+        assert torch.equal(d1.t, d2.t)
     assert hip.last_kernel() in (10, 11)
 
 
