@@ -917,7 +917,8 @@ extern "C" int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, co
                                      long lddf, float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W,
                                      int E, int D, int fold, const float* alpha2, const float* beta2, float* dalpha2,
                                      float* dbeta2, void* workspace, long workspace_bytes, void* stream) {
-  return cluster_bwd_impl(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, dbeta, accumulate_ab, B, H, W, E, D, fold,
+  // (any non-zero accumulate_ab means "accumulate", as in ABI 5: bit 1 of the internal flag word is the bf16-input switch)
+  return cluster_bwd_impl(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, dbeta, accumulate_ab ? 1 : 0, B, H, W, E, D, fold,
                           alpha2, beta2, dalpha2, dbeta2, nullptr, workspace, workspace_bytes, stream);
 }
 /* The same with a second copy of [df | dv] (one tensor of 2 E D columns, df first) as bf16 planes: the dy operand of the

@@ -549,7 +549,9 @@ __device__ __forceinline__ void planes_split_block(const float* src, long R, lon
   unsigned short* d = dst + r * ld + k0;
   const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
   vr_store_planes4(d, plane, np, a);
-  vr_store_planes4(d + 4, plane, np, b);
+  // K % 8 == 4: the thread at k0 = K - 4 owns only four columns -- a second store would land in the next row's first four
+  // (racing with that row's own writer) or, on the last row, past the plane
+  if (k0 + 4 < K) vr_store_planes4(d + 4, plane, np, b);
 }
 
 // Multi-tensor form: one launch for every weight of a step.  Table entry e (10 longs): source address, rows R, contraction

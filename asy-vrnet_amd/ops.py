@@ -572,7 +572,9 @@ eca.register_autograd(_eca_bwd, setup_context=_eca_setup)
 @torch.library.custom_op("vrnet::image_enhance", mutates_args=(), device_types="cuda")
 def image_enhance(p: torch.Tensor, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
     """p: the projected radar map ReLU(BN(conv3x3(radar))), x: the image map, both (B,H,W,C) NHWC fp32.  data_normal maps p to
-    [0, 1] with the minimum / maximum over the WHOLE batch tensor (when they coincide it only subtracts the minimum).
+    [0, 1] with the minimum / maximum over the WHOLE batch tensor.  DEVIATION from the reference, documented: when max ==
+    min (a constant map -- e.g. every ReLU output zero) vr_coc.py:64-66 divides by zero and the whole network turns NaN;
+    this kernel then only subtracts the minimum (data_normal = 0, t = x), which keeps a degenerate batch finite.
     Returns (t = (1 + data_normal(p)) * x, (min, max))."""
     p, x = p.contiguous(), x.contiguous()
     with torch.cuda.device(x.device):
@@ -617,8 +619,20 @@ def radar_enhance(a: torch.Tensor, r: torch.Tensor, weight: torch.Tensor) -> tup
     ECA Conv1d weight.  u = eca(shuffle_channels(cat([a, r], C), 2)) -- the channel-wise gate in front of the inverse
     projection -- with the concat + shuffle as ONE strided launch and the gate as moments + coefficient + scale.
     Returns (u, gate, moments)."""
-    cat = torch.ops.vrnet.cat_shuffle(a, r, a.shape[-1] == r.shape[-1])
+    cat = torch.ops.vrnet.cat_shuffle(a, r, _re_interleave(a, r))
     return torch.ops.vrnet.eca(cat, weight)
+
+
+def _re_interleave(a, r):
+    """Whether shuffle_channels(cat, 2) (vr_coc.py:70-80) interleaves: it does whenever Ca + Cb is even, and is the identity
+    for an odd sum (the 3 + 4 input level).  The kernel behind cat_shuffle interleaves two halves of EQUAL width -- every
+    site of the model; unequal widths with an even sum would need the general half-interleave of the concatenation (the
+    halves then straddle the two sources): refused rather than returned in another channel order."""
+    ca, cb = a.shape[-1], r.shape[-1]
+    if ca != cb and (ca + cb) % 2 == 0:
+        raise RuntimeError(f"vrnet::radar_enhance: widths {ca} + {cb} (unequal, even sum) need the general 2-group shuffle of "
+                           "the concatenation, which this op does not implement (the model only has equal widths and 3 + 4)")
+    return ca == cb
 
 
 @radar_enhance.register_fake
@@ -630,7 +644,7 @@ def _(a, r, weight):
 @torch.library.custom_op("vrnet::radar_enhance_backward", mutates_args=(), device_types="cuda")
 def radar_enhance_backward(g: torch.Tensor, a: torch.Tensor, r: torch.Tensor, gate: torch.Tensor, mom: torch.Tensor,
                            weight: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    il = a.shape[-1] == r.shape[-1]
+    il = _re_interleave(a, r)
     cat = torch.ops.vrnet.cat_shuffle(a, r, il)                      # recomputed: one strided copy instead of a stored tensor
     dcat, dw = torch.ops.vrnet.eca_backward(g, cat, gate, mom, weight)
     da, dr = torch.ops.vrnet.cat_shuffle_backward(dcat, a.shape[-1], il)

@@ -282,9 +282,13 @@ class SyncBatchNormStats:
         else:
             self.batch_total = batch_local
 
-    def count(self, batch_local, per_sample):
-        """Global element count per channel of a map with `per_sample` pixels per sample."""
-        total = self.batch_total if self.batch_total is not None else batch_local * self.world
+    def count(self, batch_local, per_sample, batch_total=None):
+        """Global element count per channel of a map with `per_sample` pixels per sample.  batch_total: the global sample
+        count of the FORWARD pass the caller belongs to (program.RT.sync_batch_total, captured right after begin_forward):
+        a backward pass that runs after another forward with a different batch (gradient accumulation with a short last
+        micro-batch, two models sharing this object) must not normalise with the newer count."""
+        total = batch_total if batch_total is not None else \
+            (self.batch_total if self.batch_total is not None else batch_local * self.world)
         return total * per_sample
 
     def total(self, mom):

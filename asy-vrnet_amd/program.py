@@ -107,6 +107,8 @@ class RT:
         self.tape_pos = 0           # index of the top-level tape closure being replayed
         self.concurrent = True      # fork independent chains (image / radar, seg / det, head levels) onto side streams
         self.pair_streams = False   # True: image + radar chain of a backbone stage as ONE two-stream batch (one launch per layer)
+        self.sync_batch_total = None   # SyncBatchNorm: global sample count of THIS forward pass
+        self.via_autograd = False   # parameter gradients go back through torch.autograd (stock DistributedDataParallel)
 
     # ---- fork / join of independent chains -------------------------------------------------------------
     _side_streams = {}
@@ -604,7 +606,7 @@ def bn_forward(rt, z, bn, relu, out=None, residual=None):
         # synchronised BatchNorm: per-sample moments -> sum over samples and ranks -> coefficients with the global count
         tot = rt.sync_bn.total(hip.moments(z.t, z.ld, B, HW, C))
         hip.bn_coef_fwd(tot, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                        bn.num_batches_tracked, True, 1, rt.sync_bn.count(B, HW), C, A, D, S, ms)
+                        bn.num_batches_tracked, True, 1, rt.sync_bn.count(B, HW, rt.sync_batch_total), C, A, D, S, ms)
         z.colpart = None
     elif rt.training and z.colpart is not None:
         hip.bn_coef_fwd_from_partials(z.colpart, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
@@ -642,7 +644,7 @@ def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
         mom2 = hip.moments(dy, lddy, B, HW, C, x2=z.t, ldx2=z.ld, mask=None if mask is None else mask.t,
                            ldm=0 if mask is None else mask.ld)
         tot2 = rt.sync_bn.total(mom2)
-        hip.bn_coef_bwd(tot2, ms, bn.weight, True, 1, rt.sync_bn.count(B, HW), C, A, E, D, S, rt.buf(C), rt.buf(C), 0)
+        hip.bn_coef_bwd(tot2, ms, bn.weight, True, 1, rt.sync_bn.count(B, HW, rt.sync_batch_total), C, A, E, D, S, rt.buf(C), rt.buf(C), 0)
         hip.bn_coef_bwd(mom2, ms, bn.weight, True, B, HW, C, rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C), gw, gb, accw)
     else:
         fwd = getattr(ms, "fwd_coef", None) if (mask is not None and BN_ZMASK) else None
@@ -1846,6 +1848,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
             rt.bn_colstats = False          # the statistics come from the per-sample moments pass that feeds the collective
             if model.training:
                 rt.sync_bn.begin_forward(B, x.device)
+                rt.sync_batch_total = rt.sync_bn.batch_total      # this pass's count, also for ITS backward (bn_backward)
         cd = str(os.environ.get("VRNET_COMPUTE_DTYPE") or getattr(model, "compute_dtype", "f32")).lower()   # env: diagnostics
         if cd not in ("f32", "fp32", "float32", "torch.float32", "f32-mfma", "bf16", "bfloat16", "torch.bfloat16"):
             raise RuntimeError(f"compute_dtype {cd!r}: expected 'f32', 'f32-mfma' or 'bf16'")
@@ -1858,6 +1861,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         if torch.is_autocast_enabled():
             rt.bf16 = True
         rt.bucketer = getattr(model, "_grad_bucketer", None)
+        rt.via_autograd = bool(getattr(model, "_via_autograd", False))   # stock DDP around the module (run_forward)
         rt.ready = [] if rt.bucketer is not None else None
         rt.on_param_grad = rt.ready.append if rt.bucketer is not None else None
         if getattr(model, "record_relu_masks", False):
@@ -1970,8 +1974,14 @@ def backward_end(rt, model, inputs, needs, params=None, needs_params=None):
             if stray:
                 raise RuntimeError(f"{len(stray)} parameter gradient(s) were produced outside the data-parallel buckets")
             rt.bucketer.finish()
-        elif getattr(model, "autograd_param_grads", False) and needs_params is not None:
+        elif (getattr(model, "autograd_param_grads", False) or rt.via_autograd) and needs_params is not None:
+            # through torch.autograd: every parameter's AccumulateGrad node runs, so the hooks a stock
+            # DistributedDataParallel reducer hangs on it fire (train.py:367-368).  Under such a wrapper a parameter that
+            # asks for a gradient and gets none (the six zero-size ShuffleAttention(channel=3) entries) receives zeros:
+            # the reducer counts one hook call per parameter it found in the graph
             pouts = [rt.pgrads.get(p) if need else None for p, need in zip(params, needs_params)]
+            if rt.via_autograd:
+                pouts = [torch.zeros_like(p) if (g is None and need) else g for p, g, need in zip(params, pouts, needs_params)]
         else:
             # Default: publish parameter gradients directly (.grad = buffer, or += into an existing .grad, as
             # loss.backward() would) -- saves one copy of every gradient per step.  Set
@@ -2019,8 +2029,36 @@ class _VRNetFunction(torch.autograd.Function):
         return (None, *outs, *(pouts if pouts is not None else [None] * len(ctx.params)))
 
 
+def _ddp_wrapper_of(model, depth=16):
+    """The torch DistributedDataParallel instance whose forward() is calling `model` right now (None: there is none).
+    DDP's reducer hangs its hooks on the parameters' AccumulateGrad nodes from C++ -- nothing on the module or its
+    parameters shows them -- so the wrapper is looked for where it must be: a few frames up the call stack
+    (DistributedDataParallel.forward -> _run_ddp_forward -> module(...) -> Module._call_impl -> forward -> run_forward)."""
+    import sys
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+    except Exception:      # a torch build without distributed
+        return None
+    f = sys._getframe(1)
+    while f is not None and depth > 0:
+        s = f.f_locals.get("self")
+        if isinstance(s, DDP) and any(m is model for m in s.module.modules()):
+            return s
+        f, depth = f.f_back, depth - 1
+    return None
+
+
 def run_forward(model, x, x_radar):
     params = tuple(model.parameters())
+    # Stock DistributedDataParallel around the module (the reference's train.py:367-368, unchanged): its reducer only sees
+    # gradients that arrive through autograd's AccumulateGrad nodes, so under it the parameter gradients are returned
+    # through torch.autograd instead of being published by assignment (one extra copy of every gradient per step;
+    # parallel.DataParallelVRNet is the fast path -- INTEGRATION.md).
+    ddp = _ddp_wrapper_of(model) if torch.is_grad_enabled() else None
+    if ddp is not None and getattr(model, "_grad_bucketer", None) is not None:
+        raise RuntimeError("EfficientVRNet is wrapped by torch DistributedDataParallel AND by parallel.DataParallelVRNet: "
+                           "its gradients would be all-reduced twice -- use one of the two")
+    model._via_autograd = ddp is not None
     if not torch.is_grad_enabled() or not (x.requires_grad or x_radar.requires_grad or any(p.requires_grad for p in params)):
         # nothing to differentiate (torch.no_grad(), frozen model): no tape, no saved activations, no autograd node
         rt, _, dets, seg = forward_pass(model, x, x_radar, record=False)

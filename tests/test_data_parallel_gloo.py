@@ -258,6 +258,11 @@ def _worker_sync_bn(rank, world, port, q):
     mean = tot[0, :, 0] / n
     var = tot[0, :, 1] / n - mean * mean
     ok = ok and torch.allclose(mean, full.mean((0, 1)), atol=1e-12) and torch.allclose(var, full.var((0, 1), unbiased=False), atol=1e-12)
+    # a backward pass keeps the count of ITS forward (captured by the program right after begin_forward), whatever a later
+    # forward with another batch left in the object (gradient accumulation with a short last micro-batch; round-4 ADVICE)
+    captured = sb.batch_total
+    sb.begin_forward(B + 1, "cpu")
+    ok = ok and sb.count(B, HW, captured) == sum(Bs) * HW and sb.count(B + 1, HW) == (sum(Bs) + world) * HW
     # the wrapper option: sets the stats object on the module; the captured step refuses it
     model = A.EfficientVRNet(4, 9, "nano", img_size=64)
     net = DataParallelVRNet(model, sync_bn=True)
@@ -284,3 +289,55 @@ def test_sync_batch_norm_statistics_two_ranks():
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+def test_stock_ddp_wrapper_is_found_on_the_call_stack():
+    """program._ddp_wrapper_of: the guard behind the stock-DistributedDataParallel path (train.py:367-368).  A module whose
+    forward asks "is a DDP wrapper calling me?" gets the wrapper when called through it -- also as a submodule of the
+    wrapped module -- and None when called directly.  (The routing of the gradients through torch.autograd that the guard
+    switches on needs the kernels: tests/test_net_parity.py::test_stock_distributed_data_parallel_single_rank.)"""
+    from asy_vrnet_amd.program import _ddp_wrapper_of
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    class Probe(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+            self.seen = "unset"
+
+        def forward(self, x):
+            self.seen = _ddp_wrapper_of(self)
+            return x * self.w
+
+    class Outer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inner = Probe()
+
+        def forward(self, x):
+            return self.inner(x) + 1
+
+    own = not dist.is_initialized()
+    if own:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        m = Probe()
+        m(torch.zeros(3))
+        assert m.seen is None
+        ddp = DDP(m, find_unused_parameters=True)
+        ddp(torch.zeros(3)).sum().backward()
+        assert m.seen is ddp
+        m(torch.zeros(3))
+        assert m.seen is None                       # called directly again: no wrapper on the stack
+        o = Outer()
+        ddp2 = DDP(o)
+        ddp2(torch.zeros(3)).sum().backward()
+        assert o.inner.seen is ddp2                 # found as a submodule of the wrapped module
+        other = Probe()
+        DDP(Outer())                                # an unrelated wrapper elsewhere does not count
+        other(torch.zeros(3))
+        assert other.seen is None
+    finally:
+        if own:
+            dist.destroy_process_group()

@@ -336,6 +336,59 @@ def test_data_parallel_wrapper_single_rank(A):
     assert abs(float(loss) - float(loss_of(*ref(x, r)).detach())) < 1e-5 * abs(float(loss))
 
 
+def test_stock_distributed_data_parallel_single_rank(A):
+    """The reference's own wrapper, unchanged (train.py:367-368): torch DistributedDataParallel(model,
+    find_unused_parameters=True) on a 1-rank RCCL process group.  Under it the parameter gradients go back through
+    torch.autograd (program.run_forward finds the wrapper on the call stack), so the reducer's AccumulateGrad hooks fire:
+    two steps, gradients equal to the plain run's, and the six zero-size ShuffleAttention(channel=3) parameters -- which
+    never receive a real gradient -- do not leave the reducer waiting ("Expected to have finished reduction")."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from asy_vrnet_amd.parallel import DataParallelVRNet
+
+    def loss_of(det, seg):
+        return sum((d * d).mean() for d in det) + (seg * seg).mean()
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29591")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        x, r = A.synthetic_inputs(2, 64, 3)
+        x, r = x.cuda(), r.cuda()
+        ref = build(A, "nano", 64, 7, True)
+        m = build(A, "nano", 64, 7, True)
+        ddp = DDP(m, device_ids=[torch.cuda.current_device()], find_unused_parameters=True)
+        for step in range(2):
+            for mod in (ref, m):
+                mod.zero_grad(set_to_none=True)
+            loss_of(*ref(x, r)).backward()
+            loss_of(*ddp(x, r)).backward()          # a second step raises inside DDP if a hook of step 0 never fired
+            assert m._via_autograd and not ref._via_autograd
+            n_zero = 0
+            for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+                if p.numel() == 0:
+                    n_zero += 1
+                    continue
+                assert p.grad is not None and q.grad is not None, k
+                assert torch.equal(p.grad, q.grad), (step, k)
+            assert n_zero == 6
+        # BatchNorm statistics moved the same way (the wrapper broadcasts buffers from rank 0: a no-op on one rank)
+        for (k, v), (_, w) in zip(m.state_dict().items(), ref.state_dict().items()):
+            assert torch.equal(v, w), k
+        # an eval forward through the wrapper under no_grad: no autograd node, nothing for the reducer to wait for
+        with torch.no_grad():
+            ddp.eval()(x, r)
+        ddp.train()
+        # both wrappers at once would reduce twice: refused with a message naming them
+        DataParallelVRNet(m, bucket_bytes=1 << 20)
+        with pytest.raises(RuntimeError, match="DataParallelVRNet"):
+            ddp(x, r)
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
 @pytest.mark.gpu
 def test_deepcopy_and_updated_weights_use_fresh_fused_weights(A):
     """The concatenated fc1|fc_v weights are derived caches: a deep copy (ModelEMA, yolo_training.py:457) and an

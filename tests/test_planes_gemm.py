@@ -51,6 +51,17 @@ def test_plane_split_is_exact(hip):
         assert torch.equal(p3.t[0].float(), src.to(torch.bfloat16).float()), "plane 0 is the bf16 rounding"
         p1 = split(hip, src, 1)
         assert torch.equal(p1.t[0], src.to(torch.bfloat16))
+    # K % 8 == 4 with a tight destination (ld == K): a thread stores eight columns at a time, and the one at k0 = K - 4 must
+    # not write four zeros into the next row (or, on the last row, past the plane) -- round-4 ADVICE
+    for R, K in ((37, 12), (5, 4), (64, 68)):
+        src = rnd(R, K, seed=7).cuda()
+        for np_ in (3, 1):
+            guard = torch.full((np_, R * K + 64), 7.0, dtype=torch.bfloat16, device="cuda")     # 64 sentinels behind every plane
+            out = hip.Planes(guard[:, :R * K].view(np_, R, K), ld=K, plane=R * K + 64)
+            hip.planes_from_f32(src, K, R, K, out)
+            want = src if np_ == 3 else src.to(torch.bfloat16).float()
+            assert torch.equal(out.float(), want), (R, K, np_)
+            assert bool((guard[:, R * K:] == 7.0).all()), "wrote past the plane"
     inf = torch.tensor([[float("inf"), float("-inf"), float("nan"), 1.0] * 2], device="cuda")
     p = split(hip, inf, 3).float()
     assert torch.isinf(p[0, 0]) or torch.isnan(p[0, 0])      # non-finite values stay non-finite (Inf - Inf = NaN in the residuals)

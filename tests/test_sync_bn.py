@@ -19,8 +19,8 @@ class TwoRankStub:
     def begin_forward(self, batch_local, device):
         pass
 
-    def count(self, batch_local, per_sample):
-        return 2 * batch_local * per_sample
+    def count(self, batch_local, per_sample, batch_total=None):
+        return (batch_total if batch_total is not None else 2 * batch_local) * per_sample
 
     def total(self, mom):
         tot = mom.sum(0, keepdim=True)

@@ -17,6 +17,11 @@ python3 bench.py --no-cpu-baseline --detail 2> $out/per_shape_detail_phi-l_bs8_5
 python3 bench.py --no-cpu-baseline --detail --dtype bf16 --batch 16 2> $out/per_shape_detail_phi-l_bs16_512_bf16.txt > /dev/null
 VRNET_BENCH_FORCE_DP=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
     bench.py --gpus 1 --no-cpu-baseline --no-roofline 2>/dev/null | grep metric > $out/line_dp1_rccl_3segments_phi-l_bs8_512.json
+# ---- the issue ceiling of the x6 loop on THIS round's boxes (bench.py reads the newest round's file only; round-4 ADVICE: r04 had
+# none and reported r03's number)
+[ -x tools/micro/x6_peak.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/x6_peak.hip -o tools/micro/x6_peak.bin
+(echo "# tools/micro/x6_peak.hip: register-resident x6 inner loop, no memory (mfma only / splits only / both)"; timeout 300 tools/micro/x6_peak.bin 2>&1 | grep -v amdgpu.ids) > $out/x6_issue_ceiling_micro.txt
+cp $out/x6_issue_ceiling_micro.txt profiles/${R}_x6_issue_ceiling_micro.txt
 # ---- isolated probes: the plane GEMMs of round 4 against the in-kernel-split kernels, forward and weight gradient
 (echo "# python tools/pgemm_probe.py  (single 1x1-conv GEMM launches alone: r3 x6 kernel with pre-split weights vs plane GEMM np = 3 / 1; weight gradients)"; timeout 900 python3 tools/pgemm_probe.py 2>&1 | grep -v amdgpu.ids) > $out/pgemm_probe.txt
 (echo "# python tools/cluster_probe.py  (Cluster kernels alone, phi = l, bs 8, 512 px)"; timeout 300 python3 tools/cluster_probe.py 2>&1 | grep -v amdgpu.ids) > $out/cluster_probe.txt
