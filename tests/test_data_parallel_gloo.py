@@ -341,3 +341,47 @@ def test_stock_ddp_wrapper_is_found_on_the_call_stack():
     finally:
         if own:
             dist.destroy_process_group()
+
+
+def test_n8_plan_at_l():
+    """The segment / bucket plan an 8-GPU job would run at phi = l (BASELINE configs[3]), built on the CPU from the execution
+    order a real backward pass recorded (tests/golden/dp_ready_pos.json, written on an MI355X by tools/make_golden_dp_plan.py;
+    tests/test_net_parity.py::test_recorded_order_fixture_is_current keeps it current).  The collective of the LAST captured
+    segment overlaps nothing, so it must be small: <= 5 % of the gradient bytes (round 4's byte-balancing rule stranded stage
+    2 there: 31 %).  Also: three segments, every bucket inside one segment and <= bucket_bytes + one parameter, the arena
+    covered exactly once, the head first and the embeddings last."""
+    import json
+    import asy_vrnet_amd as A
+    from asy_vrnet_amd.parallel import GradBucketer, backward_param_order
+    pos = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dp_ready_pos.json")))
+    for phi in ("l", "nano"):
+        with torch.device("meta"):                           # layout only: no 200 MB arena in the CPU suite
+            m = A.EfficientVRNet(4, 9, phi)
+        names = dict(m.named_parameters())
+        assert set(pos) == {k for k, p in names.items() if p.numel()}, "fixture and parameter set differ"
+        bk = GradBucketer(backward_param_order(m), bucket_bytes=32 << 20, segments=3)
+        for k, (tape_pos, order) in pos.items():             # what mark_ready() stamps during the recording pass
+            bk.ready_pos[names[k]] = tape_pos
+            bk._rec_order[names[k]] = order
+        bk.rebuild_from_recording()
+        total = sum(p.numel() for p in bk.params)
+        assert len(bk.cuts) == 2 and sorted(bk.segment_slices) == [0, 1, 2]
+        share = {k: sum(p.numel() for p in bk.params if bk.bucket_segment[bk.bucket_of[p]] == k) / total for k in range(3)}
+        assert 0 < share[2] <= 0.05, share                   # the un-overlapped collective
+        assert share[0] >= 0.3 and share[1] >= 0.3, share    # the two overlapped ones carry the bytes
+        # slices: consecutive, cover the arena, one segment per bucket, bucket size bounded
+        lo = 0
+        for k in range(3):
+            assert bk.segment_slices[k][0] == lo
+            lo = bk.segment_slices[k][1]
+        assert lo == bk.arena.numel()
+        biggest = max(p.numel() for p in bk.params) * 4
+        for bi, flat in enumerate(bk.buckets):
+            assert flat.numel() * 4 <= (32 << 20) + biggest
+            assert len({bk.bucket_segment[bk.bucket_of[p]] for p in bk.params if bk.bucket_of[p] == bi}) == 1
+        inv = {p: k for k, p in names.items()}
+        assert inv[bk.params[0]].startswith("head.") and "initial" in inv[bk.params[-1]] or "patch_embed" in inv[bk.params[-1]] \
+            or "enhance" in inv[bk.params[-1]], inv[bk.params[-1]]
+        # ring all-reduce over 8 ranks at ~150 GB/s per xGMI link and direction: wire time of the exposed collective
+        exposed_ms = 2 * 7 / 8 * share[2] * total * 4 / 150e9 * 1e3
+        assert exposed_ms < (0.15 if phi == "l" else 0.02), exposed_ms

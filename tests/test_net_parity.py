@@ -336,6 +336,18 @@ def test_data_parallel_wrapper_single_rank(A):
     assert abs(float(loss) - float(loss_of(*ref(x, r)).detach())) < 1e-5 * abs(float(loss))
 
 
+def test_recorded_order_fixture_is_current(A, golden_dir):
+    """tests/golden/dp_ready_pos.json -- the backward execution order the CPU test of the 8-GPU segment / bucket plan is built
+    on (tests/test_data_parallel_gloo.py::test_n8_plan_at_l) -- equals what a recording pass of THIS program stamps (the
+    order is a function of the program's structure only: identical for every width, batch and image size)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_golden_dp_plan import recorded_positions
+    want = json.load(open(os.path.join(golden_dir, "dp_ready_pos.json")))
+    got = recorded_positions("nano", size=64, batch=2)
+    assert got == want, "the backward program changed its section order: rerun tools/make_golden_dp_plan.py on the GPU"
+
+
 def test_stock_distributed_data_parallel_single_rank(A):
     """The reference's own wrapper, unchanged (train.py:367-368): torch DistributedDataParallel(model,
     find_unused_parameters=True) on a 1-rank RCCL process group.  Under it the parameter gradients go back through
