@@ -4,8 +4,10 @@ conversions are covered; the random augmentations (mosaic, mixup, HSV jitter, :2
 outside the hot path.  Host side (numpy / PIL): parsing, letterbox, box mapping.  Device side (`device_batch`,
 csrc/formats.hip): the per-pixel conversions of a letterboxed batch -- image normalisation + CHW, label clamp, one-hot --
 from bytes.  Pins: the functions the reference keeps in importable modules (`preprocess_input`, `preprocess_input_radar`,
-`resize_image`) produced tests/golden/formats_small.npz (tools/make_golden_formats.py); the rest of the row is checked
-against hand-worked values (tests/test_data.py) -- the reference has no tests or fixtures for it."""
+`resize_image`) produced tests/golden/formats_small.npz (tools/make_golden_formats.py); round 5: the reference's own
+`YoloDataset.__getitem__` (train=False) + `yolo_dataset_collate`, importable once cv2 / albumentations are stubbed (the
+evaluation path touches neither), produced tests/golden/dataset_small.npz (tools/make_golden_dataset.py) -- parsing,
+letterbox, box mapping, clamp, one-hot and collate are held to it bit for bit (tests/test_data.py)."""
 import os
 import re
 
@@ -65,17 +67,21 @@ def letterbox_geometry(iw, ih, w, h):
 
 def adjust_boxes(box, iw, ih, w, h):
     """Boxes (x1, y1, x2, y2, cls) of an iw x ih image -> the letterboxed w x h canvas: scaled and shifted like the
-    pixels, clipped to the canvas, and boxes thinner than 2 px dropped (semantics of dataloader.py:170-180, minus
-    its in-place shuffle)."""
+    pixels, clipped to the canvas, and boxes thinner than 2 px dropped (dataloader.py:170-180, minus its in-place
+    shuffle).  The reference parses the annotation into an INTEGER array (:133) and assigns the scaled coordinates back
+    into it, so every mapped coordinate is truncated towards zero before clipping -- reproduced here (pinned by
+    tests/golden/dataset_small.npz, the reference's own output)."""
     nw, nh, dx, dy = letterbox_geometry(iw, ih, w, h)
-    out = np.array(box, dtype=np.float64).reshape(-1, 5)
+    out = np.array(box, dtype=np.int64).reshape(-1, 5)
     if out.shape[0] == 0:
-        return out
-    gain = np.array([nw / iw, nh / ih, nw / iw, nh / ih])
-    shift = np.array([dx, dy, dx, dy], dtype=np.float64)
-    out[:, :4] = np.clip(out[:, :4] * gain + shift, 0.0, np.array([np.inf, np.inf, w, h]))
+        return out.astype(np.float64)
+    out[:, [0, 2]] = out[:, [0, 2]] * nw / iw + dx            # float result -> int64 storage: truncation, as the reference
+    out[:, [1, 3]] = out[:, [1, 3]] * nh / ih + dy
+    out[:, 0:2][out[:, 0:2] < 0] = 0
+    out[:, 2][out[:, 2] > w] = w
+    out[:, 3][out[:, 3] > h] = h
     keep = ((out[:, 2] - out[:, 0]) > 1) & ((out[:, 3] - out[:, 1]) > 1)
-    return out[keep]
+    return out[keep].astype(np.float64)
 
 
 def boxes_xyxy_to_cxcywh(box):

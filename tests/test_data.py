@@ -1,5 +1,5 @@
-"""Input formats: every function against hand-worked values (the reference has no fixtures for this
-row and its dataloader cannot be imported; parity unpinned)."""
+"""Input formats: every function against hand-worked values, against the functions the reference keeps in
+importable modules (formats_small.npz) and -- round 5 -- against the reference's own YoloDataset + collate (dataset_small.npz)."""
 import os
 
 import numpy as np
@@ -140,3 +140,41 @@ def test_device_batch_formats_bit_identical():
     assert np.array_equal(bo.cpu().numpy().argmax(-1), want_p) and float(bo.sum()) == lab.size
     with pytest.raises(RuntimeError, match="uint8"):
         data.device_batch(big.astype(np.float32), None, ns)
+
+
+def test_dataset_item_and_collate_match_the_reference(tmp_path):
+    """Row f4 end to end against the reference's OWN YoloDataset.__getitem__ (train=False) + yolo_dataset_collate
+    (utils/dataloader.py:71-183, 440-457), run in the build container with cv2 / albumentations stubbed
+    (tools/make_golden_dataset.py -> tests/golden/dataset_small.npz): annotation parsing, frame id, radar .npz, bicubic
+    letterbox, nearest label letterbox, box mapping incl. the reference's integer truncation, clipping and thin-box filter,
+    cx-cy-w-h, label clamp to the ignore class, one-hot, collate dtypes -- bit for bit (the boxes up to row order: the
+    reference shuffles them in place)."""
+    from PIL import Image
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_small.npz"))
+    h, w = (int(v) for v in z["input_shape"])
+    ns = int(z["num_classes_seg"])
+    os.makedirs(tmp_path / "radar")
+    batch = []
+    for i, tail in enumerate(z["line_tails"]):
+        fid = str(z[f"fid{i}"])
+        img_path = str(tmp_path / (fid + ".png"))
+        Image.fromarray(z[f"img{i}"]).save(img_path)
+        np.savez(tmp_path / "radar" / (fid + ".npz"), z[f"radar{i}"])
+        line = img_path + (" " + str(tail) if str(tail) else "")
+        path, boxes = data.parse_annotation_line(line)
+        assert path == img_path and data.frame_id(line) == fid
+        radar = data.load_radar(str(tmp_path / "radar"), data.frame_id(line))
+        image, box, label = data.letterbox_sample(Image.open(path), Image.fromarray(z[f"lab{i}"]), boxes, (h, w))
+        batch.append(data.make_sample(image, box, radar, label, ns))
+    images, bboxes, radars, pngs, seg_labels = data.yolo_dataset_collate(batch)
+    assert images.dtype == torch.float32 and pngs.dtype == torch.int64 and seg_labels.dtype == torch.float32
+    assert np.array_equal(images.numpy(), z["images"])
+    assert np.array_equal(radars.numpy(), z["radars"])
+    assert np.array_equal(pngs.numpy(), z["pngs"])
+    assert np.array_equal(seg_labels.numpy(), z["seg_labels"])
+    for i, b in enumerate(bboxes):
+        want = z[f"boxes_out{i}"].reshape(-1, 5)      # (the reference returns shape (0,) for a frame without boxes)
+        got = b.numpy()
+        assert got.shape == want.shape, (i, got, want)
+        order = lambda a: a[np.lexsort(a.T[::-1])]
+        assert np.array_equal(order(got), order(want)), (i, got, want)
