@@ -47,7 +47,7 @@ void vr_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int vrnet_abi_version(void) { return 8; }
+extern "C" int vrnet_abi_version(void) { return 9; }
 extern "C" const char* vrnet_last_error(void) { return g_err; }
 
 // Synchronous device query used by load-time checks only (never on the hot path).

@@ -773,6 +773,42 @@ __global__ __launch_bounds__(256) void cluster_ab_reduce_kernel(const float* par
   }
 }
 
+// The same reduction for up to AB_MAX Cluster modules in ONE launch (round 5): the backward kernels of a section leave their
+// per-workgroup (d alpha, d beta) partials in buffers the caller owns, and one workgroup per module adds them up once the
+// section's chains have joined -- 27 launches per step off the backward chains.  The table travels by value (kernel
+// arguments), so a captured graph needs no host memory.
+constexpr int AB_MAX = 32;
+struct AbTable {
+  const float* partial[AB_MAX];
+  float* dalpha[AB_MAX];
+  float* dbeta[AB_MAX];
+  int blocks[AB_MAX];
+  int accumulate[AB_MAX];
+};
+__global__ __launch_bounds__(256) void cluster_ab_reduce_multi_kernel(const AbTable t) {
+  __shared__ double red[8];
+  const int e = blockIdx.x;
+  const float* partial = t.partial[e];
+  const long blocks = t.blocks[e];
+  double a = 0, b = 0;
+  for (long i = threadIdx.x; i < blocks; i += 256) {
+    a += partial[2 * i];
+    b += partial[2 * i + 1];
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = a;
+    red[4 + (threadIdx.x >> 6)] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double sa = red[0] + red[1] + red[2] + red[3], sb = red[4] + red[5] + red[6] + red[7];
+    t.dalpha[e][0] = (t.accumulate[e] ? t.dalpha[e][0] : 0.f) + (float)sa;
+    t.dbeta[e][0] = (t.accumulate[e] ? t.dbeta[e][0] : 0.f) + (float)sb;
+  }
+}
+
 int cluster_plan(int N, long blocks, int* T, int* npt, int bwd) {
   if (N > 256) {      // streaming kernel (points re-read in chunks): any region size
     *T = 0;
@@ -945,8 +981,9 @@ static int cluster_bwd_impl(const float* f, const float* v, long ld, const float
   int T, npt;
   int rc = cluster_check("cluster_bwd", f, v, ld, B, H, W, E, D, fold, &T, &npt, 1);
   if (rc) return rc;
-  VR_CHECK_ARG(idx && dout && ((df && dv) || (dfvp && !df && !dv)) && dalpha && dbeta && workspace,
-               "cluster_bwd: null tensor (df / dv may both be NULL only with a plane output)");
+  VR_CHECK_ARG(idx && dout && ((df && dv) || (dfvp && !df && !dv)) && (!dalpha == !dbeta) && workspace,
+               "cluster_bwd: null tensor (df / dv may both be NULL only with a plane output; dalpha and dbeta come together)");
+  VR_CHECK_ARG(dalpha || !alpha2, "cluster_bwd: the deferred (d alpha, d beta) form is single-stream");
   VR_CHECK_ARG(lddo % 4 == 0 && vr_aligned16(dout) && (!df || (lddf % 4 == 0 && vr_aligned16(df) && vr_aligned16(dv))) &&
                    vr_planes_out_ok(dfvp, 2 * E * D),
                "cluster_bwd: rows must be 16-byte aligned");
@@ -971,8 +1008,37 @@ static int cluster_bwd_impl(const float* f, const float* v, long ld, const float
   hipStream_t st = vr_stream(stream);
   cluster_launch<true>(p, T, npt, blocks, st);
   VR_LAUNCH_CHECK("cluster_bwd");
+  // dalpha == dbeta == NULL: the per-workgroup partials stay in the first 2 * B * E * fold^2 floats of `workspace` (which the
+  // caller then owns until it has run vrnet_cluster_ab_reduce_multi over it)
+  if (!dalpha) return VR_OK;
   hipLaunchKernelGGL(cluster_ab_reduce_kernel, dim3(alpha2 ? 2 : 1), dim3(256), 0, st, p.ab_partial,
                      alpha2 ? blocks / 2 : blocks, dalpha, dbeta, accumulate_ab, dalpha2, dbeta2);
   VR_LAUNCH_CHECK("cluster_ab_reduce");
+  return VR_OK;
+}
+
+/* (d alpha, d beta) of n Cluster modules from the per-workgroup partials their backward launches left (vrnet_cluster_bwd_*
+ * with dalpha = dbeta = NULL): partial[i] = that launch's workspace, blocks[i] = its B * E * fold^2, accumulate[i] != 0 adds to
+ * the gradients.  Host arrays; one launch per 32 modules.  Replaces the per-module finishing launch behind every
+ * Cluster backward (backbone/fusion/vr_coc.py:148-149: alpha, beta are shared by all regions and heads of a module). */
+extern "C" int vrnet_cluster_ab_reduce_multi(int n, const void* const* partial, const long* blocks, float* const* dalpha,
+                                             float* const* dbeta, const int* accumulate, void* stream) {
+  VR_CHECK_ARG(n > 0 && partial && blocks && dalpha && dbeta && accumulate, "cluster_ab_reduce_multi: bad arguments");
+  if (vr_ablated("cluster")) return VR_OK;
+  for (int i0 = 0; i0 < n; i0 += AB_MAX) {
+    AbTable t{};
+    const int m = n - i0 < AB_MAX ? n - i0 : AB_MAX;
+    for (int i = 0; i < m; ++i) {
+      VR_CHECK_ARG(partial[i0 + i] && dalpha[i0 + i] && dbeta[i0 + i] && blocks[i0 + i] > 0 && blocks[i0 + i] < (1L << 31),
+                   "cluster_ab_reduce_multi: bad entry");
+      t.partial[i] = reinterpret_cast<const float*>(partial[i0 + i]);
+      t.dalpha[i] = dalpha[i0 + i];
+      t.dbeta[i] = dbeta[i0 + i];
+      t.blocks[i] = (int)blocks[i0 + i];
+      t.accumulate[i] = accumulate[i0 + i] ? 1 : 0;
+    }
+    hipLaunchKernelGGL(cluster_ab_reduce_multi_kernel, dim3(m), dim3(256), 0, vr_stream(stream), t);
+    VR_LAUNCH_CHECK("cluster_ab_reduce_multi");
+  }
   return VR_OK;
 }

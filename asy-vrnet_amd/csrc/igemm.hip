@@ -1375,6 +1375,96 @@ __global__ __launch_bounds__(64) void wgrad_rowdot_kernel(const float* ls_part, 
   }
 }
 
+// Slab reduction AND layer-scale gradient in one launch (round 5; T == 1, Cin % 4 == 0): one workgroup per output row n, SL
+// lanes per quad of the row (lane sl adds slabs sl, sl + SL, ...; the SL partials meet through LDS in lane order), rows longer
+// than 256 / SL quads in passes.  The row's dot with the weights -- what wgrad_rowdot_kernel summed from per-quad partials in a
+// second launch -- is finished here: per-thread fp64 partials over the thread's quads, then wave and workgroup sums in a fixed
+// order.  Same bits run to run; -54 launches per step and no ls_part round trip.
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const float* slab, const float* bslab, const float* row_scale,
+                                                                float* dw, float* db, int S, int Cout, int Cin, int accumulate,
+                                                                const float* row_scale2, float* dw2, float* db2,
+                                                                const float* w_ls, const float* w_ls2, const float* bias,
+                                                                const float* bias2, float* dls, float* dls2) {
+  constexpr int OUTS = 256 / SL;
+  __shared__ float red[SL][OUTS][4];
+  __shared__ double wsum[4];
+  __shared__ float bsum[16];
+  const long per = (long)Cout * Cin;
+  if (blockIdx.y) {      // second stream of a two-stream launch
+    slab += (long)S * per;
+    if (bslab) bslab += (long)S * Cout;
+    row_scale = row_scale2; dw = dw2; db = db2; w_ls = w_ls2; bias = bias2; dls = dls2;
+  }
+  const int n = blockIdx.x, Q = Cin >> 2;
+  const int o = threadIdx.x % OUTS, sl = threadIdx.x / OUTS;
+  const float rs = row_scale ? row_scale[n] : 1.f;
+  const float* row = slab + (long)n * Cin;
+  double dot = 0.0;
+  for (int q0 = 0; q0 < Q; q0 += OUTS) {
+    const int q = q0 + o;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (q < Q) {
+#pragma unroll 4
+      for (int k = sl; k < S; k += SL) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + (long)k * per + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += v[j];
+      }
+    }
+    if (SL > 1) {
+      if (q0) __syncthreads();      // the previous pass's partials have been consumed
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[sl][o][j] = s[j];
+      __syncthreads();
+    }
+    if (sl == 0 && q < Q) {
+#pragma unroll
+      for (int k = 1; k < SL; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += red[k][o][j];
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w_ls + (long)n * Cin + q * 4);
+      float dsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dsum += s[j] * wv[j];
+      dot += (double)dsum;
+      float* d = dw + (long)n * Cin + q * 4;
+      f32x4 outv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) outv[j] = s[j] * rs;
+      if (accumulate) {
+        const f32x4 old = *reinterpret_cast<const f32x4*>(d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) outv[j] = old[j] + outv[j];
+      }
+      *reinterpret_cast<f32x4*>(d) = outv;
+    }
+  }
+  // raw bias gradient of the row: 16 lanes over the slabs, added in lane order
+  if (bslab && threadIdx.x < 16) {
+    float b = 0.f;
+    for (int k = threadIdx.x; k < S; k += 16) b += bslab[(long)k * Cout + n];
+    bsum[threadIdx.x] = b;
+  }
+  dot = wave_sum(dot);               // (threads with sl != 0 hold 0)
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double acc = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    float braw = 0.f;
+    if (bslab) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) braw += bsum[k];
+      if (db) {
+        const float v = row_scale ? braw * rs : braw;
+        db[n] = accumulate ? db[n] + v : v;
+      }
+    }
+    if (bias) acc += (double)bias[n] * (double)braw;
+    dls[n] = (accumulate ? dls[n] : 0.f) + (float)acc;
+  }
+}
+
 __global__ void pack_weight_kernel(const float* w, float* out, int Cout, int Cin, int T) {
   const long total = (long)T * Cout * Cin;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1847,6 +1937,26 @@ int vr_wgrad_reduce_launch(float* slab, float* bslab, float* ls_part, long ls_st
                                const float* row_scale2, float* dw2, float* dbias2, const float* w, const float* w2,
                                const float* bias, const float* bias2, float* dls, float* dls2, hipStream_t st) {
   const bool rvec = (Cin % 4 == 0);                 // slabs are 16-byte aligned (workspace arena), rows of Cin floats
+  if (dls && T == 1 && rvec && vr_aligned16(dw) && (!dw2 || vr_aligned16(dw2)) && vr_aligned16(w) && (!w2 || vr_aligned16(w2)) &&
+      (!bias || dbias)) {
+    // slab sums, row scale AND the layer-scale gradient in one launch: one workgroup per output row
+    const int Q = Cin / 4;
+    int sl = 1;
+    while (sl < 16 && sl * 2 * Q <= 256) sl *= 2;
+#define VR_WROWS(SL_)                                                                                                     \
+  hipLaunchKernelGGL((wgrad_reduce_rows_kernel<SL_>), dim3(Cout, streams), dim3(256), 0, st, slab, bslab, row_scale, dw,  \
+                     dbias, S, Cout, Cin, accumulate, row_scale2, dw2, dbias2, w, w2, bias, bias2, dls, dls2)
+    switch (sl) {
+      case 16: VR_WROWS(16); break;
+      case 8: VR_WROWS(8); break;
+      case 4: VR_WROWS(4); break;
+      case 2: VR_WROWS(2); break;
+      default: VR_WROWS(1); break;
+    }
+#undef VR_WROWS
+    VR_LAUNCH_CHECK("conv2d_wgrad_reduce_rows");
+    return VR_OK;
+  }
   const long total = (long)T * Cout * Cin / (rvec ? 4 : 1) + (dbias ? Cout : 0);
 #define VR_WREDUCE(VEC_, SL_)                                                                                        \
   hipLaunchKernelGGL((wgrad_reduce_kernel<VEC_, SL_>), dim3(vr_cdiv(total, 256 / SL_), streams), dim3(256), 0, st, slab, \

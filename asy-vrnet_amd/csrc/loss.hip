@@ -561,3 +561,112 @@ extern "C" int vrnet_seg_loss_f32(const float* x, const long long* png, const fl
   VR_LAUNCH_CHECK("seg_loss");
   return VR_OK;
 }
+
+// ---- the synthetic backward driver of the benchmark: L = sum_k mean(t_k^2) over up to MS_MAX tensors ----------
+// (the det maps and the seg logits).  As eager torch this is ~27 elementwise / reduce launches between the forward and the
+// backward pass, every one of them exposed; here: one pass for the value (fp64 partials, fixed order), one for the gradient
+// dL/dt_k = (2 g / n_k) t_k with the upstream scalar g read on the device.
+namespace {
+constexpr int MS_MAX = 8;
+struct MsTable {
+  const float* t[MS_MAX];
+  float* grad[MS_MAX];
+  long n[MS_MAX];
+  long first[MS_MAX + 1];      // first workgroup of each tensor
+  int k;
+};
+constexpr int MS_PER_WG = 256 * 16;
+
+__global__ __launch_bounds__(256) void mean_square_partial_kernel(const MsTable tb, double* partial) {
+  __shared__ double red[4];
+  int e = 0;
+  while (e + 1 < tb.k && (long)blockIdx.x >= tb.first[e + 1]) ++e;
+  const long base = ((long)blockIdx.x - tb.first[e]) * MS_PER_WG;
+  const float* t = tb.t[e];
+  const long n = tb.n[e];
+  double s = 0.0;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const long idx = base + (long)i * 256 + threadIdx.x;
+    if (idx < n) { const double v = (double)t[idx]; s += v * v; }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)n;
+}
+__global__ __launch_bounds__(256) void mean_square_final_kernel(const double* partial, long nwg, float* loss) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long i = threadIdx.x; i < nwg; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ __launch_bounds__(256) void mean_square_grad_kernel(const MsTable tb, const float* g) {
+  int e = 0;
+  while (e + 1 < tb.k && (long)blockIdx.x >= tb.first[e + 1]) ++e;
+  const long base = ((long)blockIdx.x - tb.first[e]) * MS_PER_WG;
+  const float* t = tb.t[e];
+  float* d = tb.grad[e];
+  const long n = tb.n[e];
+  const float sc = (float)(2.0 * (double)g[0] / (double)n);
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const long idx = base + (long)i * 256 + threadIdx.x;
+    if (idx < n) d[idx] = sc * t[idx];
+  }
+}
+int ms_table(int k, const void* const* t, void* const* grad, const long* n, MsTable* tb, long* nwg) {
+  long first = 0;
+  tb->k = k;
+  for (int i = 0; i < k; ++i) {
+    tb->t[i] = reinterpret_cast<const float*>(t[i]);
+    tb->grad[i] = grad ? reinterpret_cast<float*>(grad[i]) : nullptr;
+    tb->n[i] = n[i];
+    tb->first[i] = first;
+    first += (n[i] + MS_PER_WG - 1) / MS_PER_WG;
+  }
+  tb->first[k] = first;
+  *nwg = first;
+  return 0;
+}
+}  // namespace
+
+extern "C" long vrnet_mean_square_workspace(int k, const long* n) {
+  long wg = 0;
+  for (int i = 0; i < k; ++i) wg += (n[i] + MS_PER_WG - 1) / MS_PER_WG;
+  return wg * 8 + 256;
+}
+/* loss[0] = sum_k mean(t_k^2) over k <= 8 contiguous fp32 tensors of n_k elements (host arrays of device pointers / sizes):
+ * the fixed synthetic scalar that drives the backward pass of the benchmark and of the parity tests (the reference's
+ * real losses are vrnet_yolo_loss_f32 / vrnet_seg_loss_f32). */
+extern "C" int vrnet_mean_square_f32(int k, const void* const* t, const long* n, float* loss, void* workspace, long workspace_bytes,
+                                     void* stream) {
+  VR_CHECK_ARG(k > 0 && k <= MS_MAX && t && n && loss && workspace, "mean_square: bad arguments (<= %d tensors)", MS_MAX);
+  for (int i = 0; i < k; ++i) VR_CHECK_ARG(t[i] && n[i] > 0, "mean_square: bad tensor %d", i);
+  VR_CHECK_ARG(workspace_bytes >= vrnet_mean_square_workspace(k, n), "mean_square: workspace too small");
+  MsTable tb{};
+  long nwg;
+  ms_table(k, t, nullptr, n, &tb, &nwg);
+  VR_CHECK_ARG(nwg < (1L << 31), "mean_square: too large");
+  hipStream_t st = vr_stream(stream);
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(mean_square_partial_kernel, dim3((unsigned)nwg), dim3(256), 0, st, tb, partial);
+  hipLaunchKernelGGL(mean_square_final_kernel, dim3(1), dim3(256), 0, st, partial, nwg, loss);
+  VR_LAUNCH_CHECK("mean_square");
+  return VR_OK;
+}
+/* grad_k = (2 g / n_k) t_k with the upstream gradient g of the scalar read from device memory: one launch. */
+extern "C" int vrnet_mean_square_bwd_f32(int k, const void* const* t, const long* n, const float* g, void* const* grad, void* stream) {
+  VR_CHECK_ARG(k > 0 && k <= MS_MAX && t && n && g && grad, "mean_square_bwd: bad arguments (<= %d tensors)", MS_MAX);
+  for (int i = 0; i < k; ++i) VR_CHECK_ARG(t[i] && grad[i] && n[i] > 0, "mean_square_bwd: bad tensor %d", i);
+  MsTable tb{};
+  long nwg;
+  ms_table(k, t, grad, n, &tb, &nwg);
+  VR_CHECK_ARG(nwg < (1L << 31), "mean_square_bwd: too large");
+  hipLaunchKernelGGL(mean_square_grad_kernel, dim3((unsigned)nwg), dim3(256), 0, vr_stream(stream), tb, g);
+  VR_LAUNCH_CHECK("mean_square_bwd");
+  return VR_OK;
+}

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VRNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libvrnet_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -92,6 +92,7 @@ _SIGS = {
     "vrnet_cluster_bwd_workspace": ([I, I, I], L),
     "vrnet_cluster_bwd_workspace2": ([I, I, I, I, I], L),
     "vrnet_cluster_bwd_f32": ([P, P, L, P, P, P, P, L, P, P, L, P, P, I, I, I, I, I, I, I, P, P, P, P, P, L, P], I),
+    "vrnet_cluster_ab_reduce_multi": ([I, P, P, P, P, P, P], I),
     "vrnet_dwconv3x3_f32": ([P, L, P, P, L, I, I, I, I, I, I, P], I),
     "vrnet_dwconv3x3_wgrad_workspace": ([I, I, I, I], L),
     "vrnet_dwconv3x3_wgrad_f32": ([P, L, P, L, P, I, I, I, I, I, P, L, P], I),
@@ -110,6 +111,9 @@ _SIGS = {
     "vrnet_yolo_loss_f32": ([P, P, P, P, P, I, I, I, P, P, I, F, P, P, P, P, P, L, P], I),
     "vrnet_seg_loss_workspace": ([I, I, L], L),
     "vrnet_seg_loss_f32": ([P, P, P, P, I, I, L, I, I, F, F, F, F, F, P, P, P, L, P], I),
+    "vrnet_mean_square_workspace": ([I, P], L),
+    "vrnet_mean_square_f32": ([I, P, P, P, P, L, P], I),
+    "vrnet_mean_square_bwd_f32": ([I, P, P, P, P, P], I),
     "vrnet_mt_sgd_f32": ([P, P, P, P, P, I, I, I, F, F, I, I, P], I),
     "vrnet_mt_adam_f32": ([P, P, P, P, P, I, I, I, F, F, F, F, I, P], I),
     "vrnet_mt_ema_f32": ([P, P, P, P, I, I, I, F, P], I),
@@ -605,19 +609,31 @@ def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, dalpha, db
                 fold, alpha2=None, beta2=None, dalpha2=None, dbeta2=None, planes=None, saved=None):
     """planes (Planes of 2 E Dh columns): a second copy of [df | dv] as bf16 planes (single-stream launches).
     saved = (wgt, state) of the forward (regions of more than 256 points): the backward skips its first two passes."""
-    ws = _ws.get(_lib.vrnet_cluster_bwd_workspace2(B, H, W, E, fold), f.device)
-    if planes is not None or f.dtype == torch.bfloat16 or saved is not None:
+    nb = _lib.vrnet_cluster_bwd_workspace2(B, H, W, E, fold)
+    # dalpha is None: the (d alpha, d beta) partials stay in the workspace -- then a buffer of its own, returned to the caller,
+    # who reduces a whole section's modules with one cluster_ab_reduce_multi
+    ws = torch.empty(nb, dtype=torch.uint8, device=f.device) if dalpha is None else _ws.get(nb, f.device)
+    if planes is not None or f.dtype == torch.bfloat16 or saved is not None or dalpha is None:
         assert alpha2 is None and f.dtype == v.dtype == dout.dtype
         wf, st = saved if saved is not None else (None, None)
         _check(_lib.vrnet_cluster_bwd_planes_f32(ptr(f), ptr(v), ld, 1 if f.dtype == torch.bfloat16 else 0, ptr(alpha), ptr(beta),
                                                  ptr(idx), ptr(dout), lddo, ptr(df), ptr(dv), lddf, ptr(dalpha), ptr(dbeta),
                                                  accumulate_ab, B, H, W, E, Dh, fold, _planes_out(planes), ptr(wf), ptr(st),
                                                  ptr(ws), ws.numel(), stream()), "cluster_bwd_planes")
-        return
+        return ws if dalpha is None else None
     _check(_lib.vrnet_cluster_bwd_f32(ptr(f), ptr(v), ld, ptr(alpha), ptr(beta), ptr(idx), ptr(dout), lddo, ptr(df),
                                       ptr(dv), lddf, ptr(dalpha), ptr(dbeta), accumulate_ab, B, H, W, E, Dh, fold,
                                       ptr(alpha2), ptr(beta2), ptr(dalpha2), ptr(dbeta2), ptr(ws), ws.numel(), stream()),
            "cluster_bwd")
+
+
+def cluster_ab_reduce_multi(entries):
+    """entries: [(workspace a deferred cluster_bwd returned, B * E * fold^2, dalpha, dbeta, accumulate)]: ONE launch."""
+    n = len(entries)
+    PA, LA, IA = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+    _check(_lib.vrnet_cluster_ab_reduce_multi(n, PA(*[ptr(e[0]) for e in entries]), LA(*[int(e[1]) for e in entries]),
+                                              PA(*[ptr(e[2]) for e in entries]), PA(*[ptr(e[3]) for e in entries]),
+                                              IA(*[int(e[4]) for e in entries]), stream()), "cluster_ab_reduce_multi")
 
 
 def dwconv3x3(x, ldx, w, y, ldy, B, H, W, C, flip=0, accumulate=0):
@@ -748,3 +764,22 @@ def seg_loss(x, png, onehot, weights, focal, dice, alpha, gamma, beta, smooth, g
     _check(_lib.vrnet_seg_loss_f32(ptr(x), ptr(png), ptr(onehot), ptr(weights), B, C, H * W, int(focal), int(bool(dice)),
                                    float(alpha), float(gamma), float(beta), float(smooth), float(grad_scale), ptr(out),
                                    ptr(dx), ptr(ws), ws.numel(), stream()), "seg_loss")
+
+
+def mean_square(tensors):
+    """loss = sum_k mean(t_k^2) (a 1-element fp32 tensor) over contiguous fp32 tensors: two launches."""
+    k = len(tensors)
+    PA, LA = ctypes.c_void_p * k, ctypes.c_long * k
+    n = LA(*[t.numel() for t in tensors])
+    ws = _ws.get(_lib.vrnet_mean_square_workspace(k, n), tensors[0].device)
+    loss = torch.empty((1,), dtype=torch.float32, device=tensors[0].device)
+    _check(_lib.vrnet_mean_square_f32(k, PA(*[ptr(t) for t in tensors]), n, ptr(loss), ptr(ws), ws.numel(), stream()), "mean_square")
+    return loss
+
+
+def mean_square_bwd(tensors, g, grads):
+    """grads[k] = (2 g / n_k) tensors[k]; g: 1-element device tensor."""
+    k = len(tensors)
+    PA, LA = ctypes.c_void_p * k, ctypes.c_long * k
+    _check(_lib.vrnet_mean_square_bwd_f32(k, PA(*[ptr(t) for t in tensors]), LA(*[t.numel() for t in tensors]), ptr(g),
+                                          PA(*[ptr(t) for t in grads]), stream()), "mean_square_bwd")

@@ -171,3 +171,31 @@ def training_loss(yolo_loss, outputs, outputs_seg, targets, pngs, seg_labels, we
     loss_det = yolo_loss(outputs, targets)
     seg5 = _seg(outputs_seg, pngs, seg_labels if dice_loss else None, weights, focal=focal_loss, dice=dice_loss, scale=5.0)
     return loss_det + seg5, loss_det, seg5 / 5.0
+
+
+class _MeanSquareFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *tensors):
+        ts = [t.contiguous() for t in tensors]
+        ctx.save_for_backward(*ts)
+        with torch.cuda.device(ts[0].device):
+            return hip.mean_square(ts).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ts = ctx.saved_tensors
+        grads = [torch.empty_like(t) for t in ts]
+        with torch.cuda.device(ts[0].device):
+            hip.mean_square_bwd(list(ts), g.reshape(1).contiguous().float(), grads)
+        return tuple(grads)
+
+
+def mean_square_loss(det, seg):
+    """The synthetic scalar that drives a backward pass without the reference's real losses:
+    L = sum_k mean(det_k^2) + mean(seg^2) -- value and gradient as `sum((d * d).mean() for d in det) + (seg * seg).mean()`
+    and its autograd, in three launches (value: fp64 partials in a fixed order; gradient: (2 g / n_k) t_k) instead of ~27
+    eager elementwise / reduce launches between the forward and the backward pass."""
+    ts = list(det) + [seg]
+    if not all(t.is_cuda and t.dtype == torch.float32 for t in ts):
+        raise RuntimeError("mean_square_loss: fp32 tensors on a HIP device")
+    return _MeanSquareFn.apply(*ts)

@@ -107,6 +107,8 @@ class RT:
         self.tape_pos = 0           # index of the top-level tape closure being replayed
         self.concurrent = True      # fork independent chains (image / radar, seg / det, head levels) onto side streams
         self.pair_streams = False   # True: image + radar chain of a backbone stage as ONE two-stream batch (one launch per layer)
+        self.prep = None            # WeightPrep: this forward's weight packs, issued on a side stream (forward_pass)
+        self.pending_ab = []        # deferred (d alpha, d beta) reductions of the Cluster modules of the section being replayed
         self.sync_batch_total = None   # SyncBatchNorm: global sample count of THIS forward pass
         self.via_autograd = False   # parameter gradients go back through torch.autograd (stock DistributedDataParallel)
 
@@ -272,6 +274,20 @@ class RT:
         self.pgrads.clear()
         self._aside_batches = []
         self._deferred_wgrads = []
+        self.pending_ab = []
+
+    def flush_cluster_ab(self):
+        """ONE launch finishes (d alpha, d beta) of every Cluster module whose backward kernel ran since the last flush (they
+        left per-workgroup partials in buffers of their own): called on the main stream once the section's chains have joined,
+        instead of one finishing launch on the chain behind each of the 27 Cluster backward kernels."""
+        if not self.pending_ab:
+            return
+        work, self.pending_ab = self.pending_ab, []
+        hip.cluster_ab_reduce_multi([(ws, nb, ga, gb, acc) for ws, nb, ga, gb, acc, _ in work])
+        if self.on_param_grad:
+            for *_, tm in work:
+                self.on_param_grad(tm.sim_alpha)
+                self.on_param_grad(tm.sim_beta)
 
     def buf(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -292,11 +308,23 @@ class RT:
         if kh * kw == 1:
             return w
         p = self.packed.get(conv)
+        if p is None and self.prep is not None:
+            p = self.prep.conv_pack(conv)          # packed at the start of the forward on the preparation stream
+            if p is not None:
+                self.packed[conv] = p
         if p is None:
             p = self.buf(kh * kw, co, ci)
             hip.pack_weight(w, p, co, ci, kh, kw)
             self.packed[conv] = p
         return p
+
+    def mlp_packs(self, mlp, C, hid, pmlp):
+        """(forward, backward) weight planes of a fused Mlp (hip.mlp_pack): from the preparation stream when it made them."""
+        if self.prep is not None:
+            got = self.prep.mlp_pack(mlp, pmlp, self.record)
+            if got is not None:
+                return got
+        return hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, pmlp, want_bwd=self.record)
 
     def prec_fwd(self, lda, ci, co):
         """precision flag of a forward conv launch: 1 = bf16-rounded operands (compute_dtype "bf16"); 2 = fp32 products
@@ -320,6 +348,8 @@ class RT:
         an x6 tile kernel, or the planes are switched off).  mode 0: w is [J = Cout][K = Cin]; mode 1: [K = Cout][J = Cin]."""
         if self.wplanes is None or self.bf16 or self.fp32_precision != 2 or K % 16 or not hip.conv2d_dma_plan(rows, J, K)[0]:
             return None
+        if self.prep is not None and not self.prep._wait("all", self.prep.ev_all):
+            return None         # (a forked chain ahead of the preparation stream's join: the in-kernel split path)
         sj, sk = (K, 1) if mode == 0 else (1, J)
         return self.wplanes.get((id(w), mode), w, J, K, sj, sk, kscale)
 
@@ -848,7 +878,7 @@ def cluster_block(rt, x, m, name=None):
     if pmlp:
         # fc1 -> GELU -> fc2 (+ layer-scale residual, + GroupNorm statistics of the output) as ONE kernel: the hidden
         # activation never reaches HBM; only the pre-activation is stored, for the backward pass
-        packs = hip.mlp_pack(mlp0.fc1.weight, mlp0.fc2.weight, C, hid, pmlp, want_bwd=rt.record)
+        packs = rt.mlp_packs(mlp0, C, hid, pmlp)
         pairs, per = hip.conv_stats_buffer(B, H * W, C, x.t.device)
         hip.mlp_fwd(xn2.t, xn2.ld, packs[0], mlp0.fc1.bias, mlp0.fc2.bias, x1.t, x1.ld, ls2, x2.t, C,
                     None if u is None else u.t, hid, pairs, B * H * W, C, hid, pmlp)
@@ -894,13 +924,17 @@ def cluster_block(rt, x, m, name=None):
             kwb = dict(alpha2=tm1.sim_alpha, beta2=tm1.sim_beta, dalpha2=ga2, dbeta2=gb2)
         if cstate is not None:
             kwb["saved"] = (wgt, cstate)
-        hip.cluster_bwd(f_t, v_t, 2 * ED, tm0.sim_alpha, tm0.sim_beta, idx, do.t, ED, dfv.t, dfv.t[..., ED:], 2 * ED, ga, gb,
-                        acca, B, H, W, E, Dh, fold, **kwb)
-        if rt.on_param_grad:
-            for t in (tm0, tm1):
-                if t is not None:
+        if paired:
+            hip.cluster_bwd(f_t, v_t, 2 * ED, tm0.sim_alpha, tm0.sim_beta, idx, do.t, ED, dfv.t, dfv.t[..., ED:], 2 * ED, ga, gb,
+                            acca, B, H, W, E, Dh, fold, **kwb)
+            if rt.on_param_grad:
+                for t in (tm0, tm1):
                     rt.on_param_grad(t.sim_alpha)
                     rt.on_param_grad(t.sim_beta)
+        else:       # the two scalars are finished by the section's ONE rt.flush_cluster_ab() launch
+            ws_ab = hip.cluster_bwd(f_t, v_t, 2 * ED, tm0.sim_alpha, tm0.sim_beta, idx, do.t, ED, dfv.t, dfv.t[..., ED:], 2 * ED,
+                                    None, None, 0, B, H, W, E, Dh, fold, **kwb)
+            rt.pending_ab.append((ws_ab, B * E * max(fold, 1) ** 2, ga, gb, acca, tm0))
         _fused_qkv_wgrad(rt, tm, xn, dfv)
         dxn = rt.new(B, H, W, C)                                 # d xn = [df | dv] . [fc1 ; fc_v]: one data-gradient GEMM
         wd, _, prec = rt.dgrad_operands(tm0, wcat, wcat, 2 * ED, C, 1, 1, None, 2 * ED, B * H * W)
@@ -1036,7 +1070,7 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
             hip.planes_from_f32(xn2_f.t, C, M, C, xn2_p)
     h_f = h_p = packs = None
     if pmlp:
-        packs = hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, pmlp, want_bwd=rec)
+        packs = rt.mlp_packs(mlp, C, hid, pmlp)
         pairs, per = stats_buf(C)
         hip.mlp_fwd(xn2_f.t, C, packs[0], mlp.fc1.bias, mlp.fc2.bias, x1.t, x1.ld, ls2, x2.t, C,
                     None if u is None else (u_b if mlp_hb else u.t), hid, pairs, M, C, hid, 4 if mlp_hb else pmlp)
@@ -1170,12 +1204,10 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
         dfv_p = P(2 * ED) if (fcfv[1] or fcfv[2]) else None
         dfv = f32(2 * ED) if (not fcfv[1] or not fcfv[2]) else None
         (ga, gb_), acca = _pgrads_or_scratch(rt, (tm.sim_alpha, tm.sim_beta), (1, 1))
-        hip.cluster_bwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, idx, do_t, ED, None if dfv is None else dfv.t,
-                        None if dfv is None else dfv.t[..., ED:], 2 * ED, ga, gb_, acca, B, H, W, E, Dh, fold, planes=dfv_p,
-                        saved=None if cstate is None else (wgt, cstate))
-        if rt.on_param_grad:
-            rt.on_param_grad(tm.sim_alpha)
-            rt.on_param_grad(tm.sim_beta)
+        ws_ab = hip.cluster_bwd(f_t, v_t, 2 * ED, tm.sim_alpha, tm.sim_beta, idx, do_t, ED, None if dfv is None else dfv.t,
+                                None if dfv is None else dfv.t[..., ED:], 2 * ED, None, None, 0, B, H, W, E, Dh, fold, planes=dfv_p,
+                                saved=None if cstate is None else (wgt, cstate))
+        rt.pending_ab.append((ws_ab, B * E * max(fold, 1) ** 2, ga, gb_, acca, tm))    # finished by rt.flush_cluster_ab()
         if fcfv[2]:
             _fused_qkv_wgrad(rt, tm, xn_p, dfv_p, planes=True)
         else:
@@ -1575,6 +1607,8 @@ def backbone_forward(rt, bb, x, r):
     xr = rt.new_pair(2 * B, H // 4, W // 4, dims[0])             # stage-0 input: both patch embeddings
     xh, rh = xr.halves()
     rt.parallel([lambda: embed(xe, bb.patch_embed, out=xh), lambda: embed(re_, bb.patch_embed_radar, out=rh)], site=1)
+    if rt.prep is not None:
+        rt.prep.wait_all()          # the first consumers of the weight planes / Mlp packs / [fc1 ; fc_v] copies: stage 0
     for i in range(4):
         pi, pr = f"backbone.backbone.network.{3 * i}", f"backbone.backbone.network_radar.{3 * i}"
         if can_pair(xr.H, xr.W, i):
@@ -1774,6 +1808,84 @@ class PlaneWeights:
         return self.get((id(w), 1), w, ci, co, 1, ci, kscale)
 
 
+class WeightPrep:
+    """The per-step weight preparation of a forward pass -- the [fc1 ; fc_v] copies (FusedQKV), the bf16 planes of every 1x1
+    weight (WeightPlanes / PlaneWeights), the fragment-order planes of the fused Mlps (hip.mlp_pack) and the tap-major packs of
+    the k x k convs (hip.pack_weight) -- issued at the START of the forward on a side stream, where it runs beside the input
+    fusion at full resolution (layout transposes, 3 / 4-channel convs, their BatchNorms: about a millisecond that needs none
+    of it) instead of ahead of it and, for the Mlp / conv packs, in front of each first use on the chain (round 4: ~0.16 ms of
+    plane split exclusive at the head of the step, 16 + 14 small pack launches on the chains).  Two events: `small` (the k x k
+    packs, issued first: the first 3 x 3 conv is the fourth kernel of the forward) and `all`.  A consumer waits for its event
+    on whatever stream it runs on (fork / join edges under hipGraph capture); buffers come from the side stream's pool and
+    are ordered against the next forward by its opening wait_stream."""
+
+    _streams = {}
+
+    def __init__(self, rt, model, refresh):
+        self.rt = weakref.ref(rt)      # (rt -> prep -> rt would be a cycle that keeps a forward's activations alive until the
+        self.device = rt.device        #  collector runs: test_forward_without_backward_frees_its_activations_at_once)
+        dev = rt.device
+        cur = torch.cuda.current_stream(dev)
+        st = WeightPrep._streams.get(dev)
+        if st is None:
+            st = WeightPrep._streams[dev] = torch.cuda.Stream(dev)
+        self.convs, self.mlps = {}, {}
+        self.waited = {}            # (event name, stream id) -> True
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            for mod in model.modules():
+                w = getattr(mod, "weight", None)
+                if isinstance(mod, torch.nn.Conv2d) and mod.groups == 1 and w.shape[2] * w.shape[3] > 1 and \
+                        w.shape[2] != mod.stride[0]:        # (k == stride: the patch embeddings, which run as gather + GEMM)
+                    co, ci, kh, kw = w.shape
+                    p = rt.buf(kh * kw, co, ci)
+                    hip.pack_weight(w, p, co, ci, kh, kw)
+                    self.convs[mod] = p
+            self.ev_small = torch.cuda.Event()
+            self.ev_small.record(st)
+            refresh()
+            if rt.fused_mlp and (rt.bf16 or rt.fp32_precision == 2):
+                prec = 1 if rt.bf16 else 2
+                for mod in model.modules():
+                    mlp = getattr(mod, "mlp", None)
+                    if mlp is None or not hasattr(mod, "token_mixer"):
+                        continue
+                    hid, C = mlp.fc1.weight.shape[0], mlp.fc1.weight.shape[1]
+                    if hip.mlp_fused_ok(C, hid, 32):
+                        self.mlps[mlp] = (prec, hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, prec, want_bwd=rt.record))
+            self.ev_all = torch.cuda.Event()
+            self.ev_all.record(st)
+        self.stream = st
+
+    def _wait(self, name, ev):
+        """Orders the packs behind `ev` before whatever the MAIN chain's stream runs next; False when called from a forked
+        chain before the main chain has waited (hipGraph capture on ROCm 7 only takes a star of streams: a side stream must
+        not wait for another side stream -- the caller then does without the prepared pack)."""
+        if name in self.waited or "all" in self.waited:
+            return True
+        rt = self.rt()
+        if rt is None or rt._chain != "main":
+            return False
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        self.waited[name] = True
+        return True
+
+    def conv_pack(self, conv):
+        p = self.convs.get(conv)
+        return p if (p is not None and self._wait("small", self.ev_small)) else None
+
+    def mlp_pack(self, mlp, pmlp, record):
+        ent = self.mlps.get(mlp)
+        if ent is None or ent[0] != pmlp or not self._wait("all", self.ev_all):
+            return None
+        return ent[1]
+
+    def wait_all(self):
+        """On the main chain, before the first ClusterBlock: the [fc1 ; fc_v] copies, the weight planes and the Mlp packs."""
+        ok = self._wait("all", self.ev_all)
+        assert ok, "WeightPrep.wait_all() belongs on the main chain"
+
+
 class FusedQKV:
     """Concatenated [fc1 ; fc_v] weights and biases of every Cluster module (vr_coc.py:145-147): both 1x1 convs read
     the same normalised input, so each block runs them as ONE GEMM with 2*E*D output channels (twice the tiles of the
@@ -1869,12 +1981,12 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         fq = getattr(model, "_fused_qkv", None)
         if fq is None or fq.owner != id(model) or fq.dst[0].device != x.device:
             fq = model._fused_qkv = FusedQKV(model, x.device)
-        fq.refresh()
+        refreshes = [fq.refresh]
         if getattr(model, "weight_planes", True) and not rt.bf16 and rt.fp32_precision == 2:
             wp = getattr(model, "_weight_planes", None)
             if wp is None or wp.owner != id(model) or wp.device != x.device:
                 wp = model._weight_planes = WeightPlanes(model, x.device)
-            wp.refresh()                       # after fq.refresh(): the concatenated fc1 | fc_v weights are sources too
+            refreshes.append(wp.refresh)       # after fq.refresh(): the concatenated fc1 | fc_v weights are sources too
             rt.wplanes = wp
         # plane GEMMs in the ClusterBlocks (csrc/pgemm.hip): model.plane_gemms = None (default: see below), False, True or a
         # string of GEMM kinds "fwd", "wgrad", "fwd+wgrad"
@@ -1888,8 +2000,16 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
             pwts = getattr(model, "_plane_weights", None)
             if pwts is None or pwts.owner != id(model) or pwts.device != x.device or pwts.np != rt.pnp:
                 pwts = model._plane_weights = PlaneWeights(model, x.device, rt.pnp)
-            pwts.refresh()
+            refreshes.append(pwts.refresh)
             rt.pweights = pwts
+
+        def refresh_all():
+            for fn in refreshes:
+                fn()
+        if rt.concurrent and getattr(model, "weight_prep_stream", True):
+            rt.prep = WeightPrep(rt, model, refresh_all)      # on a side stream, beside the input fusion
+        else:
+            refresh_all()
         xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=need_dx)
         ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=need_dr)
         hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)
@@ -1937,6 +2057,7 @@ def backward_range(rt, lo, hi, flush_each=False):
         for i in range(hi - 1, lo - 1, -1):
             rt.tape_pos = i
             rt.tape[i]()
+            rt.flush_cluster_ab()
             done = rt.join_aside(0 if flush_each else ASIDE_LAG)
             if flush_each:
                 rt.flush_deferred_wgrads()
@@ -1948,6 +2069,7 @@ def backward_cut(rt):
     """Every gradient kernel issued so far is ordered before whatever the current stream runs next (joins the
     side streams): the point where a captured segment ends / a bucket's collective may start."""
     with torch.cuda.device(rt.device):
+        rt.flush_cluster_ab()
         done = rt.join_aside(0)
         rt.flush_deferred_wgrads()
         done += _take_ready(rt)

@@ -116,6 +116,14 @@ def conv_flops(B, H, W, Cin, OH, OW, Cout, kh, kw, stride, pad, dil):
 
 
 def loss_of(det, seg):
+    """The fixed synthetic scalar that drives the backward pass: L = sum_k mean(det_k^2) + mean(seg^2).  On the GPU
+    it is evaluated, with its gradient, by asy_vrnet_amd.losses.mean_square_loss (three launches; the same value and gradient
+    as the eager torch expression below, tests/test_loss.py) -- the ~27 eager elementwise / reduce launches of the torch form
+    sat between the forward and the backward pass, 0.25 ms of the timed step that is the harness's, not the path's.  The CPU
+    baseline (tensors on the host) evaluates the torch form."""
+    if seg.is_cuda:
+        from asy_vrnet_amd.losses import mean_square_loss
+        return mean_square_loss(det, seg)
     return sum((d * d).mean() for d in det) + (seg * seg).mean()
 
 

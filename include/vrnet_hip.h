@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------- */
-int vrnet_abi_version(void);                 /* == 8 */
+int vrnet_abi_version(void);                 /* == 9 */
 /* Kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to: 1 fp32 MFMA
  * (register-staged), 2 fp32 MFMA (LDS-DMA ring), 3 bf16-rounded operands, 4 direct kernels for tiny channel counts,
  * 5 direct HBM-streaming kernels for 1x1 convs with <= 16 output channels over wide inputs (head predictions, seg logits),
@@ -409,12 +409,21 @@ int vrnet_cluster_fwd_forced_f32(const float* f, const float* v, long ld, const 
                                  int fold, const float* alpha2, const float* beta2, void* stream);
 long vrnet_cluster_bwd_workspace(int B, int E, int fold);                          /* regions of <= 256 points */
 long vrnet_cluster_bwd_workspace2(int B, int H, int W, int E, int fold);            /* any region size */
-/* Recomputes the forward from f, v with the saved assignment idx; df, dv share row stride lddf. */
+/* Recomputes the forward from f, v with the saved assignment idx; df, dv share row stride lddf.
+ * dalpha == dbeta == NULL (single-stream launches, also of vrnet_cluster_bwd_planes_f32; ABI 9): the per-workgroup (d alpha,
+ * d beta) partials stay in the first 2 * B * E * fold^2 floats of `workspace` and no finishing launch runs -- the caller keeps
+ * that workspace to itself and reduces a whole section's modules later with ONE vrnet_cluster_ab_reduce_multi. */
 int vrnet_cluster_bwd_f32(const float* f, const float* v, long ld, const float* alpha, const float* beta,
                           const unsigned char* idx, const float* dout, long lddo, float* df, float* dv, long lddf,
                           float* dalpha, float* dbeta, int accumulate_ab, int B, int H, int W, int E, int D,
                           int fold, const float* alpha2, const float* beta2, float* dalpha2, float* dbeta2,
                           void* workspace, long workspace_bytes, void* stream);
+
+/* (d alpha, d beta) of n Cluster modules (vr_coc.py:148-149: sim_alpha, sim_beta are shared by all regions and heads of a
+ * module) from the partials their backward launches left (above): host arrays of n workspaces, their B * E * fold^2, the
+ * gradient scalars (device) and accumulate flags; one launch per 32 modules. */
+int vrnet_cluster_ab_reduce_multi(int n, const void* const* partial, const long* blocks, float* const* dalpha,
+                                  float* const* dbeta, const int* accumulate, void* stream);
 
 /* ---- depthwise 3x3, stride 1, pad 1 (DWConv.dconv, normal_conv.py:26-27; head towers decouplehead.py:23-34)
  * w: [C][3][3] (the OIHW tensor of a groups=C conv).  flip = 1 gives the input gradient. */
@@ -515,6 +524,16 @@ long vrnet_seg_loss_workspace(int B, int C, long HW);
 int vrnet_seg_loss_f32(const float* x, const long long* png, const float* onehot, const float* weights, int B, int C,
                        long HW, int focal, int dice, float alpha, float gamma, float beta, float smooth, float grad_scale,
                        float* out, float* dx, void* workspace, long workspace_bytes, void* stream);
+
+/* ---- the synthetic backward driver: loss[0] = sum_k mean(t_k^2) over k <= 8 contiguous fp32 tensors -- the det maps
+ * and the seg logits -- and its gradient grad_k = (2 g / n_k) t_k, g = upstream gradient of the scalar (device).  t, n, grad:
+ * HOST arrays of device pointers / element counts.  Replaces the eager `sum((d * d).mean()) + (seg * seg).mean()` of the
+ * reference's own smoke test (vr_coc.py:817-830 builds the same kind of scalar) and its autograd: ~27 launches -> 3. */
+long vrnet_mean_square_workspace(int k, const long* n);
+int vrnet_mean_square_f32(int k, const void* const* t, const long* n, float* loss, void* workspace, long workspace_bytes,
+                          void* stream);
+int vrnet_mean_square_bwd_f32(int k, const void* const* t, const long* n, const float* g, void* const* grad, void* stream);
+
 
 #ifdef __cplusplus
 }

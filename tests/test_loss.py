@@ -151,3 +151,25 @@ def test_hip_seg_losses_match_oracle_and_reference():
     assert rel(ins[1].grad.cpu(), z["yolo_grad1"]) < 2e-5
     with pytest.raises(RuntimeError):
         losses.CE_Loss(seg[:, :, ::2, ::2].contiguous().cuda(), pngs.cuda(), None, num_classes=NS)
+
+
+@pytest.mark.gpu
+def test_mean_square_driver_matches_the_torch_expression():
+    """losses.mean_square_loss -- the synthetic scalar behind bench.py's backward pass -- against the eager torch
+    expression it replaces: value 1e-6, gradients 1e-6 (also with an upstream gradient other than 1), repeatable bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from asy_vrnet_amd.losses import mean_square_loss
+    g = torch.Generator().manual_seed(3)
+    shapes = [(2, 9, 64, 64), (2, 9, 32, 32), (2, 9, 16, 16), (2, 9, 512, 512)]
+    ts = [torch.randn(s, generator=g).cuda().requires_grad_() for s in shapes]
+    ref = [t.detach().clone().requires_grad_() for t in ts]
+    want = sum((d * d).mean() for d in ref[:3]) + (ref[3] * ref[3]).mean()
+    (want * 0.7).backward()
+    got = mean_square_loss(ts[:3], ts[3])
+    (got * 0.7).backward()
+    assert abs(float(got.detach()) - float(want.detach())) < 1e-6 * abs(float(want.detach()))
+    for a, b in zip(ts, ref):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-12)
+    again = mean_square_loss([t.detach() for t in ts[:3]], ts[3].detach())
+    assert torch.equal(again, got.detach())
