@@ -624,6 +624,46 @@ __global__ void enhance_mul_kernel(const float* p, const float* x, const float* 
     out[e] = (1.f + (p[e] - mn) / dst) * x[e];
 }
 
+// The same with the final step of the min / max reduction INSIDE (round 5): every workgroup folds the <= 512 partial pairs
+// minmax_partial_kernel left (fminf / fmaxf: the same bits whatever the order) and workgroup 0 also leaves (min, max) in mm for
+// the backward pass -- one launch less on the chain of every ImageEnhanceByRadar block.
+__global__ __launch_bounds__(256) void enhance_fwd_kernel(const float* p, const float* x, const float* partial, int nblocks,
+                                                          float* mm, float* out, long n, int vec) {
+  __shared__ float smn[4], smx[4];
+  float mn = INFINITY, mx = -INFINITY;
+  for (int e = threadIdx.x; e < nblocks; e += 256) {
+    mn = fminf(mn, partial[2 * e]);
+    mx = fmaxf(mx, partial[2 * e + 1]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+  mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  if (blockIdx.x == 0 && threadIdx.x == 0) { mm[0] = mn; mm[1] = mx; }
+  const float dst = mx - mn;
+  if (vec) {
+    const long n4 = n >> 2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(p + 4 * e), xv = *reinterpret_cast<const f32x4*>(x + 4 * e);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (1.f + (pv[j] - mn) / dst) * xv[j];
+      *reinterpret_cast<f32x4*>(out + 4 * e) = o;
+    }
+  } else {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+      out[e] = (1.f + (p[e] - mn) / dst) * x[e];
+  }
+}
+
 // sums: [0] sum dn, [1] sum dn*(p-mn), [2] #(p == mn), [3] #(p == mx)   with dn = dt * x
 __global__ __launch_bounds__(256) void enhance_bwd_partial_kernel(const float* dt, const float* x, const float* p,
                                                                   const float* mm, long n, double* partial) {
@@ -647,29 +687,33 @@ __global__ __launch_bounds__(256) void enhance_bwd_partial_kernel(const float* d
   if (threadIdx.x < 4) partial[4 * (long)blockIdx.x + threadIdx.x] =
       red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ __launch_bounds__(256) void enhance_bwd_final_kernel(const double* partial, int nblocks, double* sums) {
-  __shared__ double red[4][4];
-  double s[4] = {0, 0, 0, 0};
-  for (int e = threadIdx.x; e < nblocks; e += 256)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s[i] += partial[4 * (long)e + i];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]);
-  if ((threadIdx.x & 63) == 0)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) red[threadIdx.x >> 6][i] = s[i];
-  __syncthreads();
-  if (threadIdx.x < 4) sums[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
 // dx (+)= dt * (1 + n);  dp = dn/dst + [p==mn] g_mn/cnt_mn + [p==mx] g_mx/cnt_mx
-__global__ void enhance_bwd_apply_kernel(const float* dt, const float* x, const float* p, const float* mm,
-                                         const double* sums, float* dx, float* dp, long n, int accumulate_dx) {
+__global__ __launch_bounds__(256) void enhance_bwd_apply_kernel(const float* dt, const float* x, const float* p, const float* mm,
+                                                                const double* partial, int nblocks, float* dx, float* dp, long n,
+                                                                int accumulate_dx) {
+  // (round 5) the four sums are finished HERE: every workgroup adds the <= 256 partial quadruples in the same fixed order
+  __shared__ double red[4][4];
+  __shared__ double sums[4];
+  {
+    double s[4] = {0, 0, 0, 0};
+    for (int e = threadIdx.x; e < nblocks; e += 256)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[i] += partial[4 * (long)e + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = wave_sum(s[i]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[threadIdx.x >> 6][i] = s[i];
+    __syncthreads();
+    if (threadIdx.x < 4) sums[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    __syncthreads();
+  }
   const float mn = mm[0], mx = mm[1];
   const double dst = (double)mx - (double)mn;
   const float gmn = (float)((-sums[0] / dst + sums[1] / (dst * dst)) / sums[2]);
   const float gmx = (float)((-sums[1] / (dst * dst)) / sums[3]);
   const float fd = (float)dst;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
     const float pv = p[e], g = dt[e];
     const float gain = 1.f + (pv - mn) / fd;
     const float vx = g * gain;
@@ -1015,20 +1059,35 @@ extern "C" int vrnet_enhance_mul_f32(const float* p, const float* x, const float
   return VR_OK;
 }
 
+/* t = (1 + data_normal(p)) * x with the batch-wide (min, max) of p found on the way (left in mm[0..1] for the backward pass):
+ * vrnet_minmax_f32 + vrnet_enhance_mul_f32 as TWO launches instead of three (the final min / max step runs inside the apply
+ * kernel).  Same results as the two calls. */
+extern "C" int vrnet_enhance_fwd_f32(const float* p, const float* x, float* mm, float* out, long n, void* workspace,
+                                     long workspace_bytes, void* stream) {
+  VR_CHECK_ARG(p && x && mm && out && workspace && n > 0, "enhance_fwd: bad arguments");
+  VR_CHECK_ARG(workspace_bytes >= vrnet_reduce_workspace(), "enhance_fwd: workspace too small");
+  const int nb = (int)grid_for(n, 2048, 512);
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipStream_t st = vr_stream(stream);
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(256), 0, st, p, n, partial);
+  VR_LAUNCH_CHECK("minmax_partial");
+  const int vec = ((n & 3) == 0 && vr_aligned16(p) && vr_aligned16(x) && vr_aligned16(out)) ? 1 : 0;
+  hipLaunchKernelGGL(enhance_fwd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, st, p, x, partial, nb, mm, out, n, vec);
+  VR_LAUNCH_CHECK("enhance_fwd");
+  return VR_OK;
+}
+
 extern "C" int vrnet_enhance_bwd_f32(const float* dt, const float* x, const float* p, const float* mm, float* dx,
                                      float* dp, long n, int accumulate_dx, void* workspace, long workspace_bytes,
                                      void* stream) {
   VR_CHECK_ARG(dt && x && p && mm && dx && dp && workspace && n > 0, "enhance_bwd: bad arguments");
   VR_CHECK_ARG(workspace_bytes >= vrnet_reduce_workspace(), "enhance_bwd: workspace too small");
-  const int nb = (int)grid_for(n, 2048, 2048);
+  const int nb = (int)grid_for(n, 2048, 256);       // few partials: every workgroup of the apply kernel re-adds them
   double* partial = reinterpret_cast<double*>(workspace);
-  double* sums = partial + 4L * nb;
   hipStream_t st = vr_stream(stream);
   hipLaunchKernelGGL(enhance_bwd_partial_kernel, dim3(nb), dim3(256), 0, st, dt, x, p, mm, n, partial);
   VR_LAUNCH_CHECK("enhance_bwd_partial");
-  hipLaunchKernelGGL(enhance_bwd_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, sums);
-  VR_LAUNCH_CHECK("enhance_bwd_final");
-  hipLaunchKernelGGL(enhance_bwd_apply_kernel, dim3(grid_for(n)), dim3(256), 0, st, dt, x, p, mm, sums, dx, dp, n,
+  hipLaunchKernelGGL(enhance_bwd_apply_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, st, dt, x, p, mm, partial, nb, dx, dp, n,
                      accumulate_dx);
   VR_LAUNCH_CHECK("enhance_bwd_apply");
   return VR_OK;

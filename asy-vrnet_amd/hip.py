@@ -101,6 +101,7 @@ _SIGS = {
     "vrnet_reduce_workspace": ([], L),
     "vrnet_minmax_f32": ([P, L, P, P, L, P], I),
     "vrnet_enhance_mul_f32": ([P, P, P, P, L, P], I),
+    "vrnet_enhance_fwd_f32": ([P, P, P, P, L, P, L, P], I),
     "vrnet_enhance_bwd_f32": ([P, P, P, P, P, P, L, I, P, L, P], I),
     "vrnet_sa_coef_fwd": ([P] * 7 + [I, L, I, I, P, P, P, P], I),
     "vrnet_sa_apply_f32": ([P, L, P, P, P, P, L, I, L, I, P], I),
@@ -664,6 +665,12 @@ def minmax(p, n, mm):
 
 def enhance_mul(p, x, mm, out, n):
     _check(_lib.vrnet_enhance_mul_f32(ptr(p), ptr(x), ptr(mm), ptr(out), n, stream()), "enhance_mul")
+
+
+def enhance_fwd(p, x, mm, out, n):
+    """minmax + enhance_mul in two launches; mm receives (min, max)."""
+    ws = _ws.get(_lib.vrnet_reduce_workspace(), p.device)
+    _check(_lib.vrnet_enhance_fwd_f32(ptr(p), ptr(x), ptr(mm), ptr(out), n, ptr(ws), ws.numel(), stream()), "enhance_fwd")
 
 
 def enhance_bwd(dt, x, p, mm, dx, dp, n, accumulate_dx=0):

@@ -653,7 +653,7 @@ def bn_forward(rt, z, bn, relu, out=None, residual=None):
                x2=None if residual is None else residual.t, ld2=0 if residual is None else residual.ld)
     if relu and rt.relu_masks is not None:
         rt.relu_masks[bn] = y
-    if relu and residual is None:
+    if relu:
         ms.fwd_coef = (A, D, S)      # bn_backward recomputes the ReLU mask from z with these instead of reading y
     return y, ms
 
@@ -1305,10 +1305,9 @@ def image_enhance(rt, x, r, m, out=None):
     p, ms1 = bn_forward(rt, z, bn1, relu=True)
     mm = rt.buf(2)
     n = p.t.numel()
-    hip.minmax(p.t, n, mm)
     t = rt.new(B, H, W, C)
     assert x.ld == C, "image map must be contiguous"
-    hip.enhance_mul(p.t, x.t, mm, t.t, n)
+    hip.enhance_fwd(p.t, x.t, mm, t.t, n)           # min / max of p and the gain in two launches (three before round 5)
     y, ms2 = bn_forward(rt, t, m.norm, relu=False, out=out)
 
     def bwd():
@@ -1424,9 +1423,15 @@ def radar_enhance(rt, x, r, m, out=None):
     B, H, W, C = r.B, r.H, r.W, r.C
     z = rt.new(B, H, W, C)
     conv_call(rt, u, conv, z, bias=False, bn_stats=True)
-    q, ms1 = bn_forward(rt, z, bn1, relu=True)
-    s = rt.new(B, H, W, C)
-    hip.affine(s.t, C, B, H * W, C, x1=q.t, ld1=C, x2=r.t, ld2=r.ld)
+    if BN_ZMASK and rt.relu_masks is None:
+        # s = ReLU(BN(z)) + r in ONE apply launch; the ReLU output itself is never stored: the backward pass recomputes its
+        # mask from z with the forward coefficients (bn_backward, zmask form).  (round 5: -1 launch, -2 tensor passes per level)
+        s, ms1 = bn_forward(rt, z, bn1, relu=True, residual=r)
+        q = s                        # (stands in for "there is a ReLU": the zmask backward never reads it)
+    else:
+        q, ms1 = bn_forward(rt, z, bn1, relu=True)
+        s = rt.new(B, H, W, C)
+        hip.affine(s.t, C, B, H * W, C, x1=q.t, ld1=C, x2=r.t, ld2=r.ld)
     y, ms2 = bn_forward(rt, s, m.norm, relu=False, out=out)
 
     def bwd():

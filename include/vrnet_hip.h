@@ -446,6 +446,10 @@ int vrnet_upsample_bilinear_bwd_f32(const float* dy, long lddy, int dy_nchw, flo
 long vrnet_reduce_workspace(void);
 int vrnet_minmax_f32(const float* p, long n, float* mm /* [2] */, void* workspace, long workspace_bytes, void* stream);
 int vrnet_enhance_mul_f32(const float* p, const float* x, const float* mm, float* out, long n, void* stream);
+/* vrnet_minmax_f32 + vrnet_enhance_mul_f32 in two launches instead of three (the final min / max step runs inside the apply
+ * kernel); mm receives (min, max) for vrnet_enhance_bwd_f32.  workspace: vrnet_reduce_workspace() bytes.  (ABI 9) */
+int vrnet_enhance_fwd_f32(const float* p, const float* x, float* mm, float* out, long n, void* workspace, long workspace_bytes,
+                          void* stream);
 int vrnet_enhance_bwd_f32(const float* dt, const float* x, const float* p, const float* mm, float* dx, float* dp,
                           long n, int accumulate_dx, void* workspace, long workspace_bytes, void* stream);
 
