@@ -110,6 +110,7 @@ class RT:
         self.prep = None            # WeightPrep: this forward's weight packs, issued on a side stream (forward_pass)
         self.pending_ab = []        # deferred (d alpha, d beta) reductions of the Cluster modules of the section being replayed
         self.sync_batch_total = None   # SyncBatchNorm: global sample count of THIS forward pass
+        self.overlap_fusion = True
         self.via_autograd = False   # parameter gradients go back through torch.autograd (stock DistributedDataParallel)
 
     # ---- fork / join of independent chains -------------------------------------------------------------
@@ -1423,7 +1424,7 @@ def radar_enhance(rt, x, r, m, out=None):
     B, H, W, C = r.B, r.H, r.W, r.C
     z = rt.new(B, H, W, C)
     conv_call(rt, u, conv, z, bias=False, bn_stats=True)
-    if BN_ZMASK and rt.relu_masks is None:
+    if BN_ZMASK and rt.relu_masks is None and rt.sync_bn is None:      # (synchronised BatchNorm reads the ReLU output as its mask)
         # s = ReLU(BN(z)) + r in ONE apply launch; the ReLU output itself is never stored: the backward pass recomputes its
         # mask from z with the forward coefficients (bn_backward, zmask form).  (round 5: -1 launch, -2 tensor passes per level)
         s, ms1 = bn_forward(rt, z, bn1, relu=True, residual=r)
@@ -1545,7 +1546,9 @@ def backbone_forward(rt, bb, x, r):
     x, r = rt.parallel([lambda: simple_conv(rt, x0, bb.image_initial.proj),
                         lambda: simple_conv(rt, r0, bb.radar_initial.proj)], site=0)
     x = image_enhance(rt, x, r, bb.image_enhance_by_radar1)
-    r = radar_enhance(rt, x, r, bb.radar_enhance_by_image1)
+    overlapped = rt.concurrent and not rt.pair_streams and rt.overlap_fusion
+    if not overlapped:
+        r = radar_enhance(rt, x, r, bb.radar_enhance_by_image1)
     if tuple(bb.fea_pos.shape[:2]) != (H, W):
         raise RuntimeError(f"input {H}x{W} does not match fea_pos {tuple(bb.fea_pos.shape[:2])}: "
                            "construct EfficientVRNet(..., img_size=(H, W))")
@@ -1604,6 +1607,8 @@ def backbone_forward(rt, bb, x, r):
             act = cluster_block(rt, act, blk, f"{prefix}.{j}.token_mixer")
         return act
 
+    if overlapped:
+        return _backbone_overlapped(rt, bb, x, r, embed, chain)
     mask = os.environ.get("VRNET_PAIR_MASK")      # diagnostic: which stages (bits 0-3) / reducers (bits 4-6) run two-stream
 
     def can_pair(h, w, bit=None):    # rows of one stream must be whole 128-row tiles (true for every stage from 256 px at bs 2)
@@ -1648,6 +1653,61 @@ def backbone_forward(rt, bb, x, r):
     return outs, outs_r
 
 
+def branch_alias(rt, x):
+    """A second handle on x's tensor for a consumer that runs on ANOTHER chain of the next parallel section: it gets a
+    gradient buffer of its own (two chains must not accumulate into one buffer concurrently), which a closure on the MAIN tape
+    -- pushed here, so replayed right after the section's backward -- adds to x's."""
+    xa = Act(x.t, need_grad=x.need_grad)
+
+    def bwd():
+        g = take_grad(xa)
+        if g is not None:
+            rt.give_grad(x, g)
+    rt.push(bwd)
+    return xa
+
+
+def _backbone_overlapped(rt, bb, x, r, embed, chain):
+    """forward_tokens (vr_coc.py:589-675) with the asymmetric fusion un-serialised (round 5).  The reference runs, per level,
+    stage blocks (both streams) -> ImageEnhanceByRadar -> RadarEnhanceByImage -> both reducers -> next stage.  Only the radar
+    stream needs RadarEnhanceByImage: the image stream's reducer and next stage depend on the ImageEnhance output alone.  So a
+    section is  A: image reducer (or patch embedding) -> image blocks   beside   B: RadarEnhanceByImage of the previous level ->
+    radar reducer -> radar blocks,  joined in front of the next ImageEnhanceByRadar (which needs both).  The ~16 small launches
+    of a RadarEnhanceByImage (ShuffleAttention, concat, ECA, 1x1 conv, two BatchNorms -- one stream's worth of work on a chip that
+    is otherwise idle) and their ~25 backward launches then run beside the image chain's GEMMs instead of in front of both
+    chains.  Same arithmetic; the gradient of an ImageEnhance output is summed from two buffers (branch_alias) instead of
+    accumulated in one."""
+    outs, outs_r = [None] * 4, [None] * 4
+    re_mod, r_in = bb.radar_enhance_by_image1, r
+    for i in range(4):
+        pi, pr = f"backbone.backbone.network.{3 * i}", f"backbone.backbone.network_radar.{3 * i}"
+        x_prev, xa = x, branch_alias(rt, x)
+
+        def branch_a(i=i, x_prev=x_prev, pi=pi):
+            a = embed(x_prev, bb.patch_embed) if i == 0 else simple_conv(rt, x_prev, bb.network[3 * (i - 1) + 2].proj)
+            return a, chain(a, bb.network[3 * i], pi)
+
+        def branch_b(i=i, xa=xa, r_in=r_in, re_mod=re_mod, pr=pr):
+            rr = radar_enhance(rt, xa, r_in, re_mod)
+            b = embed(rr, bb.patch_embed_radar) if i == 0 else simple_conv(rt, rr, bb.network_radar[3 * (i - 1) + 2].proj)
+            return rr, b, chain(b, bb.network_radar[3 * i], pr)
+        if i == 0 and rt.prep is not None:
+            rt.prep.wait_all()      # the first consumers of the weight planes / Mlp packs / [fc1 ; fc_v] copies: stage 0
+        (tap_a, xs), (rr, tap_b, rs) = rt.parallel([branch_a, branch_b], site=2)
+        if i == 1:
+            outs_r[0] = rr                                       # RadarEnhance output at 1/4 resolution
+        if i in (1, 2):
+            outs[i], outs_r[i] = tap_a, tap_b                    # the reducers' outputs (inputs of stages 1, 2)
+        x = image_enhance(rt, xs, rs, bb.network[3 * i + 1])
+        if i in (0, 3):
+            outs[0 if i == 0 else 3] = x
+        re_mod, r_in = bb.network_radar[3 * i + 1], rs
+    # the last RadarEnhanceByImage only feeds the detection branch of the neck: it runs at the head of that branch
+    # (neck_forward), beside the segmentation branch's ASPP, not in front of both
+    outs_r[3] = (branch_alias(rt, x), r_in, re_mod)
+    return outs, outs_r
+
+
 def neck_forward(rt, nk, x, r, seg_out):
     """CoCFpnDual.forward (coc_fpn_dual.py:184-224). seg_out: NCHW tensor for the seg logits."""
     (x2, x3, x4, x5), (r2, r3, r4, r5) = backbone_forward(rt, nk.backbone, x, r)
@@ -1660,7 +1720,8 @@ def neck_forward(rt, nk, x, r, seg_out):
         return coc_upsample(rt, t, nk.upsample2_0, nchw_out=seg_out)
 
     def det_branch():        # radar-stream features only (coc_fpn_dual.py:213-221)
-        p5 = coc_conv(rt, r5, nk.p5_out_det, "backbone.p5_out_det.coc.token_mixer")
+        r5_ = radar_enhance(rt, *r5) if isinstance(r5, tuple) else r5      # (deferred by _backbone_overlapped)
+        p5 = coc_conv(rt, r5_, nk.p5_out_det, "backbone.p5_out_det.coc.token_mixer")
         p4 = coc_conv(rt, cat2(rt, r4, coc_upsample(rt, p5, nk.p5_4_det), False), nk.p4_out_det,
                       "backbone.p4_out_det.coc.token_mixer")
         p3 = coc_conv(rt, cat2(rt, r3, coc_upsample(rt, p4, nk.p4_3_det), False), nk.p3_out_det,
@@ -1957,6 +2018,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         # measured (A/B inside one gpurun call, phi=l bs 8 512 px): two chains on two streams 30.8 ms/step, one
         # two-stream chain 31.6 ms/step (and 1 480 instead of 2 070 launches): the default is the faster one
         rt.pair_streams = bool(getattr(model, "pair_streams", False))
+        rt.overlap_fusion = bool(getattr(model, "overlap_fusion", True))     # RadarEnhanceByImage beside the image chain (round 5)
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
         rt.bn_colstats = bool(getattr(model, "bn_colstats", True))
         rt.forced_idx = getattr(model, "forced_idx_maps", None)

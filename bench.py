@@ -353,6 +353,8 @@ def main():
     ap.add_argument("--no-fused-mlp", action="store_true", help="Mlp as two conv launches (A/B aid)")
     ap.add_argument("--no-weight-planes", action="store_true", help="x6 kernels split the weights themselves (A/B aid)")
     ap.add_argument("--no-bn-colstats", action="store_true", help="BatchNorm statistics by a pass over z (A/B aid)")
+    ap.add_argument("--no-overlap-fusion", action="store_true", help="RadarEnhanceByImage in front of both chains, as rounds 1-4 (A/B aid)")
+    ap.add_argument("--no-weight-prep", action="store_true", help="per-step weight packs on the main chain, as rounds 1-4 (A/B aid)")
     ap.add_argument("--diagnostic", action="store_true",
                     help="allow VRNET_* environment knobs and the diagnostic library build (tools/sweep_env.sh ablations); the "
                          "line is then marked `diagnostic`, its metric string says so, and it is not a measurement")
@@ -405,6 +407,8 @@ def main():
     model.fused_mlp = not args.no_fused_mlp
     model.weight_planes = not args.no_weight_planes
     model.bn_colstats = not args.no_bn_colstats
+    model.overlap_fusion = not args.no_overlap_fusion
+    model.weight_prep_stream = not args.no_weight_prep
     net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 

@@ -368,7 +368,7 @@ def test_n8_plan_at_l():
         assert len(bk.cuts) == 2 and sorted(bk.segment_slices) == [0, 1, 2]
         share = {k: sum(p.numel() for p in bk.params if bk.bucket_segment[bk.bucket_of[p]] == k) / total for k in range(3)}
         assert 0 < share[2] <= 0.05, share                   # the un-overlapped collective
-        assert share[0] >= 0.3 and share[1] >= 0.3, share    # the two overlapped ones carry the bytes
+        assert share[0] >= 0.25 and share[1] >= 0.25, share  # the two overlapped ones carry the bytes (section granularity: a stage is one)
         # slices: consecutive, cover the arena, one segment per bucket, bucket size bounded
         lo = 0
         for k in range(3):
