@@ -111,6 +111,7 @@ class RT:
         self.pending_ab = []        # deferred (d alpha, d beta) reductions of the Cluster modules of the section being replayed
         self.sync_batch_total = None   # SyncBatchNorm: global sample count of THIS forward pass
         self.overlap_fusion = True
+        self.branch_priority = False
         self.via_autograd = False   # parameter gradients go back through torch.autograd (stock DistributedDataParallel)
 
     # ---- fork / join of independent chains -------------------------------------------------------------
@@ -119,10 +120,13 @@ class RT:
 
     def _streams(self, n):
         """n side streams for the current nesting depth (nested sections get their own streams)."""
-        pool = RT._side_streams.setdefault(self.device, [])
+        pool = RT._side_streams.setdefault((self.device, self.branch_priority), [])
         lo = self._depth * 8
         while len(pool) < lo + n:
-            pool.append(torch.cuda.Stream(self.device))
+            # branch_priority: the SECOND chain of a section (the radar chain of a backbone stage, the detection branch of the
+            # neck -- the longer one since round 5's schedule) on a high-priority stream
+            hi = self.branch_priority and len(pool) % 8 == 1
+            pool.append(torch.cuda.Stream(self.device, priority=-1 if hi else 0))
         return pool[lo:lo + n]
 
     # ---- parameter-gradient kernels off the critical path ---------------------------------------------------
@@ -2018,6 +2022,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         # measured (A/B inside one gpurun call, phi=l bs 8 512 px): two chains on two streams 30.8 ms/step, one
         # two-stream chain 31.6 ms/step (and 1 480 instead of 2 070 launches): the default is the faster one
         rt.pair_streams = bool(getattr(model, "pair_streams", False))
+        rt.branch_priority = bool(getattr(model, "branch_priority", False))
         rt.overlap_fusion = bool(getattr(model, "overlap_fusion", True))     # RadarEnhanceByImage beside the image chain (round 5)
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
         rt.bn_colstats = bool(getattr(model, "bn_colstats", True))

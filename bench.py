@@ -186,9 +186,10 @@ class ConvTimer:
         def cluster_bwd(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, da, db, acc, B, H, W, E, Dh, fold, **kw_):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            o_cb(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, da, db, acc, B, H, W, E, Dh, fold, **kw_)
+            out = o_cb(f, v, ld, alpha, beta, idx, dout, lddo, df, dv, lddf, da, db, acc, B, H, W, E, Dh, fold, **kw_)
             e1.record()
             rec["cluster_bwd"].append((5.0 * B * H * W * E * Dh * 4, e0, e1, f"{H}x{W} E{E} D{Dh} fold{fold}"))      # read f, v, g; write df, dv
+            return out                # (the workspace holding the (d alpha, d beta) partials when their reduction is deferred)
         hip.conv2d, hip.conv2d_wgrad, hip.cluster_fwd, hip.cluster_bwd = conv2d, conv2d_wgrad, cluster_fwd, cluster_bwd
         o_mf, o_mb = self.orig_mlp
 
@@ -354,6 +355,7 @@ def main():
     ap.add_argument("--no-weight-planes", action="store_true", help="x6 kernels split the weights themselves (A/B aid)")
     ap.add_argument("--no-bn-colstats", action="store_true", help="BatchNorm statistics by a pass over z (A/B aid)")
     ap.add_argument("--no-overlap-fusion", action="store_true", help="RadarEnhanceByImage in front of both chains, as rounds 1-4 (A/B aid)")
+    ap.add_argument("--branch-priority", action="store_true", help="second chain of a section on a high-priority stream (experiment)")
     ap.add_argument("--no-weight-prep", action="store_true", help="per-step weight packs on the main chain, as rounds 1-4 (A/B aid)")
     ap.add_argument("--diagnostic", action="store_true",
                     help="allow VRNET_* environment knobs and the diagnostic library build (tools/sweep_env.sh ablations); the "
@@ -408,6 +410,7 @@ def main():
     model.weight_planes = not args.no_weight_planes
     model.bn_colstats = not args.no_bn_colstats
     model.overlap_fusion = not args.no_overlap_fusion
+    model.branch_priority = args.branch_priority
     model.weight_prep_stream = not args.no_weight_prep
     net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
