@@ -103,6 +103,7 @@ class RT:
         self._aside_open = None     # aside work of the tape closure being replayed
         self._aside_batches = []    # closed batches not yet joined: (events, tensors kept alive, parameters reported)
         self._deferred_wgrads = []
+        self._started_wgrads = []   # weight gradients issued early on the side streams, not yet joined (start_deferred_wgrads)
         self.ready = None           # with a bucketer: parameters whose gradient kernels were issued, not yet handed over
         self.tape_pos = 0           # index of the top-level tape closure being replayed
         self.concurrent = True      # fork independent chains (image / radar, seg / det, head levels) onto side streams
@@ -111,6 +112,8 @@ class RT:
         self.pending_ab = []        # deferred (d alpha, d beta) reductions of the Cluster modules of the section being replayed
         self.sync_batch_total = None   # SyncBatchNorm: global sample count of THIS forward pass
         self.overlap_fusion = True
+        self.early_wgrads = False   # measured (round 5, same call): 25.87-26.06 ms with it against 25.75-25.92 without -- the weight
+                                    # gradients then contend with the small kernels of the critical chain they were meant to fill
         self.branch_priority = False
         self.via_autograd = False   # parameter gradients go back through torch.autograd (stock DistributedDataParallel)
 
@@ -196,7 +199,40 @@ class RT:
                 fn()
         return work          # keeps the tensors alive until the caller has joined the streams
 
+    def start_deferred_wgrads(self):
+        """(round 5) Issues the weight gradients a parallel section deferred NOW, on the weight-gradient side streams, without
+        waiting for them: they run beside whatever the main chain does next (the ImageEnhanceByRadar backward between two
+        sections -- ~30 small launches during which the chip was idle) instead of waiting for the next parallel section to take
+        them along.  Joined by join_started_wgrads() (the next section's backward / a cut); the parameters they report become
+        ready only then."""
+        if not self._deferred_wgrads or not self.concurrent or self._chain != "main":
+            return
+        cur = torch.cuda.current_stream(self.device)
+        streams = self._streams(8)[4:4 + WGRAD_STREAMS]
+        for st in streams:
+            st.wait_stream(cur)
+        mark = len(self.ready) if self.ready is not None else 0
+        work = self._launch_deferred_wgrads(cur, streams)
+        fresh = []
+        if self.ready is not None:
+            fresh = self.ready[mark:]
+            del self.ready[mark:]
+        self._started_wgrads.append((streams, work, fresh))
+
+    def join_started_wgrads(self):
+        if not self._started_wgrads:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        for streams, work, fresh in self._started_wgrads:
+            for st in streams:
+                cur.wait_stream(st)
+            work.clear()
+            if self.ready is not None:
+                self.ready.extend(fresh)
+        self._started_wgrads = []
+
     def flush_deferred_wgrads(self):
+        self.join_started_wgrads()
         if not self._deferred_wgrads:
             return
         cur = torch.cuda.current_stream(self.device)
@@ -238,6 +274,7 @@ class RT:
         if self.record:
             def bwd():
                 cur_b = torch.cuda.current_stream(self.device)
+                self.join_started_wgrads()      # (same side streams; their work queues behind what was started early)
                 # weight gradients deferred by the PREVIOUS section run beside this section's data-gradient chains
                 wstreams = self._streams(8)[4:4 + WGRAD_STREAMS] if self._deferred_wgrads else []
                 for st in wstreams:
@@ -256,6 +293,7 @@ class RT:
                 for st in list(streams) + list(wstreams):
                     cur_b.wait_stream(st)
                 held.clear()
+            bwd.is_parallel = True
             main_tape.append(bwd)
         return outs
 
@@ -2023,6 +2061,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         # two-stream chain 31.6 ms/step (and 1 480 instead of 2 070 launches): the default is the faster one
         rt.pair_streams = bool(getattr(model, "pair_streams", False))
         rt.branch_priority = bool(getattr(model, "branch_priority", False))
+        rt.early_wgrads = bool(getattr(model, "early_wgrads", False))
         rt.overlap_fusion = bool(getattr(model, "overlap_fusion", True))     # RadarEnhanceByImage beside the image chain (round 5)
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
         rt.bn_colstats = bool(getattr(model, "bn_colstats", True))
@@ -2130,6 +2169,8 @@ def backward_range(rt, lo, hi, flush_each=False):
             rt.tape_pos = i
             rt.tape[i]()
             rt.flush_cluster_ab()
+            if not flush_each and rt.early_wgrads and i > lo and not getattr(rt.tape[i - 1], "is_parallel", False):
+                rt.start_deferred_wgrads()      # the next closure is main-chain work: the section's weight gradients run beside it
             done = rt.join_aside(0 if flush_each else ASIDE_LAG)
             if flush_each:
                 rt.flush_deferred_wgrads()

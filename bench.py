@@ -356,6 +356,7 @@ def main():
     ap.add_argument("--no-bn-colstats", action="store_true", help="BatchNorm statistics by a pass over z (A/B aid)")
     ap.add_argument("--no-overlap-fusion", action="store_true", help="RadarEnhanceByImage in front of both chains, as rounds 1-4 (A/B aid)")
     ap.add_argument("--branch-priority", action="store_true", help="second chain of a section on a high-priority stream (experiment)")
+    ap.add_argument("--early-wgrads", action="store_true", help="a section's deferred weight gradients start right behind it (experiment: slower)")
     ap.add_argument("--no-weight-prep", action="store_true", help="per-step weight packs on the main chain, as rounds 1-4 (A/B aid)")
     ap.add_argument("--diagnostic", action="store_true",
                     help="allow VRNET_* environment knobs and the diagnostic library build (tools/sweep_env.sh ablations); the "
@@ -410,6 +411,7 @@ def main():
     model.weight_planes = not args.no_weight_planes
     model.bn_colstats = not args.no_bn_colstats
     model.overlap_fusion = not args.no_overlap_fusion
+    model.early_wgrads = args.early_wgrads
     model.branch_priority = args.branch_priority
     model.weight_prep_stream = not args.no_weight_prep
     net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model
