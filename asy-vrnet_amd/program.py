@@ -112,7 +112,7 @@ class RT:
         self.pending_ab = []        # deferred (d alpha, d beta) reductions of the Cluster modules of the section being replayed
         self.sync_batch_total = None   # SyncBatchNorm: global sample count of THIS forward pass
         self.overlap_fusion = True
-        self.early_wgrads = False   # measured (round 5, same call): 25.87-26.06 ms with it against 25.75-25.92 without -- the weight
+        self.early_wgrads = 2       # 1 = behind every section: measured (round 5, same call): 25.87-26.06 ms with it against 25.75-25.92 without -- the weight
                                     # gradients then contend with the small kernels of the critical chain they were meant to fill
         self.branch_priority = False
         self.via_autograd = False   # parameter gradients go back through torch.autograd (stock DistributedDataParallel)
@@ -199,7 +199,7 @@ class RT:
                 fn()
         return work          # keeps the tensors alive until the caller has joined the streams
 
-    def start_deferred_wgrads(self):
+    def start_deferred_wgrads(self, nstreams=0):
         """(round 5) Issues the weight gradients a parallel section deferred NOW, on the weight-gradient side streams, without
         waiting for them: they run beside whatever the main chain does next (the ImageEnhanceByRadar backward between two
         sections -- ~30 small launches during which the chip was idle) instead of waiting for the next parallel section to take
@@ -208,7 +208,7 @@ class RT:
         if not self._deferred_wgrads or not self.concurrent or self._chain != "main":
             return
         cur = torch.cuda.current_stream(self.device)
-        streams = self._streams(8)[4:4 + WGRAD_STREAMS]
+        streams = self._streams(8)[4:4 + max(WGRAD_STREAMS, nstreams)]
         for st in streams:
             st.wait_stream(cur)
         mark = len(self.ready) if self.ready is not None else 0
@@ -2061,7 +2061,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         # two-stream chain 31.6 ms/step (and 1 480 instead of 2 070 launches): the default is the faster one
         rt.pair_streams = bool(getattr(model, "pair_streams", False))
         rt.branch_priority = bool(getattr(model, "branch_priority", False))
-        rt.early_wgrads = bool(getattr(model, "early_wgrads", False))
+        rt.early_wgrads = int(getattr(model, "early_wgrads", 2))
         rt.overlap_fusion = bool(getattr(model, "overlap_fusion", True))     # RadarEnhanceByImage beside the image chain (round 5)
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
         rt.bn_colstats = bool(getattr(model, "bn_colstats", True))
@@ -2170,7 +2170,12 @@ def backward_range(rt, lo, hi, flush_each=False):
             rt.tape[i]()
             rt.flush_cluster_ab()
             if not flush_each and rt.early_wgrads and i > lo and not getattr(rt.tape[i - 1], "is_parallel", False):
-                rt.start_deferred_wgrads()      # the next closure is main-chain work: the section's weight gradients run beside it
+                # the next closure is main-chain work: the section's weight gradients run beside it.  Mode 2 (default): only
+                # behind the LAST section of chains (stage 0) -- its weight gradients (the largest maps) otherwise run after
+                # everything else, 0.8 ms during which two kernels at a time own the chip -- and on four streams
+                left = sum(1 for f in rt.tape[:i] if getattr(f, "is_parallel", False))
+                if rt.early_wgrads == 1 or left <= 1:
+                    rt.start_deferred_wgrads(4 if rt.early_wgrads == 2 else 0)
             done = rt.join_aside(0 if flush_each else ASIDE_LAG)
             if flush_each:
                 rt.flush_deferred_wgrads()

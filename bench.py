@@ -356,7 +356,8 @@ def main():
     ap.add_argument("--no-bn-colstats", action="store_true", help="BatchNorm statistics by a pass over z (A/B aid)")
     ap.add_argument("--no-overlap-fusion", action="store_true", help="RadarEnhanceByImage in front of both chains, as rounds 1-4 (A/B aid)")
     ap.add_argument("--branch-priority", action="store_true", help="second chain of a section on a high-priority stream (experiment)")
-    ap.add_argument("--early-wgrads", action="store_true", help="a section's deferred weight gradients start right behind it (experiment: slower)")
+    ap.add_argument("--early-wgrads", type=int, default=2, help="a section's deferred weight gradients start right behind it: 0 never, "
+                    "1 every section (measured slower), 2 the last section only (default)")
     ap.add_argument("--no-weight-prep", action="store_true", help="per-step weight packs on the main chain, as rounds 1-4 (A/B aid)")
     ap.add_argument("--diagnostic", action="store_true",
                     help="allow VRNET_* environment knobs and the diagnostic library build (tools/sweep_env.sh ablations); the "
