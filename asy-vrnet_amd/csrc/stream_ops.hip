@@ -358,6 +358,46 @@ __global__ __launch_bounds__(256) void affine_kernel(const AffineArgs p) {
   }
 }
 
+// The same for channel counts that are no multiple of 4 (the 3 / 4 / 7-channel maps of the input fusion at FULL resolution:
+// 2 M pixels per sample set, vr_coc.py:303-359) when every tensor is contiguous (row stride == C): a sample is then one flat run
+// of HW * C floats, read and written 16 bytes at a time; the channel of element i is i mod C (round 5: the scalar path above ran
+// these launches -- all of them on the step's critical chain -- at 2 TB/s with a 64-bit division per element).
+__global__ __launch_bounds__(256) void affine_flat_kernel(const AffineArgs p) {
+  const long n4 = p.HW * p.C / 4;
+  const long b = blockIdx.y, cb = b * p.bstride, base = b * p.HW * p.C;
+  const int C = p.C;
+  auto one = [&](long e) {
+    const long i0 = 4 * e;
+    int c = (int)(i0 % C);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, x2 = a, mk = a, acc = a, v;
+    if (p.x1) a = ld4(p.x1 + base + i0);
+    if (p.x2) x2 = ld4(p.x2 + base + i0);
+    if (p.pre == 2) mk = ld4(p.masky + base + i0);
+    if (p.add) acc = ld4(p.add + base + i0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = p.D1 ? p.D1[cb + c] : 0.f;
+      if (p.x1) t = bn_pre(p.A ? p.A[cb + c] : 1.f, a[j], p.S1 ? p.S1[cb + c] : 0.f, t);
+      if (p.pre == 1) t = fmaxf(t, 0.f);
+      else if (p.pre == 2 && !(mk[j] > 0.f)) t = 0.f;
+      else if (p.pre == 3 && !(bn_pre(p.mA[c], x2[j], p.mS[c], p.mD[c]) > 0.f)) t = 0.f;
+      if (p.x2) t += (p.E ? p.E[cb + c] : 1.f) * (x2[j] - (p.S2 ? p.S2[cb + c] : 0.f));
+      if (p.D2) t += p.D2[cb + c];
+      if (p.add) t += acc[j];
+      v[j] = t;
+      if (++c == C) c = 0;
+    }
+    *reinterpret_cast<f32x4*>(p.out + base + i0) = v;
+  };
+  const long stride = (long)gridDim.x * 256;
+  long e = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; e + stride < n4; e += 2 * stride) {
+    one(e);
+    one(e + stride);
+  }
+  if (e < n4) one(e);
+}
+
 // ------------------------------------------------------------------------------------------ coefficients
 __device__ __forceinline__ double block_sum(double v, double* red) {
   v = wave_sum(v);
@@ -787,6 +827,71 @@ __global__ __launch_bounds__(256) void cat2_vec_kernel(float* a, long lda, int C
   }
 }
 
+// The 3 + 4 -> 7-channel concat of the input fusion (2 M rows) and its adjoint, one thread per ROW (round 5): the generic kernel
+// above does a 64-bit division per element and ran the two launches at 37 us each on the critical chain.
+template <int CA, int CB>
+__global__ __launch_bounds__(256) void cat2_rows_kernel(float* a, long lda, float* b, long ldb, float* cat, long ldc, long rows,
+                                                        int dir, int acc_a, int acc_b, int vecb) {
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+    float* w = cat + r * ldc;
+    if (dir == 0) {
+      float u[CA], v[CB];
+#pragma unroll
+      for (int j = 0; j < CA; ++j) u[j] = a[r * lda + j];
+      if (CB == 4 && vecb) {
+        const f32x4 t = ld4(b + r * ldb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = t[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < CB; ++j) v[j] = b[r * ldb + j];
+      }
+#pragma unroll
+      for (int j = 0; j < CA; ++j) w[j] = u[j];
+#pragma unroll
+      for (int j = 0; j < CB; ++j) w[CA + j] = v[j];
+    } else {
+      float t[CA + CB];
+#pragma unroll
+      for (int j = 0; j < CA + CB; ++j) t[j] = w[j];
+      if (a) {
+#pragma unroll
+        for (int j = 0; j < CA; ++j) a[r * lda + j] = acc_a ? a[r * lda + j] + t[j] : t[j];
+      }
+      if (b) {
+        if (CB == 4 && vecb) {
+          f32x4 o = {t[CA], t[CA + 1], t[CA + 2], t[CA + 3]};
+          if (acc_b) o += ld4(b + r * ldb);
+          *reinterpret_cast<f32x4*>(b + r * ldb) = o;
+        } else {
+#pragma unroll
+          for (int j = 0; j < CB; ++j) b[r * ldb + j] = acc_b ? b[r * ldb + j] + t[CA + j] : t[CA + j];
+        }
+      }
+    }
+  }
+}
+
+// [B][C][HW] -> [B][HW][ld] for C <= 4 (the network's two inputs), one thread per pixel: C coalesced plane reads, one 12- or
+// 16-byte row written (round 5: the 32 x 32 tile kernel below leaves 28 of its 32 channel lanes idle at C = 3 / 4: 26 us each)
+template <int C>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_small_kernel(const float* src, float* dst, long ldd, long HW, int vec) {
+  const long b = blockIdx.y;
+  for (long pp = (long)blockIdx.x * 256 + threadIdx.x; pp < HW; pp += (long)gridDim.x * 256) {
+    float v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = src[(b * C + c) * HW + pp];
+    float* d = dst + (b * HW + pp) * ldd;
+    if (C == 4 && vec) {
+      const f32x4 o = {v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(d) = o;
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) d[c] = v[c];
+    }
+  }
+}
+
 // 32x32 LDS-tiled transpose between [B][C][HW] and [B][HW][ld]
 __global__ void nchw_to_nhwc_kernel(const float* src, float* dst, long ldd, int C, long HW) {
   __shared__ float tile[32][33];
@@ -955,6 +1060,18 @@ static int affine_impl(const float* x1, long ld1, const float* A, const float* D
   if (pre == 2) vec = vec && (ldm % 4 == 0) && vr_aligned16(masky);
   if (add) vec = vec && (ldadd % 4 == 0) && vr_aligned16(add);
   for (const float* c : {A, D1, S1, E, D2, S2, mA, mD, mS}) vec = vec && (!c || vr_aligned16(c));
+  // contiguous tensors of a channel count that is no multiple of 4: flat 16-byte accesses over a sample's HW * C floats
+  bool flat = !vec && C % 4 != 0 && C <= 16 && (HW * C) % 4 == 0 && ldo == C && vr_aligned16(out) && (!x1 || (ld1 == C && vr_aligned16(x1))) &&
+              (!x2 || (ld2 == C && vr_aligned16(x2))) && (pre != 2 || (ldm == C && vr_aligned16(masky))) &&
+              (!add || (ldadd == C && vr_aligned16(add)));
+  if (flat) {
+    long blocks = vr_cdiv(HW * C / 4, 256 * 4);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(affine_flat_kernel, dim3(blocks, B), dim3(256), 0, vr_stream(stream), p);
+    VR_LAUNCH_CHECK("affine");
+    return VR_OK;
+  }
   long blocks = vr_cdiv(HW * (C / (vec ? 4 : 1)), 256 * 4);
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
@@ -1287,6 +1404,15 @@ extern "C" int vrnet_cat2_f32(float* a, long lda, int Ca, float* b, long ldb, in
     VR_LAUNCH_CHECK("cat2");
     return VR_OK;
   }
+  if (Ca == 3 && Cb == 4 && !interleave) {      // the input fusion's concat: one thread per row
+    long rb = vr_cdiv(rows, 256);
+    if (rb > 16384) rb = 16384;
+    const int vecb = (!b || (ldb % 4 == 0 && vr_aligned16(b))) ? 1 : 0;
+    hipLaunchKernelGGL((cat2_rows_kernel<3, 4>), dim3(rb), dim3(256), 0, vr_stream(stream), a, lda, b, ldb, cat, ldc, rows, dir,
+                       accumulate_a, accumulate_b, vecb);
+    VR_LAUNCH_CHECK("cat2");
+    return VR_OK;
+  }
   long blocks = vr_cdiv(rows * (Ca + Cb), 1024);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(cat2_kernel, dim3(blocks), dim3(256), 0, vr_stream(stream), a, lda, Ca, b, ldb, Cb, cat, ldc, rows,
@@ -1297,6 +1423,15 @@ extern "C" int vrnet_cat2_f32(float* a, long lda, int Ca, float* b, long ldb, in
 
 extern "C" int vrnet_nchw_to_nhwc_f32(const float* src, float* dst, long ldd, int B, int C, long HW, void* stream) {
   VR_CHECK_ARG(src && dst && ldd >= C, "nchw_to_nhwc: bad arguments");
+  if ((C == 3 || C == 4) && HW >= 4096) {
+    long pb = vr_cdiv(HW, 256);
+    if (pb > 4096) pb = 4096;
+    if (C == 3) hipLaunchKernelGGL((nchw_to_nhwc_small_kernel<3>), dim3(pb, B), dim3(256), 0, vr_stream(stream), src, dst, ldd, HW, 0);
+    else hipLaunchKernelGGL((nchw_to_nhwc_small_kernel<4>), dim3(pb, B), dim3(256), 0, vr_stream(stream), src, dst, ldd, HW,
+                            (ldd % 4 == 0 && vr_aligned16(dst)) ? 1 : 0);
+    VR_LAUNCH_CHECK("nchw_to_nhwc");
+    return VR_OK;
+  }
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(vr_cdiv(HW, 32), vr_cdiv(C, 32), B), dim3(32, 8), 0, vr_stream(stream),
                      src, dst, ldd, C, HW);
   VR_LAUNCH_CHECK("nchw_to_nhwc");
