@@ -1231,6 +1231,32 @@ extern "C" int vrnet_bn_coef_fwd_from_partials(const double* partial, const floa
   return VR_OK;
 }
 
+/* The same two coefficient steps from column partials with an explicit chunk count (round 5: the fused kernels of
+ * csrc/fusion.hip leave [nchunks][C][2] partials over ALL rows of the batch): train-mode BatchNorm forward coefficients +
+ * running statistics (count = B * HW values per channel), and the backward coefficients + parameter gradients from
+ * (sum dy', sum dy' z) partials. */
+extern "C" int vrnet_bn_coef_fwd_from_chunks(const double* partial, int nchunks, long count, const float* gamma, const float* beta,
+                                             float eps, float momentum, float* running_mean, float* running_var,
+                                             long long* num_batches_tracked, int C, float* A, float* D, float* S, float* mean_rstd,
+                                             void* stream) {
+  VR_CHECK_ARG(partial && nchunks > 0 && gamma && beta && running_mean && running_var && A && D && S && mean_rstd && count > 1 && C > 0,
+               "bn_coef_fwd_from_chunks: bad arguments");
+  hipLaunchKernelGGL(bn_coef_fwd_partial_kernel, dim3(vr_cdiv(C, 4)), dim3(256), 0, vr_stream(stream), partial, nchunks, gamma, beta,
+                     eps, momentum, running_mean, running_var, num_batches_tracked, 1, count, C, A, D, S, mean_rstd);
+  VR_LAUNCH_CHECK("bn_coef_fwd_from_chunks");
+  return VR_OK;
+}
+extern "C" int vrnet_bn_coef_bwd_from_chunks(const double* partial, int nchunks, long count, const float* mean_rstd,
+                                             const float* gamma, int training, int C, float* A, float* E, float* D, float* S,
+                                             float* dgamma, float* dbeta, int accumulate, void* stream) {
+  VR_CHECK_ARG(partial && nchunks > 0 && mean_rstd && gamma && A && E && D && S && dgamma && dbeta && count > 0 && C > 0,
+               "bn_coef_bwd_from_chunks: bad arguments");
+  hipLaunchKernelGGL(bn_coef_bwd_partial_kernel, dim3(vr_cdiv(C, 4)), dim3(256), 0, vr_stream(stream), partial, nchunks, mean_rstd,
+                     gamma, training, 1, count, C, A, E, D, S, dgamma, dbeta, accumulate);
+  VR_LAUNCH_CHECK("bn_coef_bwd_from_chunks");
+  return VR_OK;
+}
+
 extern "C" int vrnet_gn_coef_bwd(const double* mom2, const float* mean_rstd, const float* gamma, int B, long HW, int C,
                                  float* A, float* E, float* D, float* S, float* dgamma, float* dbeta, int accumulate,
                                  const float* gamma2, float* dgamma2, float* dbeta2, void* stream) {

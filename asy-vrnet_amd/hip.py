@@ -102,6 +102,15 @@ _SIGS = {
     "vrnet_minmax_f32": ([P, L, P, P, L, P], I),
     "vrnet_enhance_mul_f32": ([P, P, P, P, L, P], I),
     "vrnet_enhance_fwd_f32": ([P, P, P, P, L, P, L, P], I),
+    "vrnet_fusion_chunks": ([L, I], I),
+    "vrnet_fusion_fold_chunks": ([L, I], I),
+    "vrnet_bn_relu_minmax_f32": ([P, P, P, P, P, L, I, P, P], I),
+    "vrnet_bn_relu_res_stats_f32": ([P, P, P, P, P, P, L, I, P, P], I),
+    "vrnet_enhance_stats_f32": ([P, P, P, I, P, P, L, I, P, P], I),
+    "vrnet_bn_bwd_enhance_f32": ([P, P, P, P, P, P, P, P, P, P, L, I, P, P], I),
+    "vrnet_enhance_bwd_stats_f32": ([P, P, P, P, P, I, P, P, P, P, P, P, L, I, I, P, P], I),
+    "vrnet_bn_coef_fwd_from_chunks": ([P, I, L, P, P, F, F, P, P, P, I, P, P, P, P, P], I),
+    "vrnet_bn_coef_bwd_from_chunks": ([P, I, L, P, P, I, I, P, P, P, P, P, P, I, P], I),
     "vrnet_enhance_bwd_f32": ([P, P, P, P, P, P, L, I, P, L, P], I),
     "vrnet_sa_coef_fwd": ([P] * 7 + [I, L, I, I, P, P, P, P], I),
     "vrnet_sa_apply_f32": ([P, L, P, P, P, P, L, I, L, I, P], I),
@@ -790,3 +799,49 @@ def mean_square_bwd(tensors, g, grads):
     PA, LA = ctypes.c_void_p * k, ctypes.c_long * k
     _check(_lib.vrnet_mean_square_bwd_f32(k, PA(*[ptr(t) for t in tensors]), LA(*[t.numel() for t in tensors]), ptr(g),
                                           PA(*[ptr(t) for t in grads]), stream()), "mean_square_bwd")
+
+
+# ---- fused passes of the fusion blocks (csrc/fusion.hip)
+def fusion_chunks(n, C):
+    """Workgroups / partial entries of the fused fusion-block kernels for a contiguous tensor (0: shape not supported)."""
+    return _lib.vrnet_fusion_chunks(n, C)
+
+
+def fusion_fold_chunks(n, C):
+    """Entries of the (min, max) / four-sum partials (bn_relu_minmax, bn_bwd_enhance)."""
+    return _lib.vrnet_fusion_fold_chunks(n, C)
+
+
+def bn_relu_minmax(z, A, D, S, p, n, C, mmpart):
+    _check(_lib.vrnet_bn_relu_minmax_f32(ptr(z), ptr(A), ptr(D), ptr(S), ptr(p), n, C, ptr(mmpart), stream()), "bn_relu_minmax")
+
+
+def bn_relu_res_stats(z, A, D, S, res, s, n, C, colpart):
+    _check(_lib.vrnet_bn_relu_res_stats_f32(ptr(z), ptr(A), ptr(D), ptr(S), ptr(res), ptr(s), n, C, ptr(colpart), stream()),
+           "bn_relu_res_stats")
+
+
+def enhance_stats(p, x, mmpart, nmm, mm, t, n, C, colpart):
+    _check(_lib.vrnet_enhance_stats_f32(ptr(p), ptr(x), ptr(mmpart), nmm, ptr(mm), ptr(t), n, C, ptr(colpart), stream()),
+           "enhance_stats")
+
+
+def bn_bwd_enhance(g, t, A, E, D, S, x, p, mm, dt, n, C, sums4):
+    _check(_lib.vrnet_bn_bwd_enhance_f32(ptr(g), ptr(t), ptr(A), ptr(E), ptr(D), ptr(S), ptr(x), ptr(p), ptr(mm), ptr(dt), n, C,
+                                         ptr(sums4), stream()), "bn_bwd_enhance")
+
+
+def enhance_bwd_stats(dt, x, p, mm, sums4, nsums, z, fA, fD, fS, dx, dp, n, C, accumulate_dx, colpart):
+    _check(_lib.vrnet_enhance_bwd_stats_f32(ptr(dt), ptr(x), ptr(p), ptr(mm), ptr(sums4), nsums, ptr(z), ptr(fA), ptr(fD), ptr(fS),
+                                            ptr(dx), ptr(dp), n, C, accumulate_dx, ptr(colpart), stream()), "enhance_bwd_stats")
+
+
+def bn_coef_fwd_from_chunks(partial, nchunks, count, gamma, beta, eps, momentum, rmean, rvar, nbt, C, A, Dc, S, mean_rstd):
+    _check(_lib.vrnet_bn_coef_fwd_from_chunks(ptr(partial), nchunks, count, ptr(gamma), ptr(beta), eps, momentum, ptr(rmean), ptr(rvar),
+                                              ptr(nbt), C, ptr(A), ptr(Dc), ptr(S), ptr(mean_rstd), stream()), "bn_coef_fwd_from_chunks")
+
+
+def bn_coef_bwd_from_chunks(partial, nchunks, count, mean_rstd, gamma, training, C, A, E, Dc, S, dgamma, dbeta, accumulate):
+    _check(_lib.vrnet_bn_coef_bwd_from_chunks(ptr(partial), nchunks, count, ptr(mean_rstd), ptr(gamma), 1 if training else 0, C, ptr(A),
+                                              ptr(E), ptr(Dc), ptr(S), ptr(dgamma), ptr(dbeta), accumulate, stream()),
+           "bn_coef_bwd_from_chunks")

@@ -24,13 +24,14 @@ class Act:
     Two-stream buffers: the image and the radar stream of a backbone stage live in ONE (2B,H,W,C) tensor (image
     samples first) so that a stage's ClusterBlocks run as one launch per layer; `half(k)` is the Act of one stream --
     a view whose gradient is the matching half of the parent's gradient buffer (`written[k]`: that half holds data)."""
-    __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad", "pairs", "colpart", "parent", "slot", "written", "_halves",
-                 "gradp", "want_gradp", "__weakref__")
+    __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad", "pairs", "colpart", "colchunks", "parent", "slot", "written",
+                 "_halves", "gradp", "want_gradp", "__weakref__")
 
     def __init__(self, t, need_grad=True):
         self.t = t
         self.pairs = None       # (fp64 (sum, sumsq) pairs, pairs per sample) emitted by the conv that produced `t`
         self.colpart = None     # fp64 per-channel (sum, sumsq) partials per 32-row tile emitted by that conv (BatchNorm)
+        self.colchunks = 0      # > 0: `colpart` is [colchunks][C][2] over ALL rows (left by a fused kernel of csrc/fusion.hip)
         self.B, self.H, self.W, self.C = t.shape
         self.ld = t.stride(2)
         self.grad = None
@@ -112,6 +113,7 @@ class RT:
         self.pending_ab = []        # deferred (d alpha, d beta) reductions of the Cluster modules of the section being replayed
         self.sync_batch_total = None   # SyncBatchNorm: global sample count of THIS forward pass
         self.overlap_fusion = True
+        self.fused_fusion = True    # the fused passes of csrc/fusion.hip in the fusion blocks
         self.early_wgrads = 2       # 1 = behind every section: measured (round 5, same call): 25.87-26.06 ms with it against 25.75-25.92 without -- the weight
                                     # gradients then contend with the small kernels of the critical chain they were meant to fill
         self.branch_priority = False
@@ -671,11 +673,17 @@ def simple_conv(rt, x, conv, out=None):
 
 
 # ----------------------------------------------------------------------------------------- norms
-def bn_forward(rt, z, bn, relu, out=None, residual=None):
-    """y = [relu](BN(z)) [+ residual].  Returns (y, ctx) where ctx feeds bn_backward."""
+def bn_fwd_coef(rt, z, bn):
+    """Coefficients of y = A (z - S) + D for BatchNorm `bn` over z (train mode: batch statistics, running statistics updated --
+    from the producer's column partials when it left any, else by a moments pass; eval mode: running statistics).
+    Returns (A, D, S, ctx)."""
     B, HW, C = z.B, z.HW, z.C
     A, D, S, ms = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C, 2)
-    if rt.training and rt.sync_bn is not None:
+    if rt.training and rt.sync_bn is None and z.colpart is not None and z.colchunks:
+        hip.bn_coef_fwd_from_chunks(z.colpart, z.colchunks, B * HW, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
+                                    bn.running_var, bn.num_batches_tracked, C, A, D, S, ms)
+        z.colpart, z.colchunks = None, 0
+    elif rt.training and rt.sync_bn is not None:
         # synchronised BatchNorm: per-sample moments -> sum over samples and ranks -> coefficients with the global count
         tot = rt.sync_bn.total(hip.moments(z.t, z.ld, B, HW, C))
         hip.bn_coef_fwd(tot, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
@@ -691,6 +699,14 @@ def bn_forward(rt, z, bn, relu, out=None, residual=None):
     else:
         hip.bn_coef_fwd(None, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
                         bn.num_batches_tracked, False, B, HW, C, A, D, S, ms)
+        z.colpart, z.colchunks = None, 0
+    return A, D, S, ms
+
+
+def bn_forward(rt, z, bn, relu, out=None, residual=None):
+    """y = [relu](BN(z)) [+ residual].  Returns (y, ctx) where ctx feeds bn_backward."""
+    B, HW, C = z.B, z.HW, z.C
+    A, D, S, ms = bn_fwd_coef(rt, z, bn)
     y = out if out is not None else rt.new(z.B, z.H, z.W, C)
     hip.affine(y.t, y.ld, B, HW, C, x1=z.t, ld1=z.ld, A=A, D1=D, S1=S, pre=1 if relu else 0,
                x2=None if residual is None else residual.t, ld2=0 if residual is None else residual.ld)
@@ -699,6 +715,19 @@ def bn_forward(rt, z, bn, relu, out=None, residual=None):
     if relu:
         ms.fwd_coef = (A, D, S)      # bn_backward recomputes the ReLU mask from z with these instead of reading y
     return y, ms
+
+
+def bn_bwd_coef(rt, bn, z, ms, dy, lddy):
+    """Coefficients (A, E, D, S) of dz = A dy + E (z - S) + D for y = BN(z) (no ReLU) and its parameter gradients: the moments
+    pass + the coefficient kernel of bn_backward without the apply launch (the caller's fused kernel applies them)."""
+    B, HW, C = z.B, z.HW, z.C
+    (gw, gb), accw = _pgrads_or_scratch(rt, (bn.weight, bn.bias), (C, C))
+    A, E, D, S = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C)
+    hip.bn_stats_bwd(dy, lddy, z.t, z.ld, None, 0, ms, bn.weight, rt.training, B, HW, C, A, E, D, S, gw, gb, accw)
+    if rt.on_param_grad:
+        rt.on_param_grad(bn.weight)
+        rt.on_param_grad(bn.bias)
+    return A, E, D, S
 
 
 def bn_backward(rt, bn, z, ms, dy, lddy, mask=None, dz_out=None):
@@ -1338,33 +1367,77 @@ def _fused_qkv_wgrad(rt, tm, xn, dfv, planes=False):
 
 
 # ----------------------------------------------------------------------------------------- fusion blocks
+def _fusion_chunks(rt, *acts):
+    """Chunk count of the fused fusion-block kernels (csrc/fusion.hip) for contiguous maps of one shape, 0: not applicable."""
+    a = acts[0]
+    if not rt.fused_fusion or rt.sync_bn is not None or any(t.ld != t.C or t.C != a.C or t.rows != a.rows for t in acts):
+        return 0
+    return hip.fusion_chunks(a.rows * a.C, a.C)
+
+
 def image_enhance(rt, x, r, m, out=None):
     """ImageEnhanceByRadar.forward (vr_coc.py:312-316): BN((1 + minmax(ReLU(BN(conv3x3(r))))) * x).
-    out: Act to write the result into (one stream's half of the next two-stream buffer)."""
+    out: Act to write the result into (one stream's half of the next two-stream buffer).
+    Round 5 (csrc/fusion.hip): the BatchNorm + ReLU apply leaves the (min, max) partials, the gain kernel the column statistics
+    of its output, the backward of `norm` the four sums of the gain's backward, and the gain's backward the moments of bn1's --
+    6 + 7 launches where the unfused form (kept for maps the fused kernels do not take: 3 channels at the input level) has 8 + 9."""
     conv, bn1 = m.radar_projection.conv, m.radar_projection.bn
     B, H, W, C = x.B, x.H, x.W, x.C
     z = rt.new(B, H, W, C)
     conv_call(rt, r, conv, z, bias=False, bn_stats=True)
-    p, ms1 = bn_forward(rt, z, bn1, relu=True)
-    mm = rt.buf(2)
-    n = p.t.numel()
-    t = rt.new(B, H, W, C)
     assert x.ld == C, "image map must be contiguous"
-    hip.enhance_fwd(p.t, x.t, mm, t.t, n)           # min / max of p and the gain in two launches (three before round 5)
+    n = x.rows * C
+    nch = _fusion_chunks(rt, x, z)
+    mm = rt.buf(2)
+    t = rt.new(B, H, W, C)
+    if nch:
+        A, D, S, ms1 = bn_fwd_coef(rt, z, bn1)
+        p = rt.new(B, H, W, C)
+        nfold = hip.fusion_fold_chunks(n, C)
+        mmpart = rt.buf(nfold, 2)
+        hip.bn_relu_minmax(z.t, A, D, S, p.t, n, C, mmpart)
+        ms1.fwd_coef = (A, D, S)
+        if rt.relu_masks is not None:
+            rt.relu_masks[bn1] = p
+        colpart = rt.buf(nch, C, 2, dtype=torch.float64)
+        hip.enhance_stats(p.t, x.t, mmpart, nfold, mm, t.t, n, C, colpart)
+        if rt.training:
+            t.colpart, t.colchunks = colpart, nch          # BatchNorm `norm`: coefficients straight from these
+    else:
+        p, ms1 = bn_forward(rt, z, bn1, relu=True)
+        hip.enhance_fwd(p.t, x.t, mm, t.t, n)           # min / max of p and the gain in two launches (three before round 5)
     y, ms2 = bn_forward(rt, t, m.norm, relu=False, out=out)
 
     def bwd():
         g = take_grad(y)
         if g is None:
             return
-        dt = bn_backward(rt, m.norm, t, ms2, g, C)
-        dp = rt.buf(B, H, W, C)
         if x.need_grad:
             dxb, acc = rt.grad_target(x)
         else:
             dxb, acc = rt.buf(B, H, W, C), 0
-        hip.enhance_bwd(dt, x.t, p.t, mm, dxb, dp, n, accumulate_dx=acc)
-        dz = bn_backward(rt, bn1, z, ms1, dp, C, mask=p)
+        dp = rt.buf(B, H, W, C)
+        fwd = getattr(ms1, "fwd_coef", None)
+        if nch and BN_ZMASK and fwd is not None and g.is_contiguous():
+            A2, E2, D2, S2 = bn_bwd_coef(rt, m.norm, t, ms2, g, C)
+            dt = rt.buf(B, H, W, C)
+            nf = hip.fusion_fold_chunks(n, C)
+            sums4 = rt.buf(nf, 4, dtype=torch.float64)
+            hip.bn_bwd_enhance(g, t.t, A2, E2, D2, S2, x.t, p.t, mm, dt, n, C, sums4)
+            colpart = rt.buf(nch, C, 2, dtype=torch.float64)
+            hip.enhance_bwd_stats(dt, x.t, p.t, mm, sums4, nf, z.t, fwd[0], fwd[1], fwd[2], dxb, dp, n, C, acc, colpart)
+            (gw, gb), accw = _pgrads_or_scratch(rt, (bn1.weight, bn1.bias), (C, C))
+            A1, E1, D1, S1 = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C)
+            hip.bn_coef_bwd_from_chunks(colpart, nch, x.rows, ms1, bn1.weight, rt.training, C, A1, E1, D1, S1, gw, gb, accw)
+            if rt.on_param_grad:
+                rt.on_param_grad(bn1.weight)
+                rt.on_param_grad(bn1.bias)
+            dz = rt.buf(B, H, W, C)
+            hip.bn_apply_bwd_zmask(dp, C, z.t, z.ld, fwd, A1, E1, D1, S1, dz, C, B, H * W, C)
+        else:
+            dt = bn_backward(rt, m.norm, t, ms2, g, C)
+            hip.enhance_bwd(dt, x.t, p.t, mm, dxb, dp, n, accumulate_dx=acc)
+            dz = bn_backward(rt, bn1, z, ms1, dp, C, mask=p)
         conv_backward(rt, r, conv, dz, C)
     rt.push(bwd)
     return y
@@ -1466,10 +1539,19 @@ def radar_enhance(rt, x, r, m, out=None):
     B, H, W, C = r.B, r.H, r.W, r.C
     z = rt.new(B, H, W, C)
     conv_call(rt, u, conv, z, bias=False, bn_stats=True)
+    nch = _fusion_chunks(rt, r, z)
     if BN_ZMASK and rt.relu_masks is None and rt.sync_bn is None:      # (synchronised BatchNorm reads the ReLU output as its mask)
         # s = ReLU(BN(z)) + r in ONE apply launch; the ReLU output itself is never stored: the backward pass recomputes its
         # mask from z with the forward coefficients (bn_backward, zmask form).  (round 5: -1 launch, -2 tensor passes per level)
-        s, ms1 = bn_forward(rt, z, bn1, relu=True, residual=r)
+        if nch and rt.training:
+            # ... which also leaves the column statistics of s: BatchNorm `norm` needs no pass of its own over it
+            A1, D1, S1, ms1 = bn_fwd_coef(rt, z, bn1)
+            s = rt.new(B, H, W, C)
+            s.colpart, s.colchunks = rt.buf(nch, C, 2, dtype=torch.float64), nch
+            hip.bn_relu_res_stats(z.t, A1, D1, S1, r.t, s.t, r.rows * C, C, s.colpart)
+            ms1.fwd_coef = (A1, D1, S1)
+        else:
+            s, ms1 = bn_forward(rt, z, bn1, relu=True, residual=r)
         q = s                        # (stands in for "there is a ReLU": the zmask backward never reads it)
     else:
         q, ms1 = bn_forward(rt, z, bn1, relu=True)
@@ -2062,6 +2144,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         rt.pair_streams = bool(getattr(model, "pair_streams", False))
         rt.branch_priority = bool(getattr(model, "branch_priority", False))
         rt.early_wgrads = int(getattr(model, "early_wgrads", 2))
+        rt.fused_fusion = bool(getattr(model, "fused_fusion", True))
         rt.overlap_fusion = bool(getattr(model, "overlap_fusion", True))     # RadarEnhanceByImage beside the image chain (round 5)
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
         rt.bn_colstats = bool(getattr(model, "bn_colstats", True))

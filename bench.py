@@ -358,6 +358,7 @@ def main():
     ap.add_argument("--branch-priority", action="store_true", help="second chain of a section on a high-priority stream (experiment)")
     ap.add_argument("--early-wgrads", type=int, default=2, help="a section's deferred weight gradients start right behind it: 0 never, "
                     "1 every section (measured slower), 2 the last section only (default)")
+    ap.add_argument("--no-fused-fusion", action="store_true", help="fusion blocks without the fused passes of csrc/fusion.hip (A/B aid)")
     ap.add_argument("--no-weight-prep", action="store_true", help="per-step weight packs on the main chain, as rounds 1-4 (A/B aid)")
     ap.add_argument("--diagnostic", action="store_true",
                     help="allow VRNET_* environment knobs and the diagnostic library build (tools/sweep_env.sh ablations); the "
@@ -412,6 +413,7 @@ def main():
     model.weight_planes = not args.no_weight_planes
     model.bn_colstats = not args.no_bn_colstats
     model.overlap_fusion = not args.no_overlap_fusion
+    model.fused_fusion = not args.no_fused_fusion
     model.early_wgrads = args.early_wgrads
     model.branch_priority = args.branch_priority
     model.weight_prep_stream = not args.no_weight_prep

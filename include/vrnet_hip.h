@@ -450,6 +450,37 @@ int vrnet_enhance_mul_f32(const float* p, const float* x, const float* mm, float
  * kernel); mm receives (min, max) for vrnet_enhance_bwd_f32.  workspace: vrnet_reduce_workspace() bytes.  (ABI 9) */
 int vrnet_enhance_fwd_f32(const float* p, const float* x, float* mm, float* out, long n, void* workspace, long workspace_bytes,
                           void* stream);
+
+/* ---- fused passes of the fusion blocks (csrc/fusion.hip, ABI 9): an elementwise pass that also leaves the partial sums the NEXT
+ * reduction needs (contiguous NHWC tensors of n elements, row stride == C, C % 4 == 0, C <= 1024, 16-byte aligned).
+ * vrnet_fusion_chunks(n, C): workgroups = entries of the column partials (0: shape not supported): colpart [chunks][C][2] fp64;
+ * vrnet_fusion_fold_chunks(n, C): entries of mmpart [.][2] fp32 and sums4 [.][4] fp64.
+ *   vrnet_bn_relu_minmax_f32     p = ReLU(A (z - S) + D) + the (min, max) partials of p         (vr_coc.py:308 + :59-67)
+ *   vrnet_enhance_stats_f32      t = (1 + data_normal(p)) x + column (sum, sumsq) of t; mm <- (min, max)      (:314-315)
+ *   vrnet_bn_relu_res_stats_f32  s = ReLU(A (z - S) + D) + res + column (sum, sumsq) of s                      (:355-357)
+ *   vrnet_bn_bwd_enhance_f32     dt = A g + E (t - S) + D (BatchNorm backward apply) + the four sums of the gain's backward
+ *   vrnet_enhance_bwd_stats_f32  dx (+)=, dp of the gain + column (sum dp', sum dp' z), dp' = dp [fA (z - fS) + fD > 0]
+ * vrnet_bn_coef_{fwd,bwd}_from_chunks: the BatchNorm coefficient steps (vrnet_bn_coef_fwd_from_partials / the second half of
+ * vrnet_bn_stats_bwd) from such column partials; count = values per channel (B * HW). */
+int vrnet_fusion_chunks(long n, int C);
+int vrnet_fusion_fold_chunks(long n, int C);      /* entries of mmpart / sums4 (folded again by every workgroup of the next kernel) */
+int vrnet_bn_relu_minmax_f32(const float* z, const float* A, const float* D, const float* S, float* p, long n, int C, float* mmpart,
+                             void* stream);
+int vrnet_bn_relu_res_stats_f32(const float* z, const float* A, const float* D, const float* S, const float* res, float* s, long n,
+                                int C, double* colpart, void* stream);
+int vrnet_enhance_stats_f32(const float* p, const float* x, const float* mmpart, int nmm, float* mm, float* t, long n, int C,
+                            double* colpart, void* stream);
+int vrnet_bn_bwd_enhance_f32(const float* g, const float* t, const float* A, const float* E, const float* D, const float* S,
+                             const float* x, const float* p, const float* mm, float* dt, long n, int C, double* sums4, void* stream);
+int vrnet_enhance_bwd_stats_f32(const float* dt, const float* x, const float* p, const float* mm, const double* sums4, int nsums,
+                                const float* z, const float* fA, const float* fD, const float* fS, float* dx, float* dp, long n, int C,
+                                int accumulate_dx, double* colpart, void* stream);
+int vrnet_bn_coef_fwd_from_chunks(const double* partial, int nchunks, long count, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* running_mean, float* running_var, long long* num_batches_tracked, int C,
+                                  float* A, float* D, float* S, float* mean_rstd, void* stream);
+int vrnet_bn_coef_bwd_from_chunks(const double* partial, int nchunks, long count, const float* mean_rstd, const float* gamma,
+                                  int training, int C, float* A, float* E, float* D, float* S, float* dgamma, float* dbeta,
+                                  int accumulate, void* stream);
 int vrnet_enhance_bwd_f32(const float* dt, const float* x, const float* p, const float* mm, float* dx, float* dp,
                           long n, int accumulate_dx, void* workspace, long workspace_bytes, void* stream);
 
