@@ -243,6 +243,39 @@ __global__ __launch_bounds__(256) void enhance_bwd_stats_kernel(const float* dt,
   col_stats_flush(s1, s2, CV, colpart, lds);
 }
 
+// ds = A g + E (s - S) + D (backward apply of a BatchNorm WITHOUT ReLU) with the column sums the backward of the BatchNorm +
+// ReLU in front of it needs: ds' = ds [fA (z - fS) + fD > 0]: (sum ds', sum ds' z)
+__global__ __launch_bounds__(256) void bn_bwd_next_stats_kernel(const float* __restrict__ g, const float* __restrict__ sx,
+                                                                const float* __restrict__ A, const float* __restrict__ E,
+                                                                const float* __restrict__ D, const float* __restrict__ S,
+                                                                const float* __restrict__ z, const float* __restrict__ fA,
+                                                                const float* __restrict__ fD, const float* __restrict__ fS,
+                                                                float* __restrict__ ds, long n4, int C, double* __restrict__ colpart) {
+  __shared__ double lds[256 * 8];
+  const int CV = C >> 2;
+  const long G = (long)gridDim.x * 256, e0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c0 = (int)(e0 % CV) * 4;
+  const f32x4 a4 = ld4(A + c0), e4 = ld4(E + c0), d4 = ld4(D + c0), s4 = ld4(S + c0);
+  const f32x4 fa4 = ld4(fA + c0), fd4 = ld4(fD + c0), fs4 = ld4(fS + c0);
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (long e = e0; e < n4; e += G) {
+    const f32x4 gv = ld4(g + 4 * e), xv = ld4(sx + 4 * e), zv = ld4(z + 4 * e);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = a4[j] * gv[j];
+      v += e4[j] * (xv[j] - s4[j]);
+      v += d4[j];
+      o[j] = v;
+      const float vm = (bn_pre(fa4[j], zv[j], fs4[j], fd4[j]) > 0.f) ? v : 0.f;
+      s1[j] += (double)vm;
+      s2[j] += (double)vm * (double)zv[j];
+    }
+    *reinterpret_cast<f32x4*>(ds + 4 * e) = o;
+  }
+  col_stats_flush(s1, s2, CV, colpart, lds);
+}
+
 // workgroups: ~4 float4 per thread, at most 4096 (+ rounding), a multiple of CV / gcd(CV, 256) so that (workgroups * 256) % CV == 0
 int fusion_grid(long n4, int CV, long cap = 4096) {
   int g = 256, a = CV;
@@ -337,5 +370,20 @@ extern "C" int vrnet_enhance_bwd_stats_f32(const float* dt, const float* x, cons
   hipLaunchKernelGGL(enhance_bwd_stats_kernel, dim3(fusion_grid(n / 4, C / 4)), dim3(256), 0, vr_stream(stream), dt, x, p, mm, sums4,
                      nsums, z, fA, fD, fS, dx, dp, n / 4, C, accumulate_dx, colpart);
   VR_LAUNCH_CHECK("enhance_bwd_stats");
+  return VR_OK;
+}
+
+/* Backward apply of BatchNorm `norm` of RadarEnhanceByImage (ds = A g + E (s - S) + D, vr_coc.py:357) fused with the moments
+ * pass of the BatchNorm + ReLU in front of it (inverse_projection's, :355): colpart = column (sum ds', sum ds' z), ds' = ds
+ * masked by the ReLU recomputed from z with the forward coefficients (fA, fD, fS). */
+extern "C" int vrnet_bn_bwd_next_stats_f32(const float* g, const float* s, const float* A, const float* E, const float* D,
+                                           const float* S, const float* z, const float* fA, const float* fD, const float* fS,
+                                           float* ds, long n, int C, double* colpart, void* stream) {
+  VR_CHECK_ARG(g && s && A && E && D && S && z && fA && fD && fS && ds && colpart && fusion_ok(n, C) &&
+                   FUSION_ALIGNED(g, s, A, E, D, S, z, fA, fD, fS, ds), "bn_bwd_next_stats: bad arguments");
+  if (vr_ablated("affine")) return VR_OK;
+  hipLaunchKernelGGL(bn_bwd_next_stats_kernel, dim3(fusion_grid(n / 4, C / 4)), dim3(256), 0, vr_stream(stream), g, s, A, E, D, S, z,
+                     fA, fD, fS, ds, n / 4, C, colpart);
+  VR_LAUNCH_CHECK("bn_bwd_next_stats");
   return VR_OK;
 }

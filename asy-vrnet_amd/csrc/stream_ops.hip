@@ -940,6 +940,53 @@ __global__ void fill_kernel(float* dst, float v, long n) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) dst[e] = v;
 }
 
+// RadarEnhanceByImage (vr_coc.py:343-352), three launches in one (round 5): the ShuffleAttention apply (gate from P, Q, Mn of
+// vrnet_sa_coef_fwd, output channels in the module's shuffled order), torch.cat with the radar map + the 2-group channel shuffle,
+// and the per-(sample, channel) sums of the result that the ECA gate behind it needs.  Thread (tx = output quad oq of the 2 C
+// channels, ty = row): cat[4 oq .. 4 oq + 3] = {SA(x)[oq-th even slot], r[2 oq], SA(x)[odd slot], r[2 oq + 1]}, where the two
+// SA values come from input channels oq and C / 2 + oq (the inverse of sa_dst).  Partial sums in the moments layout
+// [b][chunk][2 C][2] (the second component, a sum of squares nobody reads, is written as 0).
+__global__ __launch_bounds__(256) void sa_cat_sums_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ P,
+                                                          const float* __restrict__ Q, const float* __restrict__ Mn,
+                                                          const float* __restrict__ r, long ldr, float* __restrict__ cat, long ldc,
+                                                          long HW, int C, int TPR, long rows_per_chunk, int nchunks,
+                                                          double* __restrict__ partial) {
+  extern __shared__ double sm[];   // [256][4]
+  const int tid = threadIdx.x;
+  const int tx = tid % TPR, ty = tid / TPR, RP = 256 / TPR;
+  const int chunk = blockIdx.x, b = blockIdx.y, H2 = C >> 1;
+  const long r0 = chunk * rows_per_chunk, r1 = min(HW, r0 + rows_per_chunk);
+  double s[4] = {0, 0, 0, 0};
+  if (tx < H2) {
+    const float p0 = P[b * C + tx], q0 = Q[b * C + tx], m0 = Mn[b * C + tx];
+    const float p1 = P[b * C + H2 + tx], q1 = Q[b * C + H2 + tx], m1 = Mn[b * C + H2 + tx];
+    for (long rr = r0 + ty; rr < r1; rr += RP) {
+      const long row = (long)b * HW + rr;
+      const float x0 = x[row * ldx + tx], x1 = x[row * ldx + H2 + tx];
+      const float2 rv = *reinterpret_cast<const float2*>(r + row * ldr + 2 * tx);
+      const float a0 = x0 * vr_sigmoid(p0 * (x0 - m0) + q0), a1 = x1 * vr_sigmoid(p1 * (x1 - m1) + q1);
+      const f32x4 o = {a0, rv.x, a1, rv.y};
+      *reinterpret_cast<f32x4*>(cat + row * ldc + 4 * tx) = o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += (double)o[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sm[(long)tid * 4 + j] = s[j];
+  __syncthreads();
+  if (ty == 0 && tx < H2) {
+    for (int q = 1; q < RP; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += sm[(long)(q * TPR + tx) * 4 + j];
+    double* out = partial + (((long)b * nchunks + chunk) * (2 * C) + 4 * tx) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      out[2 * j] = s[j];
+      out[2 * j + 1] = 0.0;
+    }
+  }
+}
+
 static int moments_plan(int B, long HW, int C, int vec, int* TPR, int* ncb, int* nchunks, long* rows) {
   const int CV = C / vec;
   int t = 1;
@@ -1012,6 +1059,38 @@ extern "C" int vrnet_moments_f32(const float* x, long ldx, const float* x2, long
   const long n = (long)B * C * 2;
   hipLaunchKernelGGL(moments_reduce_kernel, dim3(vr_cdiv(n, 16)), dim3(256), 0, st, reinterpret_cast<double*>(workspace), out,
                      B, nchunks, C);
+  VR_LAUNCH_CHECK("moments_reduce");
+  return VR_OK;
+}
+
+/* cat = shuffle_channels(torch.cat([ShuffleAttention(x), r], 1), 2) (vr_coc.py:343-349; the attention's gate from the P, Q, Mn
+ * of vrnet_sa_coef_fwd) and mom[b][c] = (sum over the map of cat[b, :, c], 0) for the ECA gate behind it (:350): vrnet_sa_apply_f32 +
+ * vrnet_cat2_f32 + vrnet_moments_f32 in two launches.  x, r: (B, HW, C) with row strides ldx, ldr; cat: (B, HW, 2 C), row stride
+ * ldc; C % 4 == 0, C <= 512; workspace: vrnet_moments_workspace(B, HW, 2 C). */
+extern "C" int vrnet_sa_cat_sums_f32(const float* x, long ldx, const float* P, const float* Q, const float* Mn, const float* r,
+                                     long ldr, float* cat, long ldc, int B, long HW, int C, double* mom, void* workspace,
+                                     long workspace_bytes, void* stream) {
+  VR_CHECK_ARG(x && P && Q && Mn && r && cat && mom && workspace && B > 0 && HW > 0, "sa_cat_sums: null tensor");
+  VR_CHECK_ARG(C % 4 == 0 && C >= 4 && C <= 512 && ldx >= C && ldr >= C && ldr % 2 == 0 && ldc >= 2 * C && ldc % 4 == 0 &&
+                   vr_aligned16(cat) && (reinterpret_cast<uintptr_t>(r) & 7) == 0,
+               "sa_cat_sums: needs C %% 4 == 0, C <= 512, an 8-byte aligned radar map and a 16-byte aligned output");
+  if (workspace_bytes < vrnet_moments_workspace(B, HW, 2 * C)) {
+    vr_set_error("sa_cat_sums: workspace too small");
+    return VR_ERR_WORKSPACE;
+  }
+  if (vr_ablated("misc")) return VR_OK;
+  int TPR, ncb, nchunks;
+  long rows;
+  moments_plan(B, HW, 2 * C, 4, &TPR, &ncb, &nchunks, &rows);       // (2 C / 4 quads per row = C / 2 threads: ncb == 1 up to C = 512)
+  int tpr = 1;
+  while (tpr < C / 2 && tpr < 256) tpr <<= 1;
+  hipStream_t st = vr_stream(stream);
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(sa_cat_sums_kernel, dim3(nchunks, B), dim3(256), 256 * 4 * sizeof(double), st, x, ldx, P, Q, Mn, r, ldr, cat, ldc,
+                     HW, C, tpr, rows, nchunks, partial);
+  VR_LAUNCH_CHECK("sa_cat_sums");
+  const long n = (long)B * 2 * C * 2;
+  hipLaunchKernelGGL(moments_reduce_kernel, dim3(vr_cdiv(n, 16)), dim3(256), 0, st, partial, mom, B, nchunks, 2 * C);
   VR_LAUNCH_CHECK("moments_reduce");
   return VR_OK;
 }

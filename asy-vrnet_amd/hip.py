@@ -109,10 +109,12 @@ _SIGS = {
     "vrnet_enhance_stats_f32": ([P, P, P, I, P, P, L, I, P, P], I),
     "vrnet_bn_bwd_enhance_f32": ([P, P, P, P, P, P, P, P, P, P, L, I, P, P], I),
     "vrnet_enhance_bwd_stats_f32": ([P, P, P, P, P, I, P, P, P, P, P, P, L, I, I, P, P], I),
+    "vrnet_bn_bwd_next_stats_f32": ([P, P, P, P, P, P, P, P, P, P, P, L, I, P, P], I),
     "vrnet_bn_coef_fwd_from_chunks": ([P, I, L, P, P, F, F, P, P, P, I, P, P, P, P, P], I),
     "vrnet_bn_coef_bwd_from_chunks": ([P, I, L, P, P, I, I, P, P, P, P, P, P, I, P], I),
     "vrnet_enhance_bwd_f32": ([P, P, P, P, P, P, L, I, P, L, P], I),
     "vrnet_sa_coef_fwd": ([P] * 7 + [I, L, I, I, P, P, P, P], I),
+    "vrnet_sa_cat_sums_f32": ([P, L, P, P, P, P, L, P, L, I, L, I, P, P, L, P], I),
     "vrnet_sa_apply_f32": ([P, L, P, P, P, P, L, I, L, I, P], I),
     "vrnet_sa_bwd_workspace": ([I, L, I], L),
     "vrnet_decode_outputs_f32": ([P, P, P, I, I, I, F, F, P, P], I),
@@ -697,6 +699,15 @@ def sa_apply(x, ldx, Pq, Qq, Mn, y, ldy, B, HW, C):
     _check(_lib.vrnet_sa_apply_f32(ptr(x), ldx, ptr(Pq), ptr(Qq), ptr(Mn), ptr(y), ldy, B, HW, C, stream()), "sa_apply")
 
 
+def sa_cat_sums(x, ldx, Pq, Qq, Mn, r, ldr, cat, ldc, B, HW, C):
+    """ShuffleAttention apply + cat with r + 2-group shuffle -> cat, and the (B, 2C, 2) channel sums of cat (for the ECA gate)."""
+    mom = torch.empty((B, 2 * C, 2), dtype=torch.float64, device=x.device)
+    ws = _ws.get(_lib.vrnet_moments_workspace(B, HW, 2 * C), x.device)
+    _check(_lib.vrnet_sa_cat_sums_f32(ptr(x), ldx, ptr(Pq), ptr(Qq), ptr(Mn), ptr(r), ldr, ptr(cat), ldc, B, HW, C, ptr(mom), ptr(ws),
+                                      ws.numel(), stream()), "sa_cat_sums")
+    return mom
+
+
 def sa_bwd(dy, lddy, x, ldx, Pq, Qq, Mn, mom, params, dx, lddx, grads, EF, B, HW, C, G, accumulate_dx,
            accumulate_params):
     ws = _ws.get(_lib.vrnet_sa_bwd_workspace(B, HW, C), x.device)
@@ -834,6 +845,11 @@ def bn_bwd_enhance(g, t, A, E, D, S, x, p, mm, dt, n, C, sums4):
 def enhance_bwd_stats(dt, x, p, mm, sums4, nsums, z, fA, fD, fS, dx, dp, n, C, accumulate_dx, colpart):
     _check(_lib.vrnet_enhance_bwd_stats_f32(ptr(dt), ptr(x), ptr(p), ptr(mm), ptr(sums4), nsums, ptr(z), ptr(fA), ptr(fD), ptr(fS),
                                             ptr(dx), ptr(dp), n, C, accumulate_dx, ptr(colpart), stream()), "enhance_bwd_stats")
+
+
+def bn_bwd_next_stats(g, s, A, E, D, S, z, fwd, ds, n, C, colpart):
+    _check(_lib.vrnet_bn_bwd_next_stats_f32(ptr(g), ptr(s), ptr(A), ptr(E), ptr(D), ptr(S), ptr(z), ptr(fwd[0]), ptr(fwd[1]),
+                                            ptr(fwd[2]), ptr(ds), n, C, ptr(colpart), stream()), "bn_bwd_next_stats")
 
 
 def bn_coef_fwd_from_chunks(partial, nchunks, count, gamma, beta, eps, momentum, rmean, rvar, nbt, C, A, Dc, S, mean_rstd):

@@ -25,7 +25,7 @@ class Act:
     samples first) so that a stage's ClusterBlocks run as one launch per layer; `half(k)` is the Act of one stream --
     a view whose gradient is the matching half of the parent's gradient buffer (`written[k]`: that half holds data)."""
     __slots__ = ("t", "B", "H", "W", "C", "ld", "grad", "need_grad", "pairs", "colpart", "colchunks", "parent", "slot", "written",
-                 "_halves", "gradp", "want_gradp", "__weakref__")
+                 "_halves", "gradp", "want_gradp", "sa", "__weakref__")
 
     def __init__(self, t, need_grad=True):
         self.t = t
@@ -1443,15 +1443,22 @@ def image_enhance(rt, x, r, m, out=None):
     return y
 
 
-def shuffle_attention(rt, x, m):
-    """ShuffleAttention.forward (shuffle_attention.py:48-72) on a contiguous map."""
+def shuffle_attention(rt, x, m, defer_apply=False):
+    """ShuffleAttention.forward (shuffle_attention.py:48-72) on a contiguous map.
+    defer_apply: only the gate coefficients are computed; the returned Act has NO tensor (a shape and a gradient slot) and
+    carries the coefficients as `.sa = (P, Q, Mn)` -- the caller's fused kernel (hip.sa_cat_sums) applies the gate while it
+    writes the consumer's tensor.  The backward closure is the same either way (it never reads the output)."""
     B, HW, C, G = x.B, x.HW, x.C, m.G
     params = [t.reshape(-1) for t in (m.cweight, m.cbias, m.sweight, m.sbias, m.gn.weight, m.gn.bias)]
     mom = hip.moments(x.t, x.ld, B, HW, C)
     P, Q, Mn = rt.buf(B, C), rt.buf(B, C), rt.buf(B, C)
     hip.sa_coef_fwd(mom, *params, B, HW, C, G, P, Q, Mn)
-    y = rt.new(x.B, x.H, x.W, C)
-    hip.sa_apply(x.t, x.ld, P, Q, Mn, y.t, C, B, HW, C)
+    if defer_apply:
+        y = Act(torch.empty((x.B, x.H, x.W, C), device="meta"))
+        y.sa = (P, Q, Mn)
+    else:
+        y = rt.new(x.B, x.H, x.W, C)
+        hip.sa_apply(x.t, x.ld, P, Q, Mn, y.t, C, B, HW, C)
 
     def bwd():
         g = take_grad(y)
@@ -1477,17 +1484,19 @@ def shuffle_attention(rt, x, m):
     return y
 
 
-def cat2(rt, a, b, interleave):
+def cat2(rt, a, b, interleave, written=None):
     """torch.cat([a, b], 1) [+ 2-group channel shuffle when both halves have equal width]
-    (vr_coc.py:70-80, coc_fpn_dual.py:120-130): one launch into one buffer, one for the adjoint."""
+    (vr_coc.py:70-80, coc_fpn_dual.py:120-130): one launch into one buffer, one for the adjoint.
+    written: the concatenated Act, already filled by a fused kernel (only the adjoint is recorded)."""
     B, H, W = a.B, a.H, a.W
     Ct = a.C + b.C
-    out = rt.new(B, H, W, Ct)
+    out = written if written is not None else rt.new(B, H, W, Ct)
     rows = a.rows
     il = bool(interleave and Ct % 2 == 0)
     if il:
         assert a.C == b.C
-    hip.cat2(a.t, a.ld, a.C, b.t, b.ld, b.C, out.t, Ct, rows, il)           # one launch (two strided copies before)
+    if written is None:
+        hip.cat2(a.t, a.ld, a.C, b.t, b.ld, b.C, out.t, Ct, rows, il)           # one launch (two strided copies before)
 
     def bwd():
         g = take_grad(out)
@@ -1501,12 +1510,13 @@ def cat2(rt, a, b, interleave):
     return out
 
 
-def eca(rt, x, m):
-    """eca_block.forward (eca.py:16-22)."""
+def eca(rt, x, m, mom=None):
+    """eca_block.forward (eca.py:16-22).  mom: the (B, C, 2) channel sums of x when a fused producer already has them."""
     B, HW, C = x.B, x.HW, x.C
     k = m.kernel_size
     wk = m.conv.weight.reshape(-1)
-    mom = hip.moments(x.t, x.ld, B, HW, C)
+    if mom is None:
+        mom = hip.moments(x.t, x.ld, B, HW, C)
     gate = rt.buf(B, C)
     hip.eca_coef_fwd(mom, wk, k, B, HW, C, gate)
     y = rt.new(x.B, x.H, x.W, C)
@@ -1533,8 +1543,17 @@ def eca(rt, x, m):
 
 def radar_enhance(rt, x, r, m, out=None):
     """RadarEnhanceByImage.forward (vr_coc.py:331-359).  out: as in image_enhance."""
-    a = x if m.initial else shuffle_attention(rt, x, m.image_attn)
-    u = eca(rt, cat2(rt, a, r, interleave=True), m.channel_attn)
+    C0 = x.C
+    if not m.initial and rt.fused_fusion and C0 == r.C and C0 % 4 == 0 and C0 <= 512 and r.ld % 2 == 0 and r.t.data_ptr() % 8 == 0:
+        # attention apply + concat + channel shuffle + the ECA gate's channel sums in ONE launch (csrc/stream_ops.hip,
+        # sa_cat_sums_kernel): the attention's output is never stored, the 2 C-wide tensor is written once and not re-read
+        a = shuffle_attention(rt, x, m.image_attn, defer_apply=True)
+        cat = rt.new(x.B, x.H, x.W, 2 * C0)
+        mom_cat = hip.sa_cat_sums(x.t, x.ld, a.sa[0], a.sa[1], a.sa[2], r.t, r.ld, cat.t, 2 * C0, x.B, x.HW, C0)
+        u = eca(rt, cat2(rt, a, r, interleave=True, written=cat), m.channel_attn, mom=mom_cat)
+    else:
+        a = x if m.initial else shuffle_attention(rt, x, m.image_attn)
+        u = eca(rt, cat2(rt, a, r, interleave=True), m.channel_attn)
     conv, bn1 = m.inverse_projection.conv, m.inverse_projection.bn
     B, H, W, C = r.B, r.H, r.W, r.C
     z = rt.new(B, H, W, C)
@@ -1563,8 +1582,24 @@ def radar_enhance(rt, x, r, m, out=None):
         g = take_grad(y)
         if g is None:
             return
-        ds = bn_backward(rt, m.norm, s, ms2, g, C)
-        dz = bn_backward(rt, bn1, z, ms1, ds, C, mask=q)
+        fwd = getattr(ms1, "fwd_coef", None)
+        if nch and BN_ZMASK and fwd is not None and q is s and g.is_contiguous():
+            # the backward apply of `norm` also leaves the moments of bn1's backward (csrc/fusion.hip): one pass over ds less
+            A2, E2, D2, S2 = bn_bwd_coef(rt, m.norm, s, ms2, g, C)
+            ds = rt.buf(B, H, W, C)
+            colpart = rt.buf(nch, C, 2, dtype=torch.float64)
+            hip.bn_bwd_next_stats(g, s.t, A2, E2, D2, S2, z.t, fwd, ds, r.rows * C, C, colpart)
+            (gw, gb), accw = _pgrads_or_scratch(rt, (bn1.weight, bn1.bias), (C, C))
+            A1, E1, D1, S1 = rt.buf(C), rt.buf(C), rt.buf(C), rt.buf(C)
+            hip.bn_coef_bwd_from_chunks(colpart, nch, r.rows, ms1, bn1.weight, rt.training, C, A1, E1, D1, S1, gw, gb, accw)
+            if rt.on_param_grad:
+                rt.on_param_grad(bn1.weight)
+                rt.on_param_grad(bn1.bias)
+            dz = rt.buf(B, H, W, C)
+            hip.bn_apply_bwd_zmask(ds, C, z.t, z.ld, fwd, A1, E1, D1, S1, dz, C, B, H * W, C)
+        else:
+            ds = bn_backward(rt, m.norm, s, ms2, g, C)
+            dz = bn_backward(rt, bn1, z, ms1, ds, C, mask=q)
         rt.give_grad(r, ds)                                       # long residual path (+ radar_map)
         conv_backward(rt, u, conv, dz, C)
     rt.push(bwd)

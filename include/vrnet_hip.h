@@ -475,6 +475,11 @@ int vrnet_bn_bwd_enhance_f32(const float* g, const float* t, const float* A, con
 int vrnet_enhance_bwd_stats_f32(const float* dt, const float* x, const float* p, const float* mm, const double* sums4, int nsums,
                                 const float* z, const float* fA, const float* fD, const float* fS, float* dx, float* dp, long n, int C,
                                 int accumulate_dx, double* colpart, void* stream);
+/* ds = A g + E (s - S) + D (backward apply of a BatchNorm without ReLU) + column (sum ds', sum ds' z), ds' = ds [fA (z - fS) + fD > 0]:
+ * the moments of the BatchNorm + ReLU in front of it (vr_coc.py:355-357 backwards) */
+int vrnet_bn_bwd_next_stats_f32(const float* g, const float* s, const float* A, const float* E, const float* D, const float* S,
+                                const float* z, const float* fA, const float* fD, const float* fS, float* ds, long n, int C,
+                                double* colpart, void* stream);
 int vrnet_bn_coef_fwd_from_chunks(const double* partial, int nchunks, long count, const float* gamma, const float* beta, float eps,
                                   float momentum, float* running_mean, float* running_var, long long* num_batches_tracked, int C,
                                   float* A, float* D, float* S, float* mean_rstd, void* stream);
@@ -493,6 +498,12 @@ int vrnet_sa_coef_fwd(const double* mom, const float* cw, const float* cb, const
                       void* stream);
 int vrnet_sa_apply_f32(const float* x, long ldx, const float* P, const float* Q, const float* Mn, float* y, long ldy,
                        int B, long HW, int C, void* stream);
+/* cat = shuffle_channels(cat([ShuffleAttention(x), r], 1), 2) (vr_coc.py:343-349) and mom[b][c] = (sum of cat[b, :, c], 0) for the ECA
+ * gate behind it (:350): vrnet_sa_apply_f32 + vrnet_cat2_f32 + the pass of vrnet_moments_f32 as one launch (+ the chunk reduce).
+ * x, r: (B, HW, C); cat: (B, HW, 2 C); C % 4 == 0, C <= 512; workspace: vrnet_moments_workspace(B, HW, 2 C).  (ABI 9) */
+int vrnet_sa_cat_sums_f32(const float* x, long ldx, const float* P, const float* Q, const float* Mn, const float* r, long ldr,
+                          float* cat, long ldc, int B, long HW, int C, double* mom, void* workspace, long workspace_bytes,
+                          void* stream);
 long vrnet_sa_bwd_workspace(int B, long HW, int C);
 int vrnet_sa_bwd_f32(const float* dy, long lddy, const float* x, long ldx, const float* P, const float* Q,
                      const float* Mn, const double* mom, const float* cw, const float* cb, const float* sw, const float* sb,
