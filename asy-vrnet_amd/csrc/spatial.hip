@@ -332,34 +332,6 @@ __global__ __launch_bounds__(256) void patch_scatter_kernel(const float* dp, flo
     *d = accumulate ? *d + v : v;
   }
 }
-// Both with one thread per INPUT pixel (round 5; C <= 8): the pixel's C + CP values are one contiguous run of its patch row, so
-// the index arithmetic (six divisions per ELEMENT above, one of them 64-bit: 49 / 31 us per launch at 512 x 512 x 8 on the
-// critical chain) is paid once per pixel and four neighbouring threads write one 4 (C + CP)-float patch row.
-template <int DIR>
-__global__ __launch_bounds__(256) void patch_pixel_kernel(const float* x, long ldx, const float* pos, float* out, float* dx,
-                                                          long lddx, int B, int H, int W, int C, int CP, int k, int accumulate) {
-  const int CT = C + CP, KT = k * k * CT, OH = H / k, OW = W / k;
-  const int total = B * H * W;
-  for (int pix = blockIdx.x * 256 + threadIdx.x; pix < total; pix += gridDim.x * 256) {
-    const int xx = pix % W;
-    const int q = pix / W;
-    const int yy = q % H, b = q / H;
-    const int t = (yy % k) * k + (xx % k);
-    const long o = ((long)(b * OH + yy / k) * OW + xx / k) * KT + t * CT;
-    if (DIR == 0) {
-      const float* src = x + (long)pix * ldx;
-#pragma unroll 8
-      for (int c = 0; c < C; ++c) out[o + c] = src[c];
-      const float* ps = pos + ((long)yy * W + xx) * CP;
-      for (int c = 0; c < CP; ++c) out[o + C + c] = ps[c];
-    } else {
-      float* d = dx + (long)pix * lddx;
-#pragma unroll 8
-      for (int c = 0; c < C; ++c) d[c] = accumulate ? d[c] + out[o + c] : out[o + c];
-    }
-  }
-}
-
 // weights OIHW [n][c][t] -> OHWI [n][t][c] (dir 0), and the gradient back, OHWI -> OIHW (+)= (dir 1)
 __global__ void ohwi_kernel(const float* src, float* dst, int Cout, int Cin, int T, int dir, int accumulate) {
   const long total = (long)Cout * Cin * T;
@@ -1188,12 +1160,6 @@ extern "C" int vrnet_patch_gather_f32(const float* x, long ldx, const float* pos
                                       int CP, int k, void* stream) {
   VR_CHECK_ARG(x && out && (CP == 0 || pos) && B > 0 && C > 0 && CP >= 0 && k > 0 && H % k == 0 && W % k == 0 && ldx >= C,
                "patch_gather: bad arguments");
-  if (C <= 8 && (long)B * H * W < (1L << 31)) {
-    hipLaunchKernelGGL((patch_pixel_kernel<0>), dim3(grid_for((long)B * H * W, 256, 16384)), dim3(256), 0, vr_stream(stream), x, ldx,
-                       pos, out, (float*)nullptr, 0L, B, H, W, C, CP, k, 0);
-    VR_LAUNCH_CHECK("patch_gather");
-    return VR_OK;
-  }
   hipLaunchKernelGGL(patch_gather_kernel, dim3(grid_for((long)B * H * W * (C + CP))), dim3(256), 0, vr_stream(stream), x,
                      ldx, pos, out, B, H, W, C, CP, k);
   VR_LAUNCH_CHECK("patch_gather");
@@ -1204,12 +1170,6 @@ extern "C" int vrnet_patch_scatter_f32(const float* dp, float* dx, long lddx, in
                                        int accumulate, void* stream) {
   VR_CHECK_ARG(dp && dx && B > 0 && C > 0 && CP >= 0 && k > 0 && H % k == 0 && W % k == 0 && lddx >= C,
                "patch_scatter: bad arguments");
-  if (C <= 8 && (long)B * H * W < (1L << 31)) {
-    hipLaunchKernelGGL((patch_pixel_kernel<1>), dim3(grid_for((long)B * H * W, 256, 16384)), dim3(256), 0, vr_stream(stream),
-                       (const float*)nullptr, 0L, (const float*)nullptr, const_cast<float*>(dp), dx, lddx, B, H, W, C, CP, k, accumulate);
-    VR_LAUNCH_CHECK("patch_scatter");
-    return VR_OK;
-  }
   hipLaunchKernelGGL(patch_scatter_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, vr_stream(stream), dp, dx,
                      lddx, B, H, W, C, CP, k, accumulate);
   VR_LAUNCH_CHECK("patch_scatter");

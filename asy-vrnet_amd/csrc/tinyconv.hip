@@ -385,8 +385,10 @@ int vr_tiny_conv(int mode, const float* a, long lda, const float* w, const float
 }
 
 static void tiny_wgrad_plan(long npix, int* nblk, long* ppb) {
-  long nb = vr_cdiv(npix, 8192);
-  if (nb > 1024) nb = 1024;
+  // ~4 pixels per thread (round 5: at 32 per thread the 256 workgroups of the 512 x 512 x 8 launches left every CU with one
+  // workgroup walking dependent loads: 100 us for 60 MB)
+  long nb = vr_cdiv(npix, 1024);
+  if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   *ppb = vr_cdiv(npix, nb);
   *nblk = (int)vr_cdiv(npix, *ppb);

@@ -113,6 +113,7 @@ class RT:
         self.pending_ab = []        # deferred (d alpha, d beta) reductions of the Cluster modules of the section being replayed
         self.sync_batch_total = None   # SyncBatchNorm: global sample count of THIS forward pass
         self.overlap_fusion = True
+        self.gn_colstats = False
         self.fused_fusion = True    # the fused passes of csrc/fusion.hip in the fusion blocks
         self.early_wgrads = 2       # 1 = behind every section: measured (round 5, same call): 25.87-26.06 ms with it against 25.75-25.92 without -- the weight
                                     # gradients then contend with the small kernels of the critical chain they were meant to fill
@@ -805,13 +806,33 @@ def _pgrads_or_scratch(rt, params, sizes):
     return outs, acc
 
 
-def gn_backward(rt, gn, x, ms, dy, out, accumulate=0, add=None):
+def gn_colstats(rt, gn, x):
+    """Buffers for the column statistics a data-gradient conv leaves for the backward pass of the GroupNorm `gn` whose input was
+    `x` (conv2d `colstats` with x2 / gamma: per-channel (sum dy, sum dy x) per 32-row tile + gamma-weighted tile totals), or None
+    when the shape does not qualify.  (Round 3 built this and measured it neutral while both chains saturated the chip; with the
+    radar chain as the critical path -- round 5 -- a launch less on it is worth having: model.gn_colstats.)"""
+    if not rt.gn_colstats or isinstance(gn, tuple) or not hip.colstats_ok(x.HW, x.C, x.ld) or x.t.data_ptr() % 16:
+        return None
+    part, tot = hip.colstats_buffers(x.B, x.HW, x.C, x.t.device, totals=True)
+    return (part, x.t, x.ld, gn.weight, tot)
+
+
+def gn_backward(rt, gn, x, ms, dy, out, accumulate=0, add=None, partials=None):
     """out = dx of y = GN(x) given contiguous dy [+ out (accumulate) | + add (another contiguous tensor)].
     (Round 3 could also take the moments from the epilogue of the data-gradient conv that produced dy -- vrnet_conv_colstats with
     x2 / gamma, vrnet_gn_apply_bwd_from_partials: measured neutral-to-negative in the step, never on by default; the program path
     was removed in round 4, the library entry points remain.)"""
     g0, g1 = _pair(gn)
     B, HW, C = x.B, x.HW, x.C
+    if partials is not None and (not accumulate or add is None):
+        # the moments came out of the epilogue of the data-gradient conv that produced dy: ONE launch
+        (gw, gb), accw = _pgrads_or_scratch(rt, (g0.weight, g0.bias), (C, C))
+        hip.gn_apply_bwd_from_partials(dy, C, x.t, x.ld, partials[0], partials[4], ms, g0.weight, B, HW, C, out, C, gw, gb, accw,
+                                       add=out if accumulate else add, ldadd=C if (accumulate or add is not None) else 0)
+        if rt.on_param_grad:
+            rt.on_param_grad(g0.weight)
+            rt.on_param_grad(g0.bias)
+        return
     if g1 is None and hip.gn_apply_ok(C, x.ld) and (not accumulate or add is None):
         # two launches (moments; apply + parameter gradients) where moments, reduce, coefficients and affine were four
         (gw, gb), accw = _pgrads_or_scratch(rt, (g0.weight, g0.bias), (C, C))
@@ -972,6 +993,7 @@ def cluster_block(rt, x, m, name=None):
         # ---- MLP branch
         du = rt.new(B, H, W, hid)
         dxn2 = rt.new(B, H, W, C)
+        cs2 = None
         if pmlp:
             # one kernel: d(pre-activation) and the recomputed activation are written once for the two weight gradients,
             # which run beside the rest of the block's backward like every other weight gradient
@@ -981,9 +1003,10 @@ def cluster_block(rt, x, m, name=None):
             conv_backward(rt, xn2, mlp0.fc1, du.t, hid, no_dx=True)
         else:
             conv_backward(rt, h, _attr(mlp, "fc2"), dx2, C, kscale=ls2, aux=u, row_scale=ls2, dx_to=du, ls_grad=ls2)
-            conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2)
+            cs2 = None if paired else gn_colstats(rt, m0.norm2, x1)     # d xn2's GroupNorm moments from this conv's epilogue
+            conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2, colstats=cs2)
         dx1 = rt.buf(B, H, W, C)
-        gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx1, add=dx2)   # dx1 = dx2 + d(GN -> Mlp branch)
+        gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx1, add=dx2, partials=cs2)   # dx1 = dx2 + d(GN -> Mlp branch)
         # ---- Cluster branch
         do = rt.new(B, H, W, ED)
         conv_backward(rt, o, _attr(tm, "fc2"), dx1, C, kscale=ls1, row_scale=ls1, dx_to=do, ls_grad=ls1)
@@ -1016,9 +1039,12 @@ def cluster_block(rt, x, m, name=None):
             kwd = dict(pair_rows=rows_half, w2=wd1)
         if not paired and prec == 2:
             kwd["w_planes"] = rt.planes(wcat, 1, C, 2 * ED, B * H * W)
+        cs1 = None if paired else gn_colstats(rt, m0.norm1, x)
+        if cs1 is not None:
+            kwd["colstats"] = cs1
         hip.conv2d(dfv.t, 2 * ED, wd, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1, precision=prec, **kwd)
         dx = rt.buf(B, H, W, C)
-        gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx, add=dx1)     # dx = dx1 + d(GN -> Cluster branch)
+        gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx, add=dx1, partials=cs1)     # dx = dx1 + d(GN -> Cluster branch)
         rt.give_grad(x, dx)
     rt.push(bwd)
     return x2
@@ -2057,6 +2083,7 @@ class WeightPrep:
         self.convs, self.mlps = {}, {}
         self.waited = {}            # (event name, stream id) -> True
         st.wait_stream(cur)
+        self.first_conv = None
         with torch.cuda.stream(st):
             for mod in model.modules():
                 w = getattr(mod, "weight", None)
@@ -2066,8 +2093,15 @@ class WeightPrep:
                     p = rt.buf(kh * kw, co, ci)
                     hip.pack_weight(w, p, co, ci, kh, kw)
                     self.convs[mod] = p
-            self.ev_small = torch.cuda.Event()
-            self.ev_small.record(st)
+                    if self.first_conv is None:
+                        # the 3 x 3 conv of the first ImageEnhanceByRadar (registered first) is the fourth kernel of the forward:
+                        # it only waits for ITS pack; every other pack is first used behind wait_all()
+                        self.first_conv = mod
+                        self.ev_small = torch.cuda.Event()
+                        self.ev_small.record(st)
+            if self.first_conv is None:
+                self.ev_small = torch.cuda.Event()
+                self.ev_small.record(st)
             refresh()
             if rt.fused_mlp and (rt.bf16 or rt.fp32_precision == 2):
                 prec = 1 if rt.bf16 else 2
@@ -2097,7 +2131,10 @@ class WeightPrep:
 
     def conv_pack(self, conv):
         p = self.convs.get(conv)
-        return p if (p is not None and self._wait("small", self.ev_small)) else None
+        if p is None:
+            return None
+        ok = self._wait("small", self.ev_small) if conv is self.first_conv else self._wait("all", self.ev_all)
+        return p if ok else None
 
     def mlp_pack(self, mlp, pmlp, record):
         ent = self.mlps.get(mlp)
@@ -2180,6 +2217,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         rt.branch_priority = bool(getattr(model, "branch_priority", False))
         rt.early_wgrads = int(getattr(model, "early_wgrads", 2))
         rt.fused_fusion = bool(getattr(model, "fused_fusion", True))
+        rt.gn_colstats = bool(getattr(model, "gn_colstats", False))
         rt.overlap_fusion = bool(getattr(model, "overlap_fusion", True))     # RadarEnhanceByImage beside the image chain (round 5)
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
         rt.bn_colstats = bool(getattr(model, "bn_colstats", True))
@@ -2235,14 +2273,14 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         def refresh_all():
             for fn in refreshes:
                 fn()
+        xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=need_dx)
+        ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=need_dr)
+        hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)      # (issued before the preparation stream's ~35 launches: a
+        hip.nchw_to_nhwc(x_radar.contiguous(), ra.t, 4, B, 4, H * W)  #  replayed graph enqueues its nodes in capture order)
         if rt.concurrent and getattr(model, "weight_prep_stream", True):
             rt.prep = WeightPrep(rt, model, refresh_all)      # on a side stream, beside the input fusion
         else:
             refresh_all()
-        xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=need_dx)
-        ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=need_dr)
-        hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)
-        hip.nchw_to_nhwc(x_radar.contiguous(), ra.t, 4, B, 4, H * W)
         nc, ns = model.num_classes, model.num_seg_classes
         seg = torch.empty((B, ns, H, W), device=x.device)
         dets = [torch.empty((B, 5 + nc, H // s, W // s), device=x.device) for s in (8, 16, 32)]

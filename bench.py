@@ -359,6 +359,7 @@ def main():
     ap.add_argument("--early-wgrads", type=int, default=2, help="a section's deferred weight gradients start right behind it: 0 never, "
                     "1 every section (measured slower), 2 the last section only (default)")
     ap.add_argument("--no-fused-fusion", action="store_true", help="fusion blocks without the fused passes of csrc/fusion.hip (A/B aid)")
+    ap.add_argument("--gn-colstats", action="store_true", help="GroupNorm-backward moments from the data-gradient conv's epilogue (experiment)")
     ap.add_argument("--no-weight-prep", action="store_true", help="per-step weight packs on the main chain, as rounds 1-4 (A/B aid)")
     ap.add_argument("--diagnostic", action="store_true",
                     help="allow VRNET_* environment knobs and the diagnostic library build (tools/sweep_env.sh ablations); the "
@@ -413,6 +414,7 @@ def main():
     model.weight_planes = not args.no_weight_planes
     model.bn_colstats = not args.no_bn_colstats
     model.overlap_fusion = not args.no_overlap_fusion
+    model.gn_colstats = args.gn_colstats
     model.fused_fusion = not args.no_fused_fusion
     model.early_wgrads = args.early_wgrads
     model.branch_priority = args.branch_priority
