@@ -336,6 +336,43 @@ def test_data_parallel_wrapper_single_rank(A):
     assert abs(float(loss) - float(loss_of(*ref(x, r)).detach())) < 1e-5 * abs(float(loss))
 
 
+@pytest.mark.parametrize("phi,size,batch", [("nano", 128, 2), ("s", 256, 2)])
+def test_round5_schedule_and_fused_passes_agree_with_the_round4_forms(A, phi, size, batch):
+    """Round 5 changed HOW the program runs, not what it computes: RadarEnhanceByImage beside the image chain of the next stage
+    (model.overlap_fusion), the fused passes of the fusion blocks (model.fused_fusion: csrc/fusion.hip, sa_cat_sums), the weight
+    preparation on a side stream (model.weight_prep_stream), early weight gradients of the last section (model.early_wgrads).
+    With all of them off the program is round 4's; outputs, BatchNorm statistics and every gradient must agree to rounding
+    (the fused passes reassociate a few sums: column statistics per workgroup instead of per chunk), and the default program
+    must repeat itself bit for bit."""
+    def loss_of(det, seg):
+        return sum((d * d).mean() for d in det) + (seg * seg).mean()
+    x, r = A.synthetic_inputs(batch, size, 9)
+    x, r = x.cuda(), r.cuda()
+
+    def run(**flags):
+        m = build(A, phi, size, 13, True)
+        for k, v in flags.items():
+            setattr(m, k, v)
+        det, seg = m(x, r)
+        loss_of(det, seg).backward()
+        torch.cuda.synchronize()
+        return ([d.detach() for d in det] + [seg.detach()], {k: p.grad for k, p in m.named_parameters() if p.grad is not None},
+                {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    new = run()
+    again = run()
+    old = run(overlap_fusion=False, fused_fusion=False, weight_prep_stream=False, early_wgrads=0)
+    for a, b in zip(new[0], again[0]):
+        assert torch.equal(a, b)
+    assert all(torch.equal(new[1][k], again[1][k]) for k in new[1])
+    for a, b in zip(new[0], old[0]):
+        assert ((a - b).abs().max() / b.abs().max()).item() < 2e-5
+    for k in old[2]:
+        assert torch.allclose(new[2][k], old[2][k], rtol=1e-5, atol=1e-6), k
+    assert new[1].keys() == old[1].keys()
+    worst = max(((new[1][k] - old[1][k]).norm() / old[1][k].norm().clamp_min(1e-20)).item() for k in old[1])
+    assert worst < 2e-3, worst      # (a tied arg-max or ReLU bit decided the other way would show up here as percents)
+
+
 def test_recorded_order_fixture_is_current(A, golden_dir):
     """tests/golden/dp_ready_pos.json -- the backward execution order the CPU test of the 8-GPU segment / bucket plan is built
     on (tests/test_data_parallel_gloo.py::test_n8_plan_at_l) -- equals what a recording pass of THIS program stamps (the
