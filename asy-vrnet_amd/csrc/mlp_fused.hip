@@ -33,6 +33,7 @@ struct MlpArgs {
   const float* res; long ldres;        // forward: residual input
   const float* res_scale;              // forward: layer scale [C] (NULL = 1)
   double* stats; int stats_nb;         // forward: (sum, sumsq) of the stored outputs per 32 x 32 tile (igemm_common.h)
+  const float* x2; long ldx2;          // backward with recomputed pre-activation (RC): the forward's input rows (normalised block input)
   int M, HID;
   int dbg;                             // diagnostic build only (VRNET_MLP_DBG): bit 0 = skip the hidden-sized stores, bit 1 =
                                        // counted wait that leaves the stores in flight (unsafe: timing experiments only)
@@ -57,14 +58,20 @@ __device__ __forceinline__ void mlp_st4(float* base, long off, const f32x4 v, bo
     *reinterpret_cast<vr_bf16x4*>(reinterpret_cast<unsigned short*>(base) + off) = b;
   }
 }
-template <int C, int MODE, int NPL, bool HB = false>
+// RC (backward only, round 5): the pre-activation u = W1 x + b1 is RECOMPUTED per chunk (one more GEMM against the forward's
+// fc1 fragments, which ride in the same stage: [fc2^T | fc1^T | fc1]) instead of read -- the forward then stores no hidden-sized
+// tensor at all and the backward reads one less (stage 0 at bs 8: 268 of 870 MB).  The recomputed accumulator IS the forward's
+// (same fragments, same MFMA order), so with fp32 hidden tensors the results are the unfused kernel's bits.
+template <int C, int MODE, int NPL, bool HB = false, bool RC = false>
 __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const MlpArgs p) {
+  static_assert(!RC || MODE == 1, "recompute is a backward variant");
   constexpr int KS = C / 16;                          // k16 steps of the first GEMM
   constexpr int CB = C / 32;                          // 32-channel row blocks of the second GEMM
-  constexpr int A_BYTES = KS * NPL * 1024, B_BYTES = 2 * CB * NPL * 1024, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = KS * NPL * 1024, B_BYTES = 2 * CB * NPL * 1024, ST_BYTES = A_BYTES + B_BYTES + (RC ? A_BYTES : 0);
   constexpr int NPIECE = ST_BYTES / 1024, PPW = NPIECE / 4;       // 1 KB DMA pieces per stage / per wave
   static_assert(NPIECE % 4 == 0, "whole pieces per wave");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ST_BYTES + MLP_HID_MAX * 4];
+  constexpr int BIAS_MAX = RC ? (C <= 64 ? 1024 : 1536) : MLP_HID_MAX;      // (RC: two workgroups of C = 64 must fit 160 KB of LDS)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ST_BYTES + BIAS_MAX * 4];
   float* bias_s = reinterpret_cast<float*>(smem + 2 * ST_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
   const long row = live ? pix : 0;
   const int nchunks = p.HID >> 5;
 
-  if (MODE == 0 && p.bias_a) {
+  if ((MODE == 0 || RC) && p.bias_a) {
     for (int i = tid; i < p.HID; i += 256) bias_s[i] = p.bias_a[i];
   }
   // ---- the wave's X operand: lane (pixel, hf) holds channels 16 ks + 8 hf .. + 7 of every k16 step
@@ -91,6 +98,17 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
       }
       if constexpr (NPL == 3) vr_split3(lo, hi, xs[ks]);
       else xs[ks][0] = vr_round8(lo, hi);
+    }
+  }
+  vr_bf16x8 x2s[RC ? KS : 1][NPL];      // RC: the forward's X operand, for the recomputed first GEMM
+  if constexpr (RC) {
+    const float* xr = p.x2 + row * p.ldx2 + 8 * hf;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(xr + 16 * ks);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(xr + 16 * ks + 4);
+      if constexpr (NPL == 3) vr_split3(lo, hi, x2s[ks]);
+      else x2s[ks][0] = vr_round8(lo, hi);
     }
   }
   __syncthreads();        // bias copy visible; every ordinary load above has retired before the first DMA is counted
@@ -113,7 +131,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
 
   // backward: the pre-activations of a chunk are requested one chunk ahead, together with that chunk's DMA
   f32x4 uin[4], unext[4];
-  if (MODE == 1) {
+  if (MODE == 1 && !RC) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) uin[j] = mlp_ld4(p.upre, row * p.ldu + 8 * j + 4 * hf, HB);
   }
@@ -130,7 +148,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
     asm volatile("" ::: "memory");
     if (hc + 1 < nchunks) {
       issue(hc + 1);
-      if (MODE == 1) {
+      if (MODE == 1 && !RC) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           unext[j] = mlp_ld4(p.upre, row * p.ldu + 32 * (hc + 1) + 8 * j + 4 * hf, HB);
@@ -151,6 +169,25 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
       else T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], xs[ks][0], T, 0, 0, 0);
     }
 
+    if constexpr (RC) {      // u = W1 x + b1 of this chunk, recomputed: the forward's first GEMM on the third region of the stage
+      f32x16 U;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) U[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        vr_bf16x8 a[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+          a[pl] = *reinterpret_cast<const vr_bf16x8*>(st + A_BYTES + B_BYTES + (ks * NPL + pl) * 1024);
+        if constexpr (NPL == 3) U = vr_mfma_x6(a, x2s[ks], U);
+        else U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], x2s[ks][0], U, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uin[j] = f32x4{U[4 * j], U[4 * j + 1], U[4 * j + 2], U[4 * j + 3]};
+        if (p.bias_a) uin[j] += *reinterpret_cast<const f32x4*>(bias_s + 32 * hc + 8 * j + 4 * hf);
+      }
+    }
     // ---- elementwise step.  Accumulator register 4 j + e of lane (pixel, hf) = hidden unit 32 hc + 8 j + 4 hf + e.
     f32x4 t4[4];
 #pragma unroll
@@ -203,7 +240,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mlp_fused_kernel(const M
         else Y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], hs[0], Y[cb], 0, 0, 0);
       }
     }
-    if (MODE == 1) {
+    if (MODE == 1 && !RC) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) uin[j] = unext[j];
     }
@@ -264,9 +301,10 @@ __device__ __forceinline__ unsigned short mlp_rne_bf16(float v) {
 }
 __device__ __forceinline__ float mlp_bf16_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
+// wc != nullptr: a third region per chunk, the A fragments of wc (the recompute variant's fc1 rows): slots KS + 2 CB .. + KS - 1
 __global__ void mlp_pack_kernel(const float* wa, long sa_r, long sa_c, const float* wb, long sb_r, long sb_c, int HID, int C,
-                                int npl, unsigned short* out) {
-  const int KS = C / 16, CB = C / 32, SLOTS = KS + 2 * CB;
+                                int npl, unsigned short* out, const float* wc = nullptr, long sc_r = 0, long sc_c = 0) {
+  const int KS = C / 16, CB = C / 32, SLOTS = KS + 2 * CB + (wc ? KS : 0);
   const long total = (long)(HID / 32) * SLOTS * 64;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
@@ -278,6 +316,10 @@ __global__ void mlp_pack_kernel(const float* wa, long sa_r, long sa_c, const flo
   if (s < KS) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = wa[(long)(32 * hc + r) * sa_r + (long)(16 * s + 8 * hf + e) * sa_c];
+  } else if (s >= KS + 2 * CB) {
+    const int s3 = s - KS - 2 * CB;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = wc[(long)(32 * hc + r) * sc_r + (long)(16 * s3 + 8 * hf + e) * sc_c];
   } else {
     const int k2 = (s - KS) / CB, cb = (s - KS) % CB;
 #pragma unroll
@@ -328,6 +370,23 @@ extern "C" int vrnet_mlp_pack_f32(const float* w1, const float* w2, int C, int H
     hipLaunchKernelGGL(mlp_pack_kernel, dim3(vr_cdiv(total, 256)), dim3(256), 0, st, w2, 1L, (long)HID, w1, 1L, (long)C, HID, C,
                        npl, reinterpret_cast<unsigned short*>(pack_bwd));
   VR_LAUNCH_CHECK("mlp_pack");
+  return VR_OK;
+}
+
+/* Pack of the backward kernel that recomputes the pre-activation (vrnet_mlp_bwd_rc_f32): per chunk [fc2^T | fc1^T | fc1]. */
+extern "C" long vrnet_mlp_pack_rc_bytes(int C, int HID, int precision) {
+  const int npl = precision == 2 ? 3 : 1;
+  return (long)(HID / 32) * (2 * (C / 16) + 2 * (C / 32)) * npl * 1024;
+}
+extern "C" int vrnet_mlp_pack_rc_f32(const float* w1, const float* w2, int C, int HID, int precision, void* pack, void* stream) {
+  VR_CHECK_ARG(w1 && w2 && pack, "mlp_pack_rc: null tensor");
+  VR_CHECK_ARG(vrnet_mlp_fused_ok(C, HID, 32) && HID <= (C <= 64 ? 1024 : 1536), "mlp_pack_rc: no recompute kernel for C = %d, hidden = %d", C, HID);
+  VR_CHECK_ARG(precision == 1 || precision == 2 || precision == 4, "mlp_pack_rc: precision 2 (x6) or 1 / 4 (bf16-rounded operands)");
+  const int npl = precision == 2 ? 3 : 1;
+  const long total = (long)(HID / 32) * (2 * (C / 16) + 2 * (C / 32)) * 64;
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(vr_cdiv(total, 256)), dim3(256), 0, vr_stream(stream), w2, 1L, (long)HID, w1, 1L, (long)C, HID, C,
+                     npl, reinterpret_cast<unsigned short*>(pack), w1, (long)C, 1L);
+  VR_LAUNCH_CHECK("mlp_pack_rc");
   return VR_OK;
 }
 
@@ -396,5 +455,42 @@ extern "C" int vrnet_mlp_bwd_f32(const float* dy, long lddy, const float* dy_sca
   else mlp_launch<128>(p, 1, precision, vr_stream(stream));
   vr_note_kernel(precision == 2 ? 7 : 8);
   VR_LAUNCH_CHECK("mlp_bwd");
+  return VR_OK;
+}
+
+/* vrnet_mlp_bwd_f32 WITHOUT the stored pre-activation (round 5): u = W1 x + b1 is recomputed chunk by chunk from the forward's
+ * input rows x (the normalised block input; fp32, row stride ldx) against pack = vrnet_mlp_pack_rc_f32's [fc2^T | fc1^T | fc1]
+ * -- the forward pass (vrnet_mlp_fwd_f32 with upre = NULL) then writes no hidden-sized tensor and this kernel reads one less.
+ * precision 2: h, du fp32 -- bit-identical to vrnet_mlp_bwd_f32 on the stored u; 4: h, du bf16 tensors (u itself stays fp32-
+ * accurate here, where precision 4 of the stored form rounded it to bf16).  HID <= 1024 (C = 64) / 1536 (C = 128). */
+extern "C" int vrnet_mlp_bwd_rc_f32(const float* dy, long lddy, const float* dy_scale, const void* pack, const float* x, long ldx,
+                                    const float* b1, float* h, long ldh, float* du, long lddu, float* dx, long lddx, long M, int C,
+                                    int HID, int precision, void* stream) {
+  VR_CHECK_ARG(dy && pack && x && h && du && dx, "mlp_bwd_rc: null tensor");
+  VR_CHECK_ARG(vrnet_mlp_fused_ok(C, HID, M) && HID <= (C <= 64 ? 1024 : 1536),
+               "mlp_bwd_rc: no recompute kernel for C = %d, hidden = %d, %ld rows", C, HID, M);
+  VR_CHECK_ARG(precision == 2 || precision == 4, "mlp_bwd_rc: precision 2 (x6, fp32 h / du) or 4 (bf16-rounded operands, bf16 h / du)");
+  VR_CHECK_ARG(M < (1L << 31), "mlp_bwd_rc: too many rows");
+  VR_CHECK_ARG(mlp_vec_ok(dy, lddy) && mlp_vec_ok(x, ldx) && mlp_vec_ok(h, ldh) && mlp_vec_ok(du, lddu) && mlp_vec_ok(dx, lddx) &&
+                   mlp_vec_ok(dy_scale, 0) && mlp_vec_ok(b1, 0) && vr_aligned16(pack),
+               "mlp_bwd_rc: tensors must be 16-byte aligned with row strides that are multiples of 4");
+  VR_CHECK_ARG(lddy >= C && lddx >= C && ldx >= C && ldh >= HID && lddu >= HID, "mlp_bwd_rc: row stride smaller than width");
+  if (vr_ablated("igemm") || vr_ablated("igemm_big")) return VR_OK;
+  MlpArgs p{};
+  p.x = dy; p.ldx = lddy; p.xscale = dy_scale; p.wpack = reinterpret_cast<const unsigned short*>(pack);
+  p.x2 = x; p.ldx2 = ldx; p.bias_a = b1;
+  p.hout = h; p.ldh = ldh; p.du = du; p.lddu = lddu; p.y = dx; p.ldy = lddx;
+  p.M = (int)M; p.HID = HID;
+  const dim3 grid((unsigned)vr_cdiv(M, 128)), block(256);
+  hipStream_t st = vr_stream(stream);
+  if (C == 64) {
+    if (precision == 2) hipLaunchKernelGGL((mlp_fused_kernel<64, 1, 3, false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((mlp_fused_kernel<64, 1, 1, true, true>), grid, block, 0, st, p);
+  } else {
+    if (precision == 2) hipLaunchKernelGGL((mlp_fused_kernel<128, 1, 3, false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((mlp_fused_kernel<128, 1, 1, true, true>), grid, block, 0, st, p);
+  }
+  vr_note_kernel(precision == 2 ? 7 : 8);
+  VR_LAUNCH_CHECK("mlp_bwd_rc");
   return VR_OK;
 }

@@ -50,6 +50,9 @@ _SIGS = {
     "vrnet_mlp_pack_bytes": ([I, I, I], L),
     "vrnet_mlp_pack_f32": ([P, P, I, I, I, P, P, P], I),
     "vrnet_mlp_fwd_f32": ([P, L, P, P, P, P, L, P, P, L, P, L, P, L, I, I, I, P], I),
+    "vrnet_mlp_pack_rc_bytes": ([I, I, I], L),
+    "vrnet_mlp_pack_rc_f32": ([P, P, I, I, I, P, P], I),
+    "vrnet_mlp_bwd_rc_f32": ([P, L, P, P, P, L, P, P, L, P, L, P, L, L, I, I, I, P], I),
     "vrnet_mlp_bwd_f32": ([P, L, P, P, P, L, P, L, P, L, P, L, L, I, I, I, P], I),
     "vrnet_moments_workspace": ([I, L, I], L),
     "vrnet_moments_f32": ([P, L, P, L, P, L, I, L, I, P, P, L, P], I),
@@ -398,6 +401,23 @@ def mlp_pack(w1, w2, C, HID, precision, want_bwd=True):
     bwd = torch.empty((n,), dtype=torch.uint8, device=w1.device) if want_bwd else None
     _check(_lib.vrnet_mlp_pack_f32(ptr(w1), ptr(w2), C, HID, precision, ptr(fwd), ptr(bwd), stream()), "mlp_pack")
     return fwd, bwd
+
+
+def mlp_rc_ok(C, HID):
+    """Whether the recompute form of the fused Mlp backward (mlp_bwd_rc) exists for this block."""
+    return HID <= (1024 if C <= 64 else 1536)
+
+
+def mlp_pack_rc(w1, w2, C, HID, precision):
+    """Planes of the backward kernel that recomputes the pre-activation: per chunk [fc2^T | fc1^T | fc1]."""
+    pack = torch.empty((_lib.vrnet_mlp_pack_rc_bytes(C, HID, precision),), dtype=torch.uint8, device=w1.device)
+    _check(_lib.vrnet_mlp_pack_rc_f32(ptr(w1), ptr(w2), C, HID, precision, ptr(pack), stream()), "mlp_pack_rc")
+    return pack
+
+
+def mlp_bwd_rc(dy, lddy, dy_scale, pack, x, ldx, b1, h, ldh, du, lddu, dx, lddx, M, C, HID, precision):
+    _check(_lib.vrnet_mlp_bwd_rc_f32(ptr(dy), lddy, ptr(dy_scale), ptr(pack), ptr(x), ldx, ptr(b1), ptr(h), ldh, ptr(du), lddu,
+                                     ptr(dx), lddx, M, C, HID, precision, stream()), "mlp_bwd_rc")
 
 
 def mlp_fwd(x, ldx, pack, b1, b2, res, ldres, res_scale, y, ldy, upre, ldu, stats, M, C, HID, precision):

@@ -113,6 +113,7 @@ class RT:
         self.pending_ab = []        # deferred (d alpha, d beta) reductions of the Cluster modules of the section being replayed
         self.sync_batch_total = None   # SyncBatchNorm: global sample count of THIS forward pass
         self.overlap_fusion = True
+        self.mlp_recompute = "auto"  # fused Mlp backward recomputes the pre-activation instead of reading a stored one
         self.gn_colstats = False
         self.fused_fusion = True    # the fused passes of csrc/fusion.hip in the fusion blocks
         self.early_wgrads = 2       # 1 = behind every section: measured (round 5, same call): 25.87-26.06 ms with it against 25.75-25.92 without -- the weight
@@ -364,13 +365,28 @@ class RT:
             self.packed[conv] = p
         return p
 
-    def mlp_packs(self, mlp, C, hid, pmlp):
-        """(forward, backward) weight planes of a fused Mlp (hip.mlp_pack): from the preparation stream when it made them."""
+    def mlp_packs(self, mlp, C, hid, pmlp, rc=False):
+        """(forward, backward) weight planes of a fused Mlp (hip.mlp_pack): from the preparation stream when it made them.
+        rc: the backward pack of the kernel that recomputes the pre-activation (hip.mlp_pack_rc)."""
         if self.prep is not None:
-            got = self.prep.mlp_pack(mlp, pmlp, self.record)
+            got = self.prep.mlp_pack(mlp, (pmlp, rc), self.record)
             if got is not None:
                 return got
+        if rc:
+            fwd, _ = hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, pmlp, want_bwd=False)
+            return fwd, (hip.mlp_pack_rc(mlp.fc1.weight, mlp.fc2.weight, C, hid, pmlp) if self.record else None)
         return hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, pmlp, want_bwd=self.record)
+
+    def mlp_rc(self, C, hid, bf16_tensors):
+        """Whether a fused Mlp block runs without a stored pre-activation (model.mlp_recompute: "auto" = where it measured
+        faster -- the 64-channel stage in fp32, where the backward is HBM-bound; both fused stages with bf16 tensors, where the
+        extra GEMM is one product instead of six)."""
+        mode = self.mlp_recompute
+        if not mode or not self.record or not hip.mlp_rc_ok(C, hid):
+            return False
+        if mode == "auto":
+            return bool(bf16_tensors) or C <= 64
+        return True
 
     def prec_fwd(self, lda, ci, co):
         """precision flag of a forward conv launch: 1 = bf16-rounded operands (compute_dtype "bf16"); 2 = fp32 products
@@ -964,14 +980,16 @@ def cluster_block(rt, x, m, name=None):
     x1 = rt.new(B, H, W, C)
     conv_call(rt, o, _attr(tm, "fc2"), x1, res=x, res_scale=ls1, stats=True)
     hid = mlp0.fc1.weight.shape[0]
-    u = rt.new(B, H, W, hid, need_grad=False) if rt.record else None
     x2 = rt.new(B, H, W, C)
     pmlp = 0 if paired else rt.prec_mlp(C, hid, B * H * W, H * W)
+    mlp_rc = bool(pmlp) and pmlp == 2 and rt.mlp_rc(C, hid, False)
+    u = rt.new(B, H, W, hid, need_grad=False) if (rt.record and not mlp_rc) else None
     xn2, ms2 = gn_forward(rt, x1, _attr(m, "norm2"))
     if pmlp:
         # fc1 -> GELU -> fc2 (+ layer-scale residual, + GroupNorm statistics of the output) as ONE kernel: the hidden
-        # activation never reaches HBM; only the pre-activation is stored, for the backward pass
-        packs = rt.mlp_packs(mlp0, C, hid, pmlp)
+        # activation never reaches HBM; only the pre-activation is stored, for the backward pass -- or (mlp_rc) nothing at all:
+        # the backward kernel recomputes it from xn2
+        packs = rt.mlp_packs(mlp0, C, hid, pmlp, rc=mlp_rc)
         pairs, per = hip.conv_stats_buffer(B, H * W, C, x.t.device)
         hip.mlp_fwd(xn2.t, xn2.ld, packs[0], mlp0.fc1.bias, mlp0.fc2.bias, x1.t, x1.ld, ls2, x2.t, C,
                     None if u is None else u.t, hid, pairs, B * H * W, C, hid, pmlp)
@@ -998,7 +1016,10 @@ def cluster_block(rt, x, m, name=None):
             # one kernel: d(pre-activation) and the recomputed activation are written once for the two weight gradients,
             # which run beside the rest of the block's backward like every other weight gradient
             hb = rt.new(B, H, W, hid, need_grad=False)
-            hip.mlp_bwd(dx2, C, ls2, packs[1], u.t, hid, hb.t, hid, du.t, hid, dxn2.t, C, B * H * W, C, hid, pmlp)
+            if mlp_rc:
+                hip.mlp_bwd_rc(dx2, C, ls2, packs[1], xn2.t, xn2.ld, mlp0.fc1.bias, hb.t, hid, du.t, hid, dxn2.t, C, B * H * W, C, hid, 2)
+            else:
+                hip.mlp_bwd(dx2, C, ls2, packs[1], u.t, hid, hb.t, hid, du.t, hid, dxn2.t, C, B * H * W, C, hid, pmlp)
             conv_backward(rt, hb, mlp0.fc2, dx2, C, row_scale=ls2, ls_grad=ls2, no_dx=True)
             conv_backward(rt, xn2, mlp0.fc1, du.t, hid, no_dx=True)
         else:
@@ -1143,7 +1164,8 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
     # operands of the two weight gradients -- are bf16 in HBM (hip.mlp_fwd / mlp_bwd precision 4) and the weight gradients take
     # them as they are (hip.wgrad_planes, np = 1)
     mlp_hb = bool(pmlp) and np_ == 1 and rt.pg_wgrad and hip.wgrad_planes_ok(M, hid, C) and hip.wgrad_planes_ok(M, C, hid)
-    u_b = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=x.t.device) if (mlp_hb and rec) else None
+    mlp_rc = mlp_hb and rt.mlp_rc(C, hid, True)          # ... and u not stored at all: the backward kernel recomputes it from xn2
+    u_b = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=x.t.device) if (mlp_hb and rec and not mlp_rc) else None
     # two-launch Mlp on bf16 tensors with fc1 forward and fc2 data gradient both on plane GEMMs: u (the GELU' argument) as a
     # bf16 tensor too, as the fused kernels keep it at precision 4
     u_half = np_ == 1 and not pmlp and fc1[0] and fc2[1]
@@ -1168,10 +1190,10 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
             hip.planes_from_f32(xn2_f.t, C, M, C, xn2_p)
     h_f = h_p = packs = None
     if pmlp:
-        packs = rt.mlp_packs(mlp, C, hid, pmlp)
+        packs = rt.mlp_packs(mlp, C, hid, pmlp, rc=mlp_rc)
         pairs, per = stats_buf(C)
         hip.mlp_fwd(xn2_f.t, C, packs[0], mlp.fc1.bias, mlp.fc2.bias, x1.t, x1.ld, ls2, x2.t, C,
-                    None if u is None else (u_b if mlp_hb else u.t), hid, pairs, M, C, hid, 4 if mlp_hb else pmlp)
+                    None if (u is None or mlp_rc) else (u_b if mlp_hb else u.t), hid, pairs, M, C, hid, 4 if mlp_hb else pmlp)
         if pairs is not None:
             x2.pairs = (pairs, per)
     else:
@@ -1249,7 +1271,10 @@ def cluster_block_planes(rt, x, m, name, plan, pmlp):
         dxn2 = f32(C)
         if mlp_hb:
             hb_p, du_p = P(hid), P(hid)
-            hip.mlp_bwd(dx2, C, ls2, packs[1], u_b, hid, hb_p.t[0], hid, du_p.t[0], hid, dxn2.t, C, M, C, hid, 4)
+            if mlp_rc:
+                hip.mlp_bwd_rc(dx2, C, ls2, packs[1], xn2_f.t, C, mlp.fc1.bias, hb_p.t[0], hid, du_p.t[0], hid, dxn2.t, C, M, C, hid, 4)
+            else:
+                hip.mlp_bwd(dx2, C, ls2, packs[1], u_b, hid, hb_p.t[0], hid, du_p.t[0], hid, dxn2.t, C, M, C, hid, 4)
             dx2_p = planes_of(dx2, C, dx2_p)
             wgrad(None, hb_p, dx2, dx2_p, mlp.fc2, hid, C, True, row_scale=ls2, ls=ls2)
             wgrad(None, xn2_p, None, du_p, mlp.fc1, C, hid, True)
@@ -2111,7 +2136,14 @@ class WeightPrep:
                         continue
                     hid, C = mlp.fc1.weight.shape[0], mlp.fc1.weight.shape[1]
                     if hip.mlp_fused_ok(C, hid, 32):
-                        self.mlps[mlp] = (prec, hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, prec, want_bwd=rt.record))
+                        # (bf16 mode: the blocks run at precision 4 when their hidden tensors are bf16 -- same planes as 1)
+                        rc = rt.mlp_rc(C, hid, rt.bf16)
+                        if rc:
+                            fwd, _ = hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, prec, want_bwd=False)
+                            packs = (fwd, hip.mlp_pack_rc(mlp.fc1.weight, mlp.fc2.weight, C, hid, prec))
+                        else:
+                            packs = hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, prec, want_bwd=rt.record)
+                        self.mlps[mlp] = ((prec, rc), packs)
             self.ev_all = torch.cuda.Event()
             self.ev_all.record(st)
         self.stream = st
@@ -2218,6 +2250,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         rt.early_wgrads = int(getattr(model, "early_wgrads", 2))
         rt.fused_fusion = bool(getattr(model, "fused_fusion", True))
         rt.gn_colstats = bool(getattr(model, "gn_colstats", False))
+        rt.mlp_recompute = getattr(model, "mlp_recompute", "auto")
         rt.overlap_fusion = bool(getattr(model, "overlap_fusion", True))     # RadarEnhanceByImage beside the image chain (round 5)
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
         rt.bn_colstats = bool(getattr(model, "bn_colstats", True))

@@ -360,6 +360,7 @@ def main():
                     "1 every section (measured slower), 2 the last section only (default)")
     ap.add_argument("--no-fused-fusion", action="store_true", help="fusion blocks without the fused passes of csrc/fusion.hip (A/B aid)")
     ap.add_argument("--gn-colstats", action="store_true", help="GroupNorm-backward moments from the data-gradient conv's epilogue (experiment)")
+    ap.add_argument("--mlp-recompute", default="auto", help="fused Mlp backward recomputes the pre-activation: auto (default), all, off")
     ap.add_argument("--no-weight-prep", action="store_true", help="per-step weight packs on the main chain, as rounds 1-4 (A/B aid)")
     ap.add_argument("--diagnostic", action="store_true",
                     help="allow VRNET_* environment knobs and the diagnostic library build (tools/sweep_env.sh ablations); the "
@@ -414,6 +415,7 @@ def main():
     model.weight_planes = not args.no_weight_planes
     model.bn_colstats = not args.no_bn_colstats
     model.overlap_fusion = not args.no_overlap_fusion
+    model.mlp_recompute = {"off": False, "all": True}.get(args.mlp_recompute, "auto")
     model.gn_colstats = args.gn_colstats
     model.fused_fusion = not args.no_fused_fusion
     model.early_wgrads = args.early_wgrads

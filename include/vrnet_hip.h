@@ -253,6 +253,16 @@ int vrnet_mlp_fwd_f32(const float* x, long ldx, const void* pack_fwd, const floa
 int vrnet_mlp_bwd_f32(const float* dy, long lddy, const float* dy_scale, const void* pack_bwd, const float* upre, long ldu,
                       float* h, long ldh, float* du, long lddu, float* dx, long lddx, long M, int C, int HID, int precision,
                       void* stream);
+/* The backward kernel WITHOUT a stored pre-activation (round 5, ABI 9): u = W1 x + b1 is recomputed chunk by chunk from the forward's
+ * input rows x (the normalised block input: fp32, row stride ldx) against pack = vrnet_mlp_pack_rc_f32's per-chunk
+ * [fc2^T | fc1^T | fc1] planes; the forward (vrnet_mlp_fwd_f32 with upre = NULL) then writes no hidden-sized tensor and the
+ * backward reads one less.  precision 2: fp32 h / du, bit-identical to vrnet_mlp_bwd_f32 on the stored u; 4: bf16-rounded
+ * operands, bf16 h / du.  Hidden widths up to 1024 (C = 64) / 1536 (C = 128). */
+long vrnet_mlp_pack_rc_bytes(int C, int HID, int precision);
+int vrnet_mlp_pack_rc_f32(const float* w1, const float* w2, int C, int HID, int precision, void* pack, void* stream);
+int vrnet_mlp_bwd_rc_f32(const float* dy, long lddy, const float* dy_scale, const void* pack, const float* x, long ldx,
+                         const float* b1, float* h, long ldh, float* du, long lddu, float* dx, long lddx, long M, int C, int HID,
+                         int precision, void* stream);
 
 /* ---- per-(sample, channel) moments in fp64 ---------------------------------------------------------
  * out[b][c] = { sum_p x, sum_p x*x }                    (x2 == NULL)

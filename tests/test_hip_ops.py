@@ -1132,6 +1132,26 @@ def test_fused_mlp_against_fp64(hip, case, precision):
     close(hb, uu * cdf, 2e-6, what="recomputed h")
     close(du, du_ref, 2e-5, what="du")
     close(dx, dx_ref, tol, what="dx")
+    # ---- the backward that RECOMPUTES u from x (round 5: vrnet_mlp_bwd_rc_f32; no stored hidden tensor): at precision 2 its u is
+    # the forward's accumulator again -- same fragments, same MFMA order -- so h, du, dx are the stored-u kernel's bits
+    if precision == 2 and hip.mlp_rc_ok(C, hid):
+        rc = hip.mlp_pack_rc(w1.cuda(), w2.cuda(), C, hid, 2)
+        hb2, du2, dx2 = torch.empty_like(hb), torch.empty_like(du), torch.empty_like(dx)
+        hip.mlp_bwd_rc(dy.cuda(), C, ls.cuda(), rc, xg, C, b1.cuda(), hb2, hid, du2, hid, dx2, C, M, C, hid, 2)
+        assert hip.last_kernel() == 7
+        assert torch.equal(hb2, hb) and torch.equal(du2, du) and torch.equal(dx2, dx)
+    if precision == 1 and hip.mlp_rc_ok(C, hid):
+        # bf16-rounded operands, bf16 h / du (precision 4), u recomputed in fp32: against the fp64 reference from the exact u
+        rc = hip.mlp_pack_rc(w1.cuda(), w2.cuda(), C, hid, 4)
+        hb4 = torch.empty(M, hid, dtype=torch.bfloat16, device="cuda")
+        du4, dx4 = torch.empty_like(hb4), torch.empty_like(dx)
+        hip.mlp_bwd_rc(dy.cuda(), C, ls.cuda(), rc, xg, C, b1.cuda(), hb4, hid, du4, hid, dx4, C, M, C, hid, 4)
+        ue = u_ref
+        cdf_e = 0.5 * (1 + torch.erf(ue / np.sqrt(2.0)))
+        gp_e = cdf_e + ue * torch.exp(-0.5 * ue * ue) / np.sqrt(2 * np.pi)
+        close(hb4.float(), ue * cdf_e, 6e-3, what="rc h (bf16)")
+        close(du4.float(), dh * gp_e, 6e-3, what="rc du (bf16)")
+        close(dx4, d(rd((dh * gp_e).float())) @ d(rd(w1)), 4e-3, what="rc dx")
 
 
 @pytest.mark.parametrize("case", MLP_CASES[:3])
