@@ -78,7 +78,7 @@ def pmc_traffic_bytes(phi):
         return None
     n, tot = 0, 0.0
     for row in csv.DictReader(open(files[-1])):
-        if row["kernel"].startswith(("igemm_kernel", "igemm_dma_kernel", "igemm_planes_kernel", "mlp_fused_kernel", "tiny::conv_kernel",
+        if row["kernel"].startswith(("igemm_kernel", "igemm_dma_kernel", "igemm_planes_kernel", "mlp_fused_kernel", "tiny::conv_kernel", "tiny::conv_fixed_kernel",
                                      "narrow::fwd_kernel", "narrow::dgrad_kernel")):
             k = int(row["launches"])
             n += k
@@ -152,7 +152,7 @@ class ConvTimer:
         self.hip = hip
         self.rec = {"igemm": [], "wgrad": [], "cluster_fwd": [], "cluster_bwd": []}
         self.orig = (hip.conv2d, hip.conv2d_wgrad, hip.cluster_fwd, hip.cluster_bwd)
-        self.orig_mlp = (hip.mlp_fwd, hip.mlp_bwd)
+        self.orig_mlp = (hip.mlp_fwd, hip.mlp_bwd, hip.mlp_bwd_rc)
         self.orig_planes = (hip.gemm_planes, hip.wgrad_planes)
 
     def __enter__(self):
@@ -191,7 +191,7 @@ class ConvTimer:
             rec["cluster_bwd"].append((5.0 * B * H * W * E * Dh * 4, e0, e1, f"{H}x{W} E{E} D{Dh} fold{fold}"))      # read f, v, g; write df, dv
             return out                # (the workspace holding the (d alpha, d beta) partials when their reduction is deferred)
         hip.conv2d, hip.conv2d_wgrad, hip.cluster_fwd, hip.cluster_bwd = conv2d, conv2d_wgrad, cluster_fwd, cluster_bwd
-        o_mf, o_mb = self.orig_mlp
+        o_mf, o_mb, o_mbrc = self.orig_mlp
 
         # the fused Mlp launches belong to the same kernel class (dense conv forward / data gradient): one launch does
         # the work of two 1x1 convs, 2 * (2 * M * C * HID) FLOPs
@@ -210,7 +210,15 @@ class ConvTimer:
             o_mb(*a)
             e1.record()
             rec["igemm"].append((4.0 * M * C * HID, e0, e1, f"mlpB M{M} C{C} H{HID} k{hip.last_kernel()}", hip.last_kernel()))
-        hip.mlp_fwd, hip.mlp_bwd = mlp_fwd, mlp_bwd
+
+        def mlp_bwd_rc(*a):       # (the recomputed first GEMM is not algorithmic work: the same 4 M C HID as mlp_bwd)
+            M, C, HID = a[-4], a[-3], a[-2]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_mbrc(*a)
+            e1.record()
+            rec["igemm"].append((4.0 * M * C * HID, e0, e1, f"mlpBrc M{M} C{C} H{HID} k{hip.last_kernel()}", hip.last_kernel()))
+        hip.mlp_fwd, hip.mlp_bwd, hip.mlp_bwd_rc = mlp_fwd, mlp_bwd, mlp_bwd_rc
         o_gp, o_wp = self.orig_planes
 
         # the plane GEMMs (csrc/pgemm.hip) are launches of the same two classes: a 1x1 conv's forward / data gradient, its
@@ -233,7 +241,7 @@ class ConvTimer:
 
     def __exit__(self, *a):
         self.hip.conv2d, self.hip.conv2d_wgrad, self.hip.cluster_fwd, self.hip.cluster_bwd = self.orig
-        self.hip.mlp_fwd, self.hip.mlp_bwd = self.orig_mlp
+        self.hip.mlp_fwd, self.hip.mlp_bwd, self.hip.mlp_bwd_rc = self.orig_mlp
         self.hip.gemm_planes, self.hip.wgrad_planes = self.orig_planes
 
     def summary(self, key):

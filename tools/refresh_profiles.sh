@@ -22,13 +22,17 @@ VRNET_BENCH_FORCE_DP=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-n
 [ -x tools/micro/x6_peak.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/x6_peak.hip -o tools/micro/x6_peak.bin
 (echo "# tools/micro/x6_peak.hip: register-resident x6 inner loop, no memory (mfma only / splits only / both)"; timeout 300 tools/micro/x6_peak.bin 2>&1 | grep -v amdgpu.ids) > $out/x6_issue_ceiling_micro.txt
 cp $out/x6_issue_ceiling_micro.txt profiles/${R}_x6_issue_ceiling_micro.txt
-# ---- isolated probes: the plane GEMMs of round 4 against the in-kernel-split kernels, forward and weight gradient
-(echo "# python tools/pgemm_probe.py  (single 1x1-conv GEMM launches alone: r3 x6 kernel with pre-split weights vs plane GEMM np = 3 / 1; weight gradients)"; timeout 900 python3 tools/pgemm_probe.py 2>&1 | grep -v amdgpu.ids) > $out/pgemm_probe.txt
+# ---- isolated probe: the Cluster kernels alone
 (echo "# python tools/cluster_probe.py  (Cluster kernels alone, phi = l, bs 8, 512 px)"; timeout 300 python3 tools/cluster_probe.py 2>&1 | grep -v amdgpu.ids) > $out/cluster_probe.txt
-# ---- diagnostic build: in-kernel ablations of the plane GEMM, launch-skipping ablations of the step
+# ---- same-call A/B against the previous round's head (a worktree under .ab/base, built), when present
+if [ -d .ab/base ]; then
+  (echo "# tools/ab.sh 3: ms per step, the round-4 head (.ab/base) against this tree, alternating runs of one call"; bash tools/ab.sh 3 "round4-head|.ab/base|" "round5|.|" 2>&1) > $out/ab_vs_round4_head.txt
+  (echo "# the switches of round 5, one at a time (ms per step, same call)"
+   for f in "" "--no-overlap-fusion" "--no-fused-fusion" "--no-weight-prep" "--early-wgrads 0" "--mlp-recompute off" ""; do
+     ms=$(python3 bench.py --no-cpu-baseline --no-roofline $f 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])"); echo "[$f] $ms"; done) > $out/ab_round5_switches.txt
+fi
+# ---- diagnostic build: launch-skipping ablations of the step
 export VRNET_HIP_LIB=$PWD/asy-vrnet_amd/csrc/libvrnet_hip_tuning.so
-(echo "# VRNET_PGEMM_DBG bits: 1 no MFMAs, 2 no DMA inside the loop, 4 no fragment reads (timing ablations of pgemm_kernel<3>, results garbage)"
- for d in 0 1 2 3 4 5 6 7; do echo "== VRNET_PGEMM_DBG=$d"; VRNET_PGEMM_DBG=$d timeout 300 python3 tools/pgemm_probe.py 8192 320 1280 8192 1280 320 32768 1024 256 131072 256 64 2>&1 | grep "np=3  "; done) > $out/pgemm_ablation.txt
 tools/sweep_env.sh "" "VRNET_ABLATE=igemm" "VRNET_ABLATE=wgrad" "VRNET_ABLATE=igemm,wgrad" "VRNET_ABLATE=moments,affine" \
     "VRNET_ABLATE=cluster" "VRNET_ABLATE=misc,dwconv" "VRNET_ABLATE=igemm,wgrad,moments,affine,cluster,misc,dwconv" \
     "VRNET_ABLATE=igemm_small,wgrad_small" "VRNET_ABLATE=igemm_mid,wgrad_mid" "VRNET_ABLATE=igemm_big,wgrad_big" \
