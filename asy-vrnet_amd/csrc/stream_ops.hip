@@ -1450,13 +1450,19 @@ extern "C" int vrnet_eca_coef_fwd(const double* mom, const float* wk, int k, int
 
 extern "C" int vrnet_eca_coef_bwd(const double* mom2, const double* mom, const float* gate, const float* wk, int k,
                                   int B, long HW, int C, float* F, float* dwk, int accumulate, void* stream) {
-  VR_CHECK_ARG(mom2 && mom && gate && wk && F && dwk, "eca_coef_bwd: null tensor");
-  hipLaunchKernelGGL(eca_coef_bwd_kernel, dim3(vr_cdiv((long)B * C, 256)), dim3(256), 0, vr_stream(stream), mom2, gate,
-                     wk, k, B, HW, C, F);
-  VR_LAUNCH_CHECK("eca_coef_bwd");
-  hipLaunchKernelGGL(eca_dwk_kernel, dim3(k), dim3(256), 0, vr_stream(stream), mom2, mom, gate, k, B, HW, C, dwk,
-                     accumulate);
-  VR_LAUNCH_CHECK("eca_dwk");
+  // F == NULL or dwk == NULL (ABI 9): only the other half -- the kernel-weight gradient is needed by nobody on the backward
+  // chain, so the caller may issue it on a side stream
+  VR_CHECK_ARG(mom2 && mom && gate && wk && (F || dwk), "eca_coef_bwd: null tensor");
+  if (F) {
+    hipLaunchKernelGGL(eca_coef_bwd_kernel, dim3(vr_cdiv((long)B * C, 256)), dim3(256), 0, vr_stream(stream), mom2, gate,
+                       wk, k, B, HW, C, F);
+    VR_LAUNCH_CHECK("eca_coef_bwd");
+  }
+  if (dwk) {
+    hipLaunchKernelGGL(eca_dwk_kernel, dim3(k), dim3(256), 0, vr_stream(stream), mom2, mom, gate, k, B, HW, C, dwk,
+                       accumulate);
+    VR_LAUNCH_CHECK("eca_dwk");
+  }
   return VR_OK;
 }
 

@@ -916,9 +916,11 @@ def ds_base_conv(rt, x, m, out=None):
         dt = take_grad(t)
         gw, acc = rt.pgrad(dconv.weight)
         if gw is not None:
-            hip.dwconv3x3_wgrad(x.t, x.ld, dt, C, gw, x.B, x.H, x.W, C, accumulate=acc)
-            if rt.on_param_grad:
-                rt.on_param_grad(dconv.weight)
+            def dw_wgrad(acc=acc):   # (round 5: off the chain like every other weight gradient -- two launches, ~21 us per layer,
+                hip.dwconv3x3_wgrad(x.t, x.ld, dt, C, gw, x.B, x.H, x.W, C, accumulate=acc)      # that the data gradient below
+                if rt.on_param_grad:                                                            # used to queue behind)
+                    rt.on_param_grad(dconv.weight)
+            rt.aside(dw_wgrad, (x.t, dt))
         if x.need_grad:
             buf, acc = rt.grad_target(x)
             hip.dwconv3x3(dt, C, dconv.weight, buf, C, x.B, x.H, x.W, C, flip=1, accumulate=acc)
@@ -1582,9 +1584,13 @@ def eca(rt, x, m, mom=None):
         gw, acc = rt.pgrad(m.conv.weight)
         if gw is None:
             gw, acc = rt.buf(k), 0
-        hip.eca_coef_bwd(mom2, mom, gate, wk, k, B, HW, C, Fc, gw, acc)
-        if rt.on_param_grad:
-            rt.on_param_grad(m.conv.weight)
+        hip.eca_coef_bwd(mom2, mom, gate, wk, k, B, HW, C, Fc, None, 0)
+
+        def kernel_weight_grad():        # (13 us that no later backward kernel waits for: off the chain, like a weight gradient)
+            hip.eca_coef_bwd(mom2, mom, gate, wk, k, B, HW, C, None, gw, acc)
+            if rt.on_param_grad:
+                rt.on_param_grad(m.conv.weight)
+        rt.aside(kernel_weight_grad, (mom2, mom, gate))
         if x.need_grad:
             buf, accx = rt.grad_target(x)
             hip.affine(buf, C, B, HW, C, x1=g, ld1=C, A=gate, D2=Fc, bstride=C, accumulate=accx)
@@ -1786,16 +1792,19 @@ def backbone_forward(rt, bb, x, r):
             gb, accb = rt.pgrad(conv.bias)
             if gw is not None:
                 assert gb is None or accb == accw
-                gw2 = rt.buf(co, KT)
-                if gb is not None and accb:       # one accumulate flag covers dw and dbias: start the scratch dw at 0
-                    hip.fill_(gw2, 0.0)
-                hip.conv2d_wgrad(patches.t, KT, g, co, gw2, gb, None, B, OH, OW, KT, OH, OW, co, 1, 1, 1, 0, 1,
-                                 accumulate=0 if gb is None else accb, precision=rt.prec_wgrad(KT, co, KT, co))
-                hip.weight_ohwi(gw2, gw, co, ci, kh, kw, 1, accumulate=accw)
-                if rt.on_param_grad:
-                    rt.on_param_grad(conv.weight)
-                    if gb is not None:
-                        rt.on_param_grad(conv.bias)
+
+                def embed_wgrad():       # (round 5: off the chain -- a 131 072-row weight gradient sat in front of the data
+                    gw2 = rt.buf(co, KT)  #  gradient on the tail of the backward pass)
+                    if gb is not None and accb:       # one accumulate flag covers dw and dbias: start the scratch dw at 0
+                        hip.fill_(gw2, 0.0)
+                    hip.conv2d_wgrad(patches.t, KT, g, co, gw2, gb, None, B, OH, OW, KT, OH, OW, co, 1, 1, 1, 0, 1,
+                                     accumulate=0 if gb is None else accb, precision=rt.prec_wgrad(KT, co, KT, co))
+                    hip.weight_ohwi(gw2, gw, co, ci, kh, kw, 1, accumulate=accw)
+                    if rt.on_param_grad:
+                        rt.on_param_grad(conv.weight)
+                        if gb is not None:
+                            rt.on_param_grad(conv.bias)
+                rt.aside(embed_wgrad, (patches.t, g))
             if act.need_grad:
                 dp = rt.buf(B, OH, OW, KT)
                 wd, _, prec = rt.dgrad_operands(conv, w2, w2, co, KT, 1, 1, None, co)

@@ -364,7 +364,8 @@ int vrnet_bn_coef_bwd(const double* mom2, const float* mean_rstd, const float* g
                       void* stream);
 /* eca_block (backbone/attention_modules/eca.py:16-22): gate[b][c] = sigmoid(conv1d_k(mean_hw x)). */
 int vrnet_eca_coef_fwd(const double* mom, const float* wk, int k, int B, long HW, int C, float* gate, void* stream);
-/* mom2 = moments(dy, x2 = x): dx = gate*dy + F[b][c]; dwk [k]. */
+/* mom2 = moments(dy, x2 = x): dx = gate*dy + F[b][c]; dwk [k].  F or dwk may be NULL (ABI 9): only the other half is computed
+ * (dwk, the Conv1d weight gradient, is needed by nothing on the backward chain: a caller may issue it on a side stream). */
 int vrnet_eca_coef_bwd(const double* mom2, const double* mom, const float* gate, const float* wk, int k, int B,
                        long HW, int C, float* F, float* dwk, int accumulate, void* stream);
 /* Layer scale x + ls*o (vr_coc.py:266-271), mom2 = moments(dx, x2 = o): dls[c] = sum dx*o; dbias = ls * sum dx.
