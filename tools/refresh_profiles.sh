@@ -33,6 +33,7 @@ if [ -d .ab/base ]; then
 fi
 # ---- diagnostic build: launch-skipping ablations of the step
 export VRNET_HIP_LIB=$PWD/asy-vrnet_amd/csrc/libvrnet_hip_tuning.so
+[ asy-vrnet_amd/csrc/libvrnet_hip_tuning.so -nt asy-vrnet_amd/csrc/libvrnet_hip.so ] || echo "STALE diagnostic build (run make tuning after make)" >&2
 tools/sweep_env.sh "" "VRNET_ABLATE=igemm" "VRNET_ABLATE=wgrad" "VRNET_ABLATE=igemm,wgrad" "VRNET_ABLATE=moments,affine" \
     "VRNET_ABLATE=cluster" "VRNET_ABLATE=misc,dwconv" "VRNET_ABLATE=igemm,wgrad,moments,affine,cluster,misc,dwconv" \
     "VRNET_ABLATE=igemm_small,wgrad_small" "VRNET_ABLATE=igemm_mid,wgrad_mid" "VRNET_ABLATE=igemm_big,wgrad_big" \
