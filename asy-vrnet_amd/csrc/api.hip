@@ -47,6 +47,15 @@ void vr_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Diagnostic: one thread writes the device's constant-rate clock (100 MHz) to *dst at the point of `stream` where it is issued --
+// timelines of the captured step without a tracer attached (tools/debug/section_stamps.py).
+__global__ void clock_stamp_kernel(long long* dst) { *dst = (long long)wall_clock64(); }
+extern "C" int vrnet_clock_stamp(long long* dst, void* stream) {
+  if (!dst) return VR_ERR_ARG;
+  hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst);
+  return VR_OK;
+}
+
 extern "C" int vrnet_abi_version(void) { return 9; }
 extern "C" const char* vrnet_last_error(void) { return g_err; }
 

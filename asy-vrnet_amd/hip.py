@@ -132,6 +132,7 @@ _SIGS = {
     "vrnet_mt_sgd_f32": ([P, P, P, P, P, I, I, I, F, F, I, I, P], I),
     "vrnet_mt_adam_f32": ([P, P, P, P, P, I, I, I, F, F, F, F, I, P], I),
     "vrnet_mt_ema_f32": ([P, P, P, P, I, I, I, F, P], I),
+    "vrnet_clock_stamp": ([P, P], I),
     "vrnet_mt_copy_f32": ([P, P, P, P, I, I, I, P], I),
     "vrnet_sa_bwd_f32": ([P, L, P, L, P, P, P, P] + [P] * 6 + [P, L] + [P] * 6 + [P, I, L, I, I, I, I, P, L, P], I),
 }
@@ -609,6 +610,11 @@ def nhwc_to_nchw(src, lds, dst, B, C, HW, accumulate=0):
 
 def add_(dst, src):
     _check(_lib.vrnet_add_f32(ptr(dst), ptr(src), dst.numel(), stream()), "add")
+
+
+def clock_stamp(buf, slot):
+    """buf[slot] (int64) = the device clock (100 MHz) when the stream reaches this point (diagnostic)."""
+    _check(_lib.vrnet_clock_stamp(buf.data_ptr() + 8 * slot, stream()), "clock_stamp")
 
 
 def fill_(dst, value):

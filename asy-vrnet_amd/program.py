@@ -119,7 +119,17 @@ class RT:
         self.early_wgrads = 2       # 1 = behind every section: measured (round 5, same call): 25.87-26.06 ms with it against 25.75-25.92 without -- the weight
                                     # gradients then contend with the small kernels of the critical chain they were meant to fill
         self.branch_priority = False
+        self.stamps = None          # diagnostic: (int64 buffer, [names]) -- rt.stamp(name) writes the device clock in stream order
         self.via_autograd = False   # parameter gradients go back through torch.autograd (stock DistributedDataParallel)
+
+    def stamp(self, name):
+        """Diagnostic (model.debug_stamps): the device clock at this point of the current stream (tools/debug/section_stamps.py)."""
+        if self.stamps is None:
+            return
+        buf, names = self.stamps
+        if len(names) < buf.numel():
+            hip.clock_stamp(buf, len(names))
+            names.append(name)
 
     # ---- fork / join of independent chains -------------------------------------------------------------
     _side_streams = {}
@@ -268,7 +278,9 @@ class RT:
             self.tape = []
             self._chain = (self._depth, bi)
             with torch.cuda.stream(st):
+                self.stamp(f"  fwd site {site} chain {bi} start")
                 outs.append(fn())
+                self.stamp(f"  fwd site {site} chain {bi} end")
             subtapes.append(self.tape)
         self._chain = outer_chain
         self._depth -= 1
@@ -290,10 +302,15 @@ class RT:
                     st.wait_stream(cur_b)
                     self._chain = (self._depth, bi)
                     with torch.cuda.stream(st):
+                        self.stamp(f"  bwd site {site} chain {bi} start")
                         for f in reversed(sub):
                             f()
+                        self.stamp(f"  bwd site {site} chain {bi} end")
                 self._chain = outer
                 self._depth -= 1
+                # (round 5, measured neutral and not kept: joining the weight-gradient streams only at the next section -- the
+                # join of the stage-1 section waits 0.45 ms for stage 2's weight gradients, but the step is bound by the work,
+                # not by that wait: 24.44 vs 24.47 ms; a chain of the last section issuing its own weight gradients: +0.1 ms)
                 for st in list(streams) + list(wstreams):
                     cur_b.wait_stream(st)
                 held.clear()
@@ -1903,20 +1920,29 @@ def _backbone_overlapped(rt, bb, x, r, embed, chain):
         x_prev, xa = x, branch_alias(rt, x)
 
         def branch_a(i=i, x_prev=x_prev, pi=pi):
+            rt.stamp(f"s{i} A start")
             a = embed(x_prev, bb.patch_embed) if i == 0 else simple_conv(rt, x_prev, bb.network[3 * (i - 1) + 2].proj)
-            return a, chain(a, bb.network[3 * i], pi)
+            out = a, chain(a, bb.network[3 * i], pi)
+            rt.stamp(f"s{i} A end")
+            return out
 
         def branch_b(i=i, xa=xa, r_in=r_in, re_mod=re_mod, pr=pr):
+            rt.stamp(f"s{i} B start")
             rr = radar_enhance(rt, xa, r_in, re_mod)
+            rt.stamp(f"s{i} B RE done")
             b = embed(rr, bb.patch_embed_radar) if i == 0 else simple_conv(rt, rr, bb.network_radar[3 * (i - 1) + 2].proj)
-            return rr, b, chain(b, bb.network_radar[3 * i], pr)
+            out = rr, b, chain(b, bb.network_radar[3 * i], pr)
+            rt.stamp(f"s{i} B end")
+            return out
         if i == 0 and rt.prep is not None:
             rt.prep.wait_all()      # the first consumers of the weight planes / Mlp packs / [fc1 ; fc_v] copies: stage 0
+        rt.stamp(f"s{i} fork")
         (tap_a, xs), (rr, tap_b, rs) = rt.parallel([branch_a, branch_b], site=2)
         if i == 1:
             outs_r[0] = rr                                       # RadarEnhance output at 1/4 resolution
         if i in (1, 2):
             outs[i], outs_r[i] = tap_a, tap_b                    # the reducers' outputs (inputs of stages 1, 2)
+        rt.stamp(f"s{i} join")
         x = image_enhance(rt, xs, rs, bb.network[3 * i + 1])
         if i in (0, 3):
             outs[0 if i == 0 else 3] = x
@@ -2256,6 +2282,11 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         # two-stream chain 31.6 ms/step (and 1 480 instead of 2 070 launches): the default is the faster one
         rt.pair_streams = bool(getattr(model, "pair_streams", False))
         rt.branch_priority = bool(getattr(model, "branch_priority", False))
+        if getattr(model, "debug_stamps", False):
+            if getattr(model, "_stamp_buf", None) is None:
+                model._stamp_buf = torch.zeros(512, dtype=torch.int64, device=x.device)
+            model._stamp_names = []
+            rt.stamps = (model._stamp_buf, model._stamp_names)
         rt.early_wgrads = int(getattr(model, "early_wgrads", 2))
         rt.fused_fusion = bool(getattr(model, "fused_fusion", True))
         rt.gn_colstats = bool(getattr(model, "gn_colstats", False))
@@ -2317,6 +2348,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
                 fn()
         xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=need_dx)
         ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=need_dr)
+        rt.stamp("step start")
         hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)      # (issued before the preparation stream's ~35 launches: a
         hip.nchw_to_nhwc(x_radar.contiguous(), ra.t, 4, B, 4, H * W)  #  replayed graph enqueues its nodes in capture order)
         if rt.concurrent and getattr(model, "weight_prep_stream", True):
@@ -2327,7 +2359,9 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         seg = torch.empty((B, ns, H, W), device=x.device)
         dets = [torch.empty((B, 5 + nc, H // s, W // s), device=x.device) for s in (8, 16, 32)]
         feats, seg_lo = neck_forward(rt, model.backbone, xa, ra, seg)
+        rt.stamp("neck done")
         head_forward(rt, model.head, feats, dets)
+        rt.stamp("forward done")
     model._last_idx_maps = rt.idx_maps
     if rt.relu_masks is not None:        # {BatchNorm state_dict prefix: (B,H,W,C) bool}: which ReLU inputs were > 0
         names = {mod: k for k, mod in model.named_modules()}
@@ -2356,6 +2390,7 @@ def backward_begin(rt, gdets, gseg):
         raise RuntimeError("EfficientVRNet backward called twice (activations are freed after the first pass)")
     rt.det_grads, rt.seg_grad = tuple(gdets), gseg
     rt.tape_pos = len(rt.tape)
+    rt.stamp("backward begin")
 
 
 def backward_range(rt, lo, hi, flush_each=False):
@@ -2367,6 +2402,8 @@ def backward_range(rt, lo, hi, flush_each=False):
             rt.tape_pos = i
             rt.tape[i]()
             rt.flush_cluster_ab()
+            if rt.stamps is not None:
+                rt.stamp(f"bwd {i} {'P ' if getattr(rt.tape[i], 'is_parallel', False) else ''}{getattr(rt.tape[i], '__qualname__', '?').split('.')[0]}")
             if not flush_each and rt.early_wgrads and i > lo and not getattr(rt.tape[i - 1], "is_parallel", False):
                 # the next closure is main-chain work: the section's weight gradients run beside it.  Mode 2 (default): only
                 # behind the LAST section of chains (stage 0) -- its weight gradients (the largest maps) otherwise run after
@@ -2396,6 +2433,7 @@ def backward_end(rt, model, inputs, needs, params=None, needs_params=None):
     """Input gradients (NCHW) and publication of the parameter gradients; frees the tape."""
     with torch.cuda.device(rt.device):
         backward_cut(rt)
+        rt.stamp("backward joined")
         rt.tape = None
         outs = []
         for act, need in zip(inputs, needs):

@@ -34,6 +34,9 @@ int vrnet_last_kernel(void);
 /* Launches of kernel family `family` (same codes) issued by this process (all threads) since the library was loaded. */
 long vrnet_kernel_launches(int family);
 const char* vrnet_last_error(void);          /* host string, thread local */
+/* Diagnostic: a one-thread kernel writes the device's constant-rate clock (wall_clock64, 100 MHz) to *dst in stream order:
+ * section timelines of the captured step without a tracer attached (no reference counterpart). */
+int vrnet_clock_stamp(long long* dst, void* stream);
 /* 0 for the product library, which reads NO environment variable; 1 for the diagnostic build (make tuning:
  * libvrnet_hip_tuning.so, -DVR_TUNING) in which the VRNET_* dispatch knobs and the VRNET_ABLATE launch-skipping timing
  * ablation exist.  Benchmarks must refuse a library that answers 1. */

@@ -521,3 +521,28 @@ def test_forward_without_backward_frees_its_activations_at_once(A):
                 assert held <= max(1 << 20, peak // 50), (mode, held, peak)
     finally:
         gc.enable()
+
+
+def test_section_stamps_follow_the_program_order(A):
+    """model.debug_stamps (tools/debug/section_stamps.py): device-clock stamps at the forks, chain ends and joins of the program --
+    the untraced timeline of the step.  On one stream they must be monotone; a chain starts after its fork and the join comes
+    after both chain ends; outputs are unchanged by the stamps."""
+    m = build(A, "nano", 128, 5, True)
+    g = torch.Generator().manual_seed(3)
+    x, r = torch.randn(2, 3, 128, 128, generator=g).cuda(), torch.randn(2, 4, 128, 128, generator=g).cuda()
+    det0, seg0 = m(x, r)
+    m.debug_stamps = True
+    det, seg = m(x, r)
+    (sum(d.square().mean() for d in det) + seg.square().mean()).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(seg, seg0) and all(torch.equal(a, b) for a, b in zip(det, det0))
+    names = m._stamp_names
+    ticks = m._stamp_buf[:len(names)].cpu().tolist()
+    t = dict(zip(names, ticks))         # (the chain stamps of rt.parallel repeat per section: the named ones below are unique)
+    assert names[0] == "step start" and names[-1] == "backward joined"
+    main = [v for n, v in zip(names, ticks) if not n.startswith(" ") and " A " not in n and " B " not in n]
+    assert all(a <= b for a, b in zip(main, main[1:])), list(zip(names, ticks))
+    for i in range(4):
+        assert t[f"s{i} fork"] <= min(t[f"s{i} A start"], t[f"s{i} B start"])
+        assert max(t[f"s{i} A end"], t[f"s{i} B end"]) <= t[f"s{i} join"]
+    assert t["backward joined"] - t["step start"] > 0
