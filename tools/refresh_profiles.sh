@@ -57,6 +57,9 @@ rm -rf gpurun_out/pmc_traffic
 bash tools/pmc_mfma.sh $out/mfma_util_pmc_phi-l_bs8_512.csv > $out/pmc_mfma.log 2>&1
 rm -rf gpurun_out/pmc_mfma
 python3 tools/join_hbm_rate.py $out/hbm_traffic_pmc_phi-l_bs8_512.csv $out/kernel_stats_phi-l_bs8_512_serial.csv > $out/hbm_rate_per_kernel_phi-l_bs8_512.csv 2>/dev/null
+# ---- the replayed step WITHOUT a tracer: device-clock stamps at the forks / chain ends / joins (a tracer delays the second chain)
+(echo "# python tools/debug/section_stamps.py   (phi = l, bs 8, 512 px, fp32; device clock, us)"; python3 tools/debug/section_stamps.py 2>&1 | grep -v amdgpu.ids) > $out/section_timeline_untraced_phi-l_bs8_512.txt
+(echo "# python tools/debug/section_stamps.py --bf16 --batch 16"; python3 tools/debug/section_stamps.py --bf16 --batch 16 2>&1 | grep -v amdgpu.ids) > $out/section_timeline_untraced_phi-l_bs16_512_bf16.txt
 # ---- the headline line LAST, with the PMC traffic of THIS kernel source in place (bench.py checks the source hash), by the
 # driver's exact command
 cp $out/hbm_traffic_pmc_phi-l_bs8_512.csv profiles/${R}_hbm_traffic_pmc_phi-l_bs8_512.csv
