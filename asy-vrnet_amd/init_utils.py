@@ -54,8 +54,9 @@ def randomize_state_dict(sd, seed=0):
 
 
 def synthetic_inputs(batch, size, seed, device="cpu"):
-    """x ~ N(0,1) (B,3,S,S), x_radar ~ U(0,1) (B,4,S,S)  (vr_coc.py:817-818 uses rand)."""
-    rng = np.random.default_rng([seed, batch, size])
-    x = torch.from_numpy(rng.standard_normal((batch, 3, size, size), dtype=np.float32))
-    r = torch.from_numpy(rng.random((batch, 4, size, size), dtype=np.float32))
+    """x ~ N(0,1) (B,3,S,S), x_radar ~ U(0,1) (B,4,S,S)  (vr_coc.py:817-818 uses rand); size may be (H, W)."""
+    h, w = (size, size) if isinstance(size, int) else size
+    rng = np.random.default_rng([seed, batch, size] if isinstance(size, int) else [seed, batch, h, w])
+    x = torch.from_numpy(rng.standard_normal((batch, 3, h, w), dtype=np.float32))
+    r = torch.from_numpy(rng.random((batch, 4, h, w), dtype=np.float32))
     return x.to(device), r.to(device)

@@ -243,6 +243,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "fp64":        # only the double-precision 512 px case
         whole_net("net_nano_512_train_fp64", "nano", 512, 2, True, 3, 9, seg_stride=16, dtype=torch.float64)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "rect":        # only the rectangular case (round 5): H != W
+        whole_net("net_nano_128x192_train", "nano", [128, 192], 2, True, 5, 11, seg_stride=2)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "decisions":   # only the two cases that also pin the reference's hard decisions
         whole_net("net_nano_128_train", "nano", 128, 2, True, 2, 8, decisions=True)
         whole_net("net_nano_512_train", "nano", 512, 2, True, 3, 9, seg_stride=8, decisions=True)
@@ -261,6 +264,7 @@ def main():
     whole_net("net_tiny_128_eval", "tiny", 128, 1, False, 4, 10, with_grads=False)
     whole_net("net_nano_512_train", "nano", 512, 2, True, 3, 9, seg_stride=8, decisions=True)
     whole_net("net_nano_512_train_fp64", "nano", 512, 2, True, 3, 9, seg_stride=16, dtype=torch.float64)
+    whole_net("net_nano_128x192_train", "nano", [128, 192], 2, True, 5, 11, seg_stride=2)
     # ---- sub-modules (seeded inputs: shape, seed, kind recorded in meta)
     def case(name, mod, shapes, kinds=None, **meta):
         kinds = kinds or ["normal"] * len(shapes)

@@ -94,7 +94,8 @@ def load_reference():
 def build_reference_model(num_classes=4, num_seg_classes=9, phi="nano", img_size=512):
     """EfficientVRNet with fea_pos sized for img_size."""
     ref = load_reference()
-    ref.neck.coc_small = functools.partial(ref.orig_coc_small, img_w=img_size, img_h=img_size)
+    iw, ih = (img_size, img_size) if isinstance(img_size, int) else img_size      # (H, W): the reference's img_w is the FIRST
+    ref.neck.coc_small = functools.partial(ref.orig_coc_small, img_w=iw, img_h=ih)   # spatial axis (vr_coc.py:402-407, 583-585)
     try:
         model = ref.evr.EfficientVRNet(num_classes=num_classes, num_seg_classes=num_seg_classes, phi=phi)
     finally:
