@@ -561,3 +561,18 @@ def test_rectangular_input_against_oracle(A, phi, hw, batch, training):
     rep = compare_with_oracle(m, batch, hw, iseed=13, check_grads=training, oracle_dtype=torch.float64)
     print(rep)
     assert rep["ok"], rep
+
+
+def test_batch_one_training_raises_like_the_reference(A):
+    """A training-mode forward of ONE sample: ASPP's global-pool branch puts a (1, C, 1, 1) tensor through a train-mode
+    BatchNorm2d (coc_fpn_dual.py:97-101), which PyTorch rejects ("Expected more than 1 value per channel when training");
+    the reference therefore cannot train at batch 1 and neither can this path -- same error text, no silent statistics.
+    Evaluation at batch 1 works (net_tiny_128_eval)."""
+    m = build(A, "nano", 64, 1, True)
+    x, r = A.synthetic_inputs(1, 64, 2)
+    with pytest.raises(RuntimeError, match="Expected more than 1 value per channel when training"):
+        m(x.cuda(), r.cuda())
+    m.eval()
+    with torch.no_grad():
+        det, seg = m(x.cuda(), r.cuda())
+    assert seg.shape == (1, 9, 64, 64) and all(torch.isfinite(d).all() for d in det)
