@@ -356,8 +356,16 @@ __device__ __forceinline__ void src_index(float scale, int o, int in_size, int* 
   *l1 = r - (float)a;
 }
 
+// bnA != nullptr (round 5, K11): the taps are ReLU(BatchNorm(z)) of the pre-normalisation map x = z, evaluated on the fly as
+// fmaxf(fma(A[c], z - S[c], D[c]), 0) -- the expression of the apply kernel (stream_ops.hip bn_pre), so the result has the bits of
+// affine + upsample while the low-resolution activation is never stored.
+__device__ __forceinline__ float up_tap(float v, const float* bnA, const float* bnD, const float* bnS, int c) {
+  return bnA ? fmaxf(__builtin_fmaf(bnA[c], v - bnS[c], bnD[c]), 0.f) : v;
+}
+
 __global__ __launch_bounds__(256) void upsample_kernel(const float* x, long ldx, float* y, long ldy, int B, int H,
-                                                       int W, int C, int OH, int OW, int out_nchw) {
+                                                       int W, int C, int OH, int OW, int out_nchw, const float* bnA,
+                                                       const float* bnD, const float* bnS) {
   const float ry = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float rx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
   const long total = (long)B * OH * OW * C;
@@ -374,8 +382,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* x, long ldx,
     src_index(ry, oy, H, &y0, &y1, &ly);
     src_index(rx, ox, W, &x0, &x1, &lx);
     const float* base = x + (b * H * W) * ldx + c;
-    const float v00 = base[((long)y0 * W + x0) * ldx], v01 = base[((long)y0 * W + x1) * ldx];
-    const float v10 = base[((long)y1 * W + x0) * ldx], v11 = base[((long)y1 * W + x1) * ldx];
+    const float v00 = up_tap(base[((long)y0 * W + x0) * ldx], bnA, bnD, bnS, c), v01 = up_tap(base[((long)y0 * W + x1) * ldx], bnA, bnD, bnS, c);
+    const float v10 = up_tap(base[((long)y1 * W + x0) * ldx], bnA, bnD, bnS, c), v11 = up_tap(base[((long)y1 * W + x1) * ldx], bnA, bnD, bnS, c);
     const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
     if (out_nchw) y[e] = v;
     else y[((b * OH + oy) * OW + ox) * ldy + c] = v;
@@ -385,7 +393,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* x, long ldx,
 // NHWC output on 16-byte accesses: a thread interpolates four consecutive channels of one output pixel (index arithmetic
 // once per quad; the same expression per component as the scalar kernel).
 __global__ __launch_bounds__(256) void upsample_vec_kernel(const float* x, long ldx, float* y, long ldy, int B, int H, int W,
-                                                           int C, int OH, int OW) {
+                                                           int C, int OH, int OW, const float* bnA, const float* bnD,
+                                                           const float* bnS) {
   const float ry = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float rx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
   const int CQ = C >> 2;
@@ -401,10 +410,20 @@ __global__ __launch_bounds__(256) void upsample_vec_kernel(const float* x, long 
     src_index(ry, oy, H, &y0, &y1, &ly);
     src_index(rx, ox, W, &x0, &x1, &lx);
     const float* base = x + (b * H * W) * ldx + 4 * cq;
-    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((long)y0 * W + x0) * ldx);
-    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((long)y0 * W + x1) * ldx);
-    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((long)y1 * W + x0) * ldx);
-    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((long)y1 * W + x1) * ldx);
+    f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((long)y0 * W + x0) * ldx);
+    f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((long)y0 * W + x1) * ldx);
+    f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((long)y1 * W + x0) * ldx);
+    f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((long)y1 * W + x1) * ldx);
+    if (bnA) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * cq + j;
+        v00[j] = up_tap(v00[j], bnA, bnD, bnS, c);
+        v01[j] = up_tap(v01[j], bnA, bnD, bnS, c);
+        v10[j] = up_tap(v10[j], bnA, bnD, bnS, c);
+        v11[j] = up_tap(v11[j], bnA, bnD, bnS, c);
+      }
+    }
     f32x4 v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = (1.f - ly) * ((1.f - lx) * v00[j] + lx * v01[j]) + ly * ((1.f - lx) * v10[j] + lx * v11[j]);
@@ -462,7 +481,8 @@ __global__ __launch_bounds__(256) void upsample_bwd_vec_kernel(const float* dy, 
 // NCHW output (the seg logits, C = num_seg_classes): a thread writes four consecutive ox of one (b, c, oy) row as one 16-byte
 // store; the row pair and its weight are found once per thread.  Same expression per output as upsample_kernel.
 __global__ __launch_bounds__(256) void upsample_nchw4_kernel(const float* x, long ldx, float* y, int B, int H, int W, int C,
-                                                             int OH, int OW) {
+                                                             int OH, int OW, const float* bnA, const float* bnD,
+                                                             const float* bnS) {
   const float ry = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float rx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
   const int OQ = OW >> 2;
@@ -484,7 +504,8 @@ __global__ __launch_bounds__(256) void upsample_nchw4_kernel(const float* x, lon
       int x0, x1;
       float lx;
       src_index(rx, 4 * oq + j, W, &x0, &x1, &lx);
-      const float v00 = r0[(long)x0 * ldx], v01 = r0[(long)x1 * ldx], v10 = r1[(long)x0 * ldx], v11 = r1[(long)x1 * ldx];
+      const float v00 = up_tap(r0[(long)x0 * ldx], bnA, bnD, bnS, c), v01 = up_tap(r0[(long)x1 * ldx], bnA, bnD, bnS, c);
+      const float v10 = up_tap(r1[(long)x0 * ldx], bnA, bnD, bnS, c), v11 = up_tap(r1[(long)x1 * ldx], bnA, bnD, bnS, c);
       v[j] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
     }
     *reinterpret_cast<f32x4*>(y + ((b * C + c) * OH + oy) * (long)OW + 4 * oq) = v;
@@ -1007,21 +1028,37 @@ extern "C" int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* 
   return VR_OK;
 }
 
+static int upsample_launch(const float* x, long ldx, float* y, long ldy, int B, int H, int W, int C, int scale, int out_nchw,
+                           const float* bnA, const float* bnD, const float* bnS, void* stream) {
+  if (!out_nchw && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && vr_aligned16(x) && vr_aligned16(y))
+    hipLaunchKernelGGL(upsample_vec_kernel, dim3(grid_for((long)B * H * W * scale * scale * (C / 4))), dim3(256), 0,
+                       vr_stream(stream), x, ldx, y, ldy, B, H, W, C, H * scale, W * scale, bnA, bnD, bnS);
+  else if (out_nchw && (W * scale) % 4 == 0 && vr_aligned16(y))
+    hipLaunchKernelGGL(upsample_nchw4_kernel, dim3(grid_for((long)B * H * W * scale * scale * C / 4)), dim3(256), 0,
+                       vr_stream(stream), x, ldx, y, B, H, W, C, H * scale, W * scale, bnA, bnD, bnS);
+  else
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long)B * H * W * scale * scale * C)), dim3(256), 0,
+                       vr_stream(stream), x, ldx, y, ldy, B, H, W, C, H * scale, W * scale, out_nchw, bnA, bnD, bnS);
+  VR_LAUNCH_CHECK("upsample");
+  return VR_OK;
+}
+
 extern "C" int vrnet_upsample_bilinear_f32(const float* x, long ldx, float* y, long ldy, int B, int H, int W, int C,
                                            int scale, int out_nchw, void* stream) {
   if (vr_ablated("misc")) return VR_OK;
   VR_CHECK_ARG(x && y && scale >= 1 && B > 0 && H > 0 && W > 0 && C > 0, "upsample: bad arguments");
-  if (!out_nchw && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && vr_aligned16(x) && vr_aligned16(y))
-    hipLaunchKernelGGL(upsample_vec_kernel, dim3(grid_for((long)B * H * W * scale * scale * (C / 4))), dim3(256), 0,
-                       vr_stream(stream), x, ldx, y, ldy, B, H, W, C, H * scale, W * scale);
-  else if (out_nchw && (W * scale) % 4 == 0 && vr_aligned16(y))
-    hipLaunchKernelGGL(upsample_nchw4_kernel, dim3(grid_for((long)B * H * W * scale * scale * C / 4)), dim3(256), 0,
-                       vr_stream(stream), x, ldx, y, B, H, W, C, H * scale, W * scale);
-  else
-    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long)B * H * W * scale * scale * C)), dim3(256), 0,
-                       vr_stream(stream), x, ldx, y, ldy, B, H, W, C, H * scale, W * scale, out_nchw);
-  VR_LAUNCH_CHECK("upsample");
-  return VR_OK;
+  return upsample_launch(x, ldx, y, ldy, B, H, W, C, scale, out_nchw, nullptr, nullptr, nullptr, stream);
+}
+
+/* CoCUpsample (coc_fpn_dual.py:15-26: 1x1 conv -> BatchNorm -> ReLU -> bilinear) without the low-resolution activation: the
+ * upsample gathers ReLU(A (z - S) + D) from the conv output z (round 5, K11).  Same bits as vrnet_affine_f32 (pre = 1) followed
+ * by vrnet_upsample_bilinear_f32. */
+extern "C" int vrnet_bn_relu_upsample_bilinear_f32(const float* z, long ldz, const float* A, const float* D, const float* S,
+                                                   float* y, long ldy, int B, int H, int W, int C, int scale, int out_nchw,
+                                                   void* stream) {
+  if (vr_ablated("misc")) return VR_OK;
+  VR_CHECK_ARG(z && A && D && S && y && scale >= 1 && B > 0 && H > 0 && W > 0 && C > 0, "bn_relu_upsample: bad arguments");
+  return upsample_launch(z, ldz, y, ldy, B, H, W, C, scale, out_nchw, A, D, S, stream);
 }
 
 extern "C" int vrnet_upsample_bilinear_bwd_f32(const float* dy, long lddy, int dy_nchw, float* dx, long lddx, int B,

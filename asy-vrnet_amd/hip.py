@@ -100,6 +100,7 @@ _SIGS = {
     "vrnet_dwconv3x3_wgrad_workspace": ([I, I, I, I], L),
     "vrnet_dwconv3x3_wgrad_f32": ([P, L, P, L, P, I, I, I, I, I, P, L, P], I),
     "vrnet_upsample_bilinear_f32": ([P, L, P, L, I, I, I, I, I, I, P], I),
+    "vrnet_bn_relu_upsample_bilinear_f32": ([P, L, P, P, P, P, L, I, I, I, I, I, I, P], I),
     "vrnet_upsample_bilinear_bwd_f32": ([P, L, I, P, L, I, I, I, I, I, I, P], I),
     "vrnet_reduce_workspace": ([], L),
     "vrnet_minmax_f32": ([P, L, P, P, L, P], I),
@@ -688,6 +689,12 @@ def dwconv3x3_wgrad(x, ldx, dy, lddy, dw, B, H, W, C, accumulate=0):
 def upsample(x, ldx, y, ldy, B, H, W, C, scale, out_nchw=0):
     _check(_lib.vrnet_upsample_bilinear_f32(ptr(x), ldx, ptr(y), ldy, B, H, W, C, scale, out_nchw, stream()),
            "upsample")
+
+
+def bn_relu_upsample(z, ldz, A, Dc, S, y, ldy, B, H, W, C, scale, out_nchw=0):
+    """y = upsample(ReLU(A (z - S) + Dc)): BatchNorm apply + ReLU on the taps (CoCUpsample without its low-resolution output)."""
+    _check(_lib.vrnet_bn_relu_upsample_bilinear_f32(ptr(z), ldz, ptr(A), ptr(Dc), ptr(S), ptr(y), ldy, B, H, W, C, scale, out_nchw,
+                                                    stream()), "bn_relu_upsample")
 
 
 def upsample_bwd(dy, lddy, dy_nchw, dx, lddx, B, H, W, C, scale, accumulate=0):

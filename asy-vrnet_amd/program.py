@@ -116,6 +116,7 @@ class RT:
         self.mlp_recompute = "auto"  # fused Mlp backward recomputes the pre-activation instead of reading a stored one
         self.gn_colstats = False
         self.fused_fusion = True    # the fused passes of csrc/fusion.hip in the fusion blocks
+        self.fused_upsample = True  # CoCUpsample: BatchNorm + ReLU applied on the taps of the bilinear gather (K11)
         self.early_wgrads = 2       # 1 = behind every section: measured (round 5, same call): 25.87-26.06 ms with it against 25.75-25.92 without -- the weight
                                     # gradients then contend with the small kernels of the critical chain they were meant to fill
         self.branch_priority = False
@@ -1683,8 +1684,38 @@ def radar_enhance(rt, x, r, m, out=None):
 # ----------------------------------------------------------------------------------------- neck pieces
 def coc_upsample(rt, x, m, nchw_out=None):
     """CoCUpsample.forward (coc_fpn_dual.py:24-26): BaseConv 1x1 -> bilinear, align_corners=True."""
-    lo = base_conv(rt, x, m.upsample[0])
+    bc = m.upsample[0]
     s = m.scale
+    if rt.fused_upsample and not bc.ds_conv and BN_ZMASK and rt.relu_masks is None and rt.sync_bn is None:
+        # (round 5, K11) conv -> [BatchNorm + ReLU on the taps of the bilinear gather]: the low-resolution activation is never
+        # stored (the backward needs z and the forward coefficients only: the ReLU mask is recomputed from them)
+        conv, bn = bc.conv, bc.bn
+        co, ci, kh, kw, st, pd, dl, OH, OW = conv_geom(x, conv)
+        z = rt.new(x.B, OH, OW, co)
+        conv_call(rt, x, conv, z, bias=False, bn_stats=True)
+        cA, cD, cS, ms = bn_fwd_coef(rt, z, bn)
+        ms.fwd_coef = (cA, cD, cS)
+        B, H, W, C = z.B, z.H, z.W, co
+        hi = None if nchw_out is not None else rt.new(B, H * s, W * s, C)
+        if nchw_out is not None:
+            hip.bn_relu_upsample(z.t, C, cA, cD, cS, nchw_out, 0, B, H, W, C, s, out_nchw=1)
+        else:
+            hip.bn_relu_upsample(z.t, C, cA, cD, cS, hi.t, C, B, H, W, C, s)
+
+        def bwd_fused():
+            g = rt.seg_grad if nchw_out is not None else take_grad(hi)
+            if g is None:
+                return
+            dlo = rt.buf(B, H, W, C)
+            if nchw_out is not None:
+                hip.upsample_bwd(g.contiguous(), 0, 1, dlo, C, B, H, W, C, s)
+            else:
+                hip.upsample_bwd(g, C, 0, dlo, C, B, H, W, C, s)
+            dz = bn_backward(rt, bn, z, ms, dlo, C, mask=z)      # (mask: only "there is a ReLU" on this path)
+            conv_backward(rt, x, conv, dz, co)
+        rt.push(bwd_fused)
+        return z if nchw_out is not None else hi
+    lo = base_conv(rt, x, bc)
     B, H, W, C = lo.B, lo.H, lo.W, lo.C
     if nchw_out is not None:
         hip.upsample(lo.t, C, nchw_out, 0, B, H, W, C, s, out_nchw=1)
@@ -2289,6 +2320,7 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
             rt.stamps = (model._stamp_buf, model._stamp_names)
         rt.early_wgrads = int(getattr(model, "early_wgrads", 2))
         rt.fused_fusion = bool(getattr(model, "fused_fusion", True))
+        rt.fused_upsample = bool(getattr(model, "fused_upsample", True))
         rt.gn_colstats = bool(getattr(model, "gn_colstats", False))
         rt.mlp_recompute = getattr(model, "mlp_recompute", "auto")
         rt.overlap_fusion = bool(getattr(model, "overlap_fusion", True))     # RadarEnhanceByImage beside the image chain (round 5)

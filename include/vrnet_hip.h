@@ -451,6 +451,11 @@ int vrnet_dwconv3x3_wgrad_f32(const float* x, long ldx, const float* dy, long ld
  * out_nchw / dy_nchw: the high-resolution side is a contiguous (B,C,OH,OW) tensor (the seg logits). */
 int vrnet_upsample_bilinear_f32(const float* x, long ldx, float* y, long ldy, int B, int H, int W, int C, int scale,
                                 int out_nchw, void* stream);
+/* The same gather from the PRE-normalisation map z of CoCUpsample's 1x1 BaseConv (coc_fpn_dual.py:15-26): every tap is
+ * ReLU(A (z - S) + D) evaluated on the fly (A, D, S per channel: the BatchNorm coefficients), so the low-resolution activation
+ * is never stored.  Bit-identical to vrnet_affine_f32 (pre = 1) + vrnet_upsample_bilinear_f32. */
+int vrnet_bn_relu_upsample_bilinear_f32(const float* z, long ldz, const float* A, const float* D, const float* S, float* y,
+                                        long ldy, int B, int H, int W, int C, int scale, int out_nchw, void* stream);
 int vrnet_upsample_bilinear_bwd_f32(const float* dy, long lddy, int dy_nchw, float* dx, long lddx, int B, int H, int W,
                                     int C, int scale, int accumulate, void* stream);
 

@@ -576,3 +576,23 @@ def test_batch_one_training_raises_like_the_reference(A):
     with torch.no_grad():
         det, seg = m(x.cuda(), r.cuda())
     assert seg.shape == (1, 9, 64, 64) and all(torch.isfinite(d).all() for d in det)
+
+
+@pytest.mark.parametrize("phi,size", [("nano", 128), ("s", 128)])
+def test_fused_upsample_has_the_bits_of_the_three_launch_form(A, phi, size):
+    """CoCUpsample with BatchNorm + ReLU applied on the taps of the bilinear gather (model.fused_upsample, K11:
+    vrnet_bn_relu_upsample_bilinear_f32) against conv -> BN apply -> upsample: the tap expression is the apply kernel's, so
+    outputs, statistics and every gradient are EQUAL, not close."""
+    x, r = A.synthetic_inputs(2, size, 4)
+    x, r = x.cuda(), r.cuda()
+
+    def run(fused):
+        m = build(A, phi, size, 17, True)
+        m.fused_upsample = fused
+        det, seg = m(x, r)
+        (sum((d * d).mean() for d in det) + (seg * seg).mean()).backward()
+        torch.cuda.synchronize()
+        return [d.detach() for d in det] + [seg.detach()], {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    (o1, g1), (o0, g0) = run(True), run(False)
+    assert all(torch.equal(a, b) for a, b in zip(o1, o0))
+    assert g1.keys() == g0.keys() and all(torch.equal(g1[k], g0[k]) for k in g0), [k for k in g0 if not torch.equal(g1[k], g0[k])][:5]
