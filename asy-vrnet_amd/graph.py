@@ -51,8 +51,9 @@ class GraphedStep:
             raise RuntimeError("GraphedStep: synchronised BatchNorm issues collectives inside the forward / backward program; "
                                "capture is for rank-local BatchNorm statistics (the default) -- run sync_bn steps eagerly")
         self.device = torch.device(device)
-        self.x = torch.zeros((batch, 3, size, size), device=device)
-        self.r = torch.zeros((batch, 4, size, size), device=device)
+        h, w = (size, size) if isinstance(size, int) else size          # size: a side, or (H, W) for rectangular inputs
+        self.x = torch.zeros((batch, 3, h, w), device=device)
+        self.r = torch.zeros((batch, 4, h, w), device=device)
         cur = torch.cuda.current_stream(device)
         saved = [(b, b.detach().clone()) for b in self.model.buffers() if b.numel()]
         self.stream = torch.cuda.Stream(device)          # warm-up AND capture run here: scratch arenas (hip.Workspace is

@@ -1696,25 +1696,26 @@ def coc_upsample(rt, x, m, nchw_out=None):
         cA, cD, cS, ms = bn_fwd_coef(rt, z, bn)
         ms.fwd_coef = (cA, cD, cS)
         B, H, W, C = z.B, z.H, z.W, co
-        hi = None if nchw_out is not None else rt.new(B, H * s, W * s, C)
-        if nchw_out is not None:
+        to_nchw = nchw_out is not None      # (the closure below must not capture the output tensor itself: output -> autograd
+        hi = None if to_nchw else rt.new(B, H * s, W * s, C)      #  node -> tape -> closure -> output would be a cycle)
+        if to_nchw:
             hip.bn_relu_upsample(z.t, C, cA, cD, cS, nchw_out, 0, B, H, W, C, s, out_nchw=1)
         else:
             hip.bn_relu_upsample(z.t, C, cA, cD, cS, hi.t, C, B, H, W, C, s)
 
         def bwd_fused():
-            g = rt.seg_grad if nchw_out is not None else take_grad(hi)
+            g = rt.seg_grad if to_nchw else take_grad(hi)
             if g is None:
                 return
             dlo = rt.buf(B, H, W, C)
-            if nchw_out is not None:
+            if to_nchw:
                 hip.upsample_bwd(g.contiguous(), 0, 1, dlo, C, B, H, W, C, s)
             else:
                 hip.upsample_bwd(g, C, 0, dlo, C, B, H, W, C, s)
             dz = bn_backward(rt, bn, z, ms, dlo, C, mask=z)      # (mask: only "there is a ReLU" on this path)
             conv_backward(rt, x, conv, dz, co)
         rt.push(bwd_fused)
-        return z if nchw_out is not None else hi
+        return z if to_nchw else hi
     lo = base_conv(rt, x, bc)
     B, H, W, C = lo.B, lo.H, lo.W, lo.C
     if nchw_out is not None:

@@ -186,7 +186,7 @@ def test_against_reference_golden(A, name, golden_dir):
 
 
 @pytest.mark.parametrize("pair", [False, True])
-@pytest.mark.parametrize("phi,size,batch", [("nano", 64, 2), ("nano", 256, 2), ("s", 128, 4)])
+@pytest.mark.parametrize("phi,size,batch", [("nano", 64, 2), ("nano", 256, 2), ("s", 128, 4), ("nano", (128, 192), 2)])
 def test_captured_step_equals_eager_step_bit_for_bit(A, phi, size, batch, pair):
     """graph.GraphedStep (what bench.py times) replays the same kernels as the eager step, with the chains really
     concurrent on their side streams: every parameter gradient, the loss and the BatchNorm statistics must equal the
