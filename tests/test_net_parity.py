@@ -596,3 +596,56 @@ def test_fused_upsample_has_the_bits_of_the_three_launch_form(A, phi, size):
     (o1, g1), (o0, g0) = run(True), run(False)
     assert all(torch.equal(a, b) for a, b in zip(o1, o0))
     assert g1.keys() == g0.keys() and all(torch.equal(g1[k], g0[k]) for k in g0), [k for k in g0 if not torch.equal(g1[k], g0[k])][:5]
+
+
+@pytest.mark.parametrize("phi,size,batch", [("nano", 128, 2), ("s", 128, 2)])
+def test_segment_k_of_the_captured_backward_is_complete_when_graph_k_ends(A, phi, size, batch):
+    """What N > 1 correctness rests on: the captured step of a data-parallel model is three hipGraphs, and the
+    all-reduce of arena slice k is issued right behind graph k.  So when graph k has finished, EVERY gradient of slice k must
+    have its final value -- a weight gradient that a later graph still writes (deferred past the cut, started early and joined
+    late) would be averaged half-finished on every rank, silently.  One rank is enough to see it: replay the graphs one at a
+    time without the collectives, snapshot slice k after graph k, compare with the arena after the whole step; and the arena of
+    the cut step must agree with the gradients of the plain, uncut step."""
+    import torch.distributed as dist
+    from asy_vrnet_amd.graph import GraphedStep
+    from asy_vrnet_amd.parallel import DataParallelVRNet
+
+    def loss_of(det, seg):
+        return sum((d * d).mean() for d in det) + (seg * seg).mean()
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29593")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        x, r = A.synthetic_inputs(batch, size, 3, "cuda")
+        ref = build(A, phi, size, 7, True)
+        sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+        loss_of(*ref(x, r)).backward()
+        m = build(A, phi, size, 7, True)
+        net = DataParallelVRNet(m, force_collective=True)
+        gs = GraphedStep(net, loss_of, batch, size, x.device)
+        bk = m._grad_bucketer
+        assert len(gs.graphs) == 3 and sorted(bk.segment_slices) == [0, 1, 2]
+        for rep in range(2):
+            m.load_state_dict(sd0)
+            gs.x.copy_(x)
+            gs.r.copy_(r)
+            snaps = {}
+            for k, g in enumerate(gs.graphs):
+                g.replay()
+                torch.cuda.synchronize()
+                lo, hi = bk.segment_slices[k]
+                assert hi > lo
+                snaps[k] = bk.arena[lo:hi].clone()
+            for k, snap in snaps.items():
+                lo, hi = bk.segment_slices[k]
+                assert torch.equal(bk.arena[lo:hi], snap), f"replay {rep}: a later graph still wrote gradients of segment {k}"
+            for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+                if p.numel() and q.grad is not None:
+                    v = bk.view(p)      # (rounding-level: in the arena a gradient is accumulated into a zeroed view, and the
+                    assert v is not None, k      #  flush at a cut changes which slab-reduce kernel finishes a layer-scale gradient)
+                    assert ((v - q.grad).norm() / q.grad.norm().clamp_min(1e-20)).item() < 1e-5, k
+    finally:
+        if own_group:
+            dist.destroy_process_group()
