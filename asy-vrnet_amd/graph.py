@@ -122,7 +122,7 @@ class GraphedStep:
                 if k + 2 == len(bounds):
                     program.backward_end(rt, model, state["inputs"], (False, False))
                 else:
-                    program.backward_cut(rt)
+                    program.backward_cut(rt, final=False)
             pool = g.pool()
             self.graphs.append(g)
             if k + 2 >= len(bounds):
