@@ -56,7 +56,7 @@ extern "C" int vrnet_clock_stamp(long long* dst, void* stream) {
   return VR_OK;
 }
 
-extern "C" int vrnet_abi_version(void) { return 9; }
+extern "C" int vrnet_abi_version(void) { return 10; }
 extern "C" const char* vrnet_last_error(void) { return g_err; }
 
 // Synchronous device query used by load-time checks only (never on the hot path).

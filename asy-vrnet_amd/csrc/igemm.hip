@@ -19,6 +19,14 @@
 
 #include <cstdlib>
 
+// default variants of igemm_planes_reg_kernel for the 128 x 64 / 128 x 128 tile classes (0: igemm_planes_kernel)
+#ifndef VR_PLANES_REG21
+#define VR_PLANES_REG21 0
+#endif
+#ifndef VR_PLANES_REG22
+#define VR_PLANES_REG22 0
+#endif
+
 namespace {
 
 template <int BM, int BN, int BK, int TM, int TN, int WM, int WN, int MODE, bool VEC>
@@ -1480,6 +1488,8 @@ __global__ void pack_weight_kernel(const float* w, float* out, int Cout, int Cin
 
 // igemm_bf16.hip
 int vr_igemm_bf16_launch(const void* args, int mode, hipStream_t st);
+// igemm_planes.hip: x6 with pre-split weights, A fragments from global memory; returns 1 when the shape has no such kernel
+int vr_igemm_planes_reg_launch(const void* args, const void* planes, int variant, long M, int S, hipStream_t st);
 int vr_wgrad_bf16_launch(const void* args, int ident, int blocks_x, int splits, int streams, hipStream_t st);
 
 // narrowconv.hip
@@ -1776,6 +1786,17 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
       IgemmArgs q = p;
       q.kscale = nullptr;
       const int JB = (int)(((p.CN + 127) >> 7) << 1);
+      // round 6: A fragments straight from global memory (igemm_planes.hip); variant = 100 NW + 10 TN + AD
+      static const int reg21 = vr_tune("VRNET_PLANES_REG21", VR_PLANES_REG21), reg22 = vr_tune("VRNET_PLANES_REG22", VR_PLANES_REG22);
+      const int reg_variant = tile == 22 ? reg22 : reg21;
+      if (reg_variant && vr_igemm_planes_reg_launch(&q, w_planes, reg_variant, M, S, st) == 0) {
+        if (S > 1)
+          hipLaunchKernelGGL((igemm_splitk_finish_kernel<1, 2, 4, 1>), dim3((unsigned)(8 * vr_cdiv(mt, 8) * nt21)), block, 0, st, q,
+                             (int)mt, (int)nt21);
+        vr_note_kernel(9);
+        VR_LAUNCH_CHECK("conv2d(x6, pre-split weights, A from global memory)");
+        return VR_OK;
+      }
       if (tile == 22) {
         dim3 grid((unsigned)(8 * vr_cdiv(mt, 8) * nt22));
         // 128 x 128 tile: two stages (40 KB, 3 workgroups per CU) measured 0.2 ms per step ahead of three (60 KB, 2 per CU)

@@ -373,6 +373,10 @@ extern "C" int vrnet_mlp_pack_f32(const float* w1, const float* w2, int C, int H
   return VR_OK;
 }
 
+/* Whether the recompute form of the fused backward (vrnet_mlp_pack_rc_f32 / vrnet_mlp_bwd_rc_f32) exists: the fused kernels' shapes
+ * with the hidden width its LDS budget allows (two workgroups of C = 64 must fit 160 KB). */
+extern "C" int vrnet_mlp_rc_ok(int C, int HID, long M) { return vrnet_mlp_fused_ok(C, HID, M) && HID <= (C <= 64 ? 1024 : 1536); }
+
 /* Pack of the backward kernel that recomputes the pre-activation (vrnet_mlp_bwd_rc_f32): per chunk [fc2^T | fc1^T | fc1]. */
 extern "C" long vrnet_mlp_pack_rc_bytes(int C, int HID, int precision) {
   const int npl = precision == 2 ? 3 : 1;
@@ -380,7 +384,7 @@ extern "C" long vrnet_mlp_pack_rc_bytes(int C, int HID, int precision) {
 }
 extern "C" int vrnet_mlp_pack_rc_f32(const float* w1, const float* w2, int C, int HID, int precision, void* pack, void* stream) {
   VR_CHECK_ARG(w1 && w2 && pack, "mlp_pack_rc: null tensor");
-  VR_CHECK_ARG(vrnet_mlp_fused_ok(C, HID, 32) && HID <= (C <= 64 ? 1024 : 1536), "mlp_pack_rc: no recompute kernel for C = %d, hidden = %d", C, HID);
+  VR_CHECK_ARG(vrnet_mlp_rc_ok(C, HID, 32), "mlp_pack_rc: no recompute kernel for C = %d, hidden = %d", C, HID);
   VR_CHECK_ARG(precision == 1 || precision == 2 || precision == 4, "mlp_pack_rc: precision 2 (x6) or 1 / 4 (bf16-rounded operands)");
   const int npl = precision == 2 ? 3 : 1;
   const long total = (long)(HID / 32) * (2 * (C / 16) + 2 * (C / 32)) * 64;
@@ -467,7 +471,7 @@ extern "C" int vrnet_mlp_bwd_rc_f32(const float* dy, long lddy, const float* dy_
                                     const float* b1, float* h, long ldh, float* du, long lddu, float* dx, long lddx, long M, int C,
                                     int HID, int precision, void* stream) {
   VR_CHECK_ARG(dy && pack && x && h && du && dx, "mlp_bwd_rc: null tensor");
-  VR_CHECK_ARG(vrnet_mlp_fused_ok(C, HID, M) && HID <= (C <= 64 ? 1024 : 1536),
+  VR_CHECK_ARG(vrnet_mlp_rc_ok(C, HID, M),
                "mlp_bwd_rc: no recompute kernel for C = %d, hidden = %d, %ld rows", C, HID, M);
   VR_CHECK_ARG(precision == 2 || precision == 4, "mlp_bwd_rc: precision 2 (x6, fp32 h / du) or 4 (bf16-rounded operands, bf16 h / du)");
   VR_CHECK_ARG(M < (1L << 31), "mlp_bwd_rc: too many rows");

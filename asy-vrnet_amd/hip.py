@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VRNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libvrnet_hip.so")   # override: diagnostic builds only
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -47,6 +47,7 @@ _SIGS = {
     "vrnet_conv2d_wgrad_f32": ([P, L, P, L, P, P, P] + [I] * 14 + [P, P, P, P, P, P, P, P, P, P, L, P], I),
     "vrnet_pack_weight_f32": ([P, P, I, I, I, I, P], I),
     "vrnet_mlp_fused_ok": ([I, I, L], I),
+    "vrnet_mlp_rc_ok": ([I, I, L], I),
     "vrnet_mlp_pack_bytes": ([I, I, I], L),
     "vrnet_mlp_pack_f32": ([P, P, I, I, I, P, P, P], I),
     "vrnet_mlp_fwd_f32": ([P, L, P, P, P, P, L, P, P, L, P, L, P, L, I, I, I, P], I),
@@ -405,9 +406,10 @@ def mlp_pack(w1, w2, C, HID, precision, want_bwd=True):
     return fwd, bwd
 
 
-def mlp_rc_ok(C, HID):
-    """Whether the recompute form of the fused Mlp backward (mlp_bwd_rc) exists for this block."""
-    return HID <= (1024 if C <= 64 else 1536)
+def mlp_rc_ok(C, HID, M=32):
+    """Whether the recompute form of the fused Mlp backward (mlp_bwd_rc) exists for this block (the library's own predicate:
+    vrnet_mlp_rc_ok, which vrnet_mlp_pack_rc_f32 and vrnet_mlp_bwd_rc_f32 check too)."""
+    return bool(_lib.vrnet_mlp_rc_ok(C, HID, M))
 
 
 def mlp_pack_rc(w1, w2, C, HID, precision):

@@ -572,9 +572,9 @@ eca.register_autograd(_eca_bwd, setup_context=_eca_setup)
 @torch.library.custom_op("vrnet::image_enhance", mutates_args=(), device_types="cuda")
 def image_enhance(p: torch.Tensor, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
     """p: the projected radar map ReLU(BN(conv3x3(radar))), x: the image map, both (B,H,W,C) NHWC fp32.  data_normal maps p to
-    [0, 1] with the minimum / maximum over the WHOLE batch tensor.  DEVIATION from the reference, documented: when max ==
-    min (a constant map -- e.g. every ReLU output zero) vr_coc.py:64-66 divides by zero and the whole network turns NaN;
-    this kernel then only subtracts the minimum (data_normal = 0, t = x), which keeps a degenerate batch finite.
+    [0, 1] with the minimum / maximum over the WHOLE batch tensor.  As in the reference (vr_coc.py:59-67), a constant map
+    (max == min, e.g. every ReLU output zero) divides 0 by 0: the kernels compute (p - min) / (max - min) unguarded and the
+    result is NaN, exactly the reference's behaviour for such a degenerate batch (no guard is added on either side).
     Returns (t = (1 + data_normal(p)) * x, (min, max))."""
     p, x = p.contiguous(), x.contiguous()
     with torch.cuda.device(x.device):

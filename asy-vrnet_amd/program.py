@@ -339,6 +339,7 @@ class RT:
         self.pgrads.clear()
         self._aside_batches = []
         self._deferred_wgrads = []
+        self._started_wgrads = []
         self.pending_ab = []
 
     def flush_cluster_ab(self):
@@ -2173,7 +2174,8 @@ class WeightPrep:
         if st is None:
             st = WeightPrep._streams[dev] = torch.cuda.Stream(dev)
         self.convs, self.mlps = {}, {}
-        self.waited = {}            # (event name, stream id) -> True
+        self.waited = {}            # event name -> True: only the MAIN chain ever waits (_wait refuses elsewhere), and a chain
+                                    # that is told True was forked behind that wait, so the order is inherited through the fork
         st.wait_stream(cur)
         self.first_conv = None
         with torch.cuda.stream(st):
@@ -2545,23 +2547,48 @@ class _VRNetFunction(torch.autograd.Function):
         return (None, *outs, *(pouts if pouts is not None else [None] * len(ctx.params)))
 
 
-def _ddp_wrapper_of(model, depth=16):
+_warned_unwrapped = [False]
+
+
+def _ddp_wrapper_of(model):
     """The torch DistributedDataParallel instance whose forward() is calling `model` right now (None: there is none).
     DDP's reducer hangs its hooks on the parameters' AccumulateGrad nodes from C++ -- nothing on the module or its
-    parameters shows them -- so the wrapper is looked for where it must be: a few frames up the call stack
-    (DistributedDataParallel.forward -> _run_ddp_forward -> module(...) -> Module._call_impl -> forward -> run_forward)."""
+    parameters shows them -- so the wrapper is looked for where it must be: up the call stack
+    (DistributedDataParallel.forward -> _run_ddp_forward -> module(...) -> Module._call_impl -> forward -> run_forward;
+    the WHOLE stack is walked -- it stops at the first wrapper -- so any depth of nesting modules and hooks is covered).
+    A wrapper that calls the module from somewhere the stack does not show (a helper thread) can say so explicitly:
+    `model.autograd_param_grads = True` returns the parameter gradients through autograd without any detection."""
     import sys
     try:
         from torch.nn.parallel import DistributedDataParallel as DDP
     except Exception:      # a torch build without distributed
         return None
     f = sys._getframe(1)
-    while f is not None and depth > 0:
+    while f is not None:
         s = f.f_locals.get("self")
         if isinstance(s, DDP) and any(m is model for m in s.module.modules()):
             return s
-        f, depth = f.f_back, depth - 1
+        f = f.f_back
     return None
+
+
+def _warn_if_unreduced(model):
+    """Several ranks, gradients wanted, and neither parallel.DataParallelVRNet nor a DistributedDataParallel wrapper nor
+    model.autograd_param_grads: the ranks would diverge silently -- say so once."""
+    if _warned_unwrapped[0]:
+        return
+    try:
+        import torch.distributed as dist
+        many = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:
+        many = False
+    if many:
+        import warnings
+        _warned_unwrapped[0] = True
+        warnings.warn("EfficientVRNet runs on several ranks without parallel.DataParallelVRNet, without a torch "
+                      "DistributedDataParallel wrapper on its call stack and without model.autograd_param_grads = True: "
+                      "parameter gradients are published by assignment (.grad = buffer), no reducer hook will see them and "
+                      "the ranks' gradients are NOT averaged", RuntimeWarning, stacklevel=3)
 
 
 def run_forward(model, x, x_radar):
@@ -2575,6 +2602,9 @@ def run_forward(model, x, x_radar):
         raise RuntimeError("EfficientVRNet is wrapped by torch DistributedDataParallel AND by parallel.DataParallelVRNet: "
                            "its gradients would be all-reduced twice -- use one of the two")
     model._via_autograd = ddp is not None
+    if (ddp is None and not getattr(model, "autograd_param_grads", False) and getattr(model, "_grad_bucketer", None) is None
+            and torch.is_grad_enabled() and model.training):
+        _warn_if_unreduced(model)
     if not torch.is_grad_enabled() or not (x.requires_grad or x_radar.requires_grad or any(p.requires_grad for p in params)):
         # nothing to differentiate (torch.no_grad(), frozen model): no tape, no saved activations, no autograd node
         rt, _, dets, seg = forward_pass(model, x, x_radar, record=False)

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------- */
-int vrnet_abi_version(void);                 /* == 9 */
+int vrnet_abi_version(void);                 /* == 10 */
 /* Kernel family the last vrnet_conv2d_f32 / vrnet_conv2d_wgrad_f32 call of this thread dispatched to: 1 fp32 MFMA
  * (register-staged), 2 fp32 MFMA (LDS-DMA ring), 3 bf16-rounded operands, 4 direct kernels for tiny channel counts,
  * 5 direct HBM-streaming kernels for 1x1 convs with <= 16 output channels over wide inputs (head predictions, seg logits),
@@ -260,7 +260,9 @@ int vrnet_mlp_bwd_f32(const float* dy, long lddy, const float* dy_scale, const v
  * input rows x (the normalised block input: fp32, row stride ldx) against pack = vrnet_mlp_pack_rc_f32's per-chunk
  * [fc2^T | fc1^T | fc1] planes; the forward (vrnet_mlp_fwd_f32 with upre = NULL) then writes no hidden-sized tensor and the
  * backward reads one less.  precision 2: fp32 h / du, bit-identical to vrnet_mlp_bwd_f32 on the stored u; 4: bf16-rounded
- * operands, bf16 h / du.  Hidden widths up to 1024 (C = 64) / 1536 (C = 128). */
+ * operands, bf16 h / du.  Hidden widths up to 1024 (C = 64) / 1536 (C = 128): vrnet_mlp_rc_ok (ABI 10) is the predicate the
+ * pack and the kernel check, for callers that decide in the FORWARD pass whether to store u. */
+int vrnet_mlp_rc_ok(int C, int HID, long M);
 long vrnet_mlp_pack_rc_bytes(int C, int HID, int precision);
 int vrnet_mlp_pack_rc_f32(const float* w1, const float* w2, int C, int HID, int precision, void* pack, void* stream);
 int vrnet_mlp_bwd_rc_f32(const float* dy, long lddy, const float* dy_scale, const void* pack, const float* x, long ldx,

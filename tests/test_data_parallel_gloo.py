@@ -338,6 +338,23 @@ def test_stock_ddp_wrapper_is_found_on_the_call_stack():
         DDP(Outer())                                # an unrelated wrapper elsewhere does not count
         other(torch.zeros(3))
         assert other.seen is None
+        # 24 nested wrapper modules (72+ Python frames between DistributedDataParallel.forward and the probe): round 5 walked
+        # 16 frames and would have missed the wrapper here -- the whole stack is walked now
+        class Shell(torch.nn.Module):
+            def __init__(self, inner):
+                super().__init__()
+                self.inner = inner
+
+            def forward(self, x):
+                return self.inner(x)
+
+        deep = Probe()
+        nest = deep
+        for _ in range(24):
+            nest = Shell(nest)
+        ddp3 = DDP(nest)
+        ddp3(torch.zeros(3)).sum().backward()
+        assert deep.seen is ddp3
     finally:
         if own:
             dist.destroy_process_group()
