@@ -19,9 +19,12 @@
 
 #include <cstdlib>
 
-// default variants of igemm_planes_reg_kernel for the 128 x 64 / 128 x 128 tile classes (0: igemm_planes_kernel)
+// default variants of igemm_planes_reg_kernel for the 128 x 64 / 128 x 128 tile classes (0: igemm_planes_kernel; -1: per-shape rule)
 #ifndef VR_PLANES_REG21
 #define VR_PLANES_REG21 0
+#endif
+#ifndef VR_PLANES_STREAM_MIN_ROWS
+#define VR_PLANES_STREAM_MIN_ROWS 0      // 0: never
 #endif
 #ifndef VR_PLANES_REG22
 #define VR_PLANES_REG22 0
@@ -1490,6 +1493,8 @@ __global__ void pack_weight_kernel(const float* w, float* out, int Cout, int Cin
 int vr_igemm_bf16_launch(const void* args, int mode, hipStream_t st);
 // igemm_planes.hip: x6 with pre-split weights, A fragments from global memory; returns 1 when the shape has no such kernel
 int vr_igemm_planes_reg_launch(const void* args, const void* planes, int variant, long M, int S, hipStream_t st);
+// igemm_planes.hip: K = 64 / 128 over big maps, B resident in LDS, barrier-free A streams; returns 1 when the shape has no such kernel
+int vr_igemm_planes_stream_launch(const void* args, const void* planes, long M, hipStream_t st);
 int vr_wgrad_bf16_launch(const void* args, int ident, int blocks_x, int splits, int streams, hipStream_t st);
 
 // narrowconv.hip
@@ -1786,9 +1791,33 @@ extern "C" int vrnet_conv2d_f32(const float* a, long lda, const float* w, const 
       IgemmArgs q = p;
       q.kscale = nullptr;
       const int JB = (int)(((p.CN + 127) >> 7) << 1);
-      // round 6: A fragments straight from global memory (igemm_planes.hip); variant = 100 NW + 10 TN + AD
+      // round 6: A fragments straight from global memory (igemm_planes.hip); variant = 100 NW + 10 TN + workgroups per CU.
+      // Measured alone, warm / operands rotated through > 256 MB (profiles/r06_planes_reg_probe.txt): the 256 x 64 tile with
+      // eight waves on one B stage takes 10-17 % less time where the 128 x 64 grid leaves the chip under-filled and the
+      // contraction is long (8 192 rows x 320 columns, K >= 512: 70.5 -> 58.8 us warm, 75.5 -> 68.2 cold); elsewhere the
+      // variants are within +-5 % of igemm_planes_kernel cold and the step does not move (24.33 vs 24.26-24.31 ms, same call),
+      // so only that class is dispatched (-1 = this rule; the diagnostic build can force a variant for every launch).
+      // Round 6: two more forms of this GEMM (igemm_planes.hip), both measured and NEITHER dispatched by the product build (the
+      // diagnostic build can force them: VRNET_PLANES_STREAM_MIN_ROWS / VRNET_PLANES_REG21 / _REG22; tests/test_planes_reg.py runs
+      // the parity cases on them).  Alone they are faster -- profiles/r06_planes_reg_probe.txt, r06_planes_stream_probe.txt:
+      // A fragments from global memory 5-17 % on the under-filled 8 192-row grids with long contractions (70.5 -> 58.8 us on
+      // 256 x 64 tiles of eight waves), resident B + barrier-free A streams 5-15 % at 131 072 rows x <= 128 columns -- but with
+      // operands rotated through > 256 MB (as inside the step) the gains shrink to 0-10 %, and IN the step they are not there:
+      // same call, ms per step: round-5 head 25.09-25.15, the 256 x 64 rule on 25.27-25.38, rule off 25.16-25.26, streaming rule on
+      // or off 25.38-25.47 vs 25.39-25.46; every 128 x 64 variant 24.17-24.35 against 24.14-24.50 (profiles/r06_planes_reg_step.txt).
+      static const int stream_min = vr_tune("VRNET_PLANES_STREAM_MIN_ROWS", VR_PLANES_STREAM_MIN_ROWS);
+      static const int stream_max_n = vr_tune("VRNET_PLANES_STREAM_MAX_COLS", 128);
+      if (stream_min > 0 && S == 1 && M >= stream_min && p.CN <= stream_max_n && !p.perm2 &&
+          vr_igemm_planes_stream_launch(&q, w_planes, M, st) == 0) {
+        vr_note_kernel(9);
+        VR_LAUNCH_CHECK("conv2d(x6, pre-split weights, resident B)");
+        return VR_OK;
+      }
+      // variant = 100 NW + 10 TN + workgroups per CU; -1 = 256 x 64 tiles where the 128 x 64 grid under-fills the chip and the
+      // contraction is long (the rule that measured +0.2 ms in the step)
       static const int reg21 = vr_tune("VRNET_PLANES_REG21", VR_PLANES_REG21), reg22 = vr_tune("VRNET_PLANES_REG22", VR_PLANES_REG22);
-      const int reg_variant = tile == 22 ? reg22 : reg21;
+      int reg_variant = tile == 22 ? reg22 : reg21;
+      if (reg_variant < 0) reg_variant = (tile == 21 && S == 1 && M <= 8192 && p.CK >= 512 && p.CN <= 512) ? 812 : 0;
       if (reg_variant && vr_igemm_planes_reg_launch(&q, w_planes, reg_variant, M, S, st) == 0) {
         if (S > 1)
           hipLaunchKernelGGL((igemm_splitk_finish_kernel<1, 2, 4, 1>), dim3((unsigned)(8 * vr_cdiv(mt, 8) * nt21)), block, 0, st, q,

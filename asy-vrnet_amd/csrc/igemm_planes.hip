@@ -28,6 +28,9 @@ __device__ __forceinline__ void vr_load_a(f32x4 (&a)[4], const float* ptr) {
   asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(a[3]) : "v"(ptr) : "memory");
 }
 template <int N>
+struct IC { static constexpr int value = N; };
+
+template <int N>
 __device__ __forceinline__ void vr_wait_a(f32x4 (&a)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N) : "memory");
 }
@@ -294,6 +297,135 @@ __global__ __launch_bounds__(64 * NW, WPS) void igemm_planes_reg_kernel(const Ig
   igemm_epilogue<1, TNW, NW, 1>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Short contractions over the big maps (K = 64 / 128 at the 128 x 128 and 64 x 64 stages: 131 072 / 32 768 rows).  These
+// launches move 50-170 MB for 1-4 GFLOP -- HBM-bound -- and ran at 1.5-2.7 TB/s on the tile kernels: a workgroup lives for two
+// to eight K steps, so its prologue (first loads at HBM latency), its barriers and its epilogue are most of its life.  Here the
+// whole B column tile (K / 16 x TN x 6 KB of weight planes) is brought into LDS ONCE per workgroup and stays; after that
+// single barrier the four waves never synchronise again: each wave streams its own 32-row blocks of A through two landing
+// buffers (two chunks = 8 KB per wave in flight, across block boundaries and under the epilogue), splits in the shadow of
+// the MFMAs and stores its 32 x 64 TN outputs through a wave-private staging tile.
+// Workgroup w: xcd = w % 8, slot = w / 8, column tile = slot % NT, row group = slot / NT -- the NT column tiles of a row
+// group run on one XCD (one L2 fetches the A rows once); wave (row group q, wave) owns row blocks q * 4 + wave + k * stride.
+template <int TN, int KS, int WPS>
+__global__ __launch_bounds__(256, WPS) void igemm_planes_stream_kernel(const IgemmArgs p, const unsigned char* planes, int JB, int NT,
+                                                                       int nrb, int RG) {
+  constexpr int TNW = 2 * TN;
+  constexpr int K16B = TN * 6144, ST_BYTES = 2 * K16B, B_BYTES = KS * ST_BYTES, NPIECE = B_BYTES / 1024;
+  static_assert(KS == 2 || KS == 4, "the landing buffers alternate by step parity across blocks; chunk steps are named statically");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[B_BYTES + 4 * 32 * STAGE_LD * 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = blockIdx.x, xcd = w & 7, slot = w >> 3;
+  const int ct = slot % NT, rg = slot / NT;
+  const int n0 = ct * 64 * TN;
+  const int stride = 32 * RG;                      // row blocks between two consecutive blocks of a wave
+  const int rb0 = (rg * 8 + xcd) * 4 + wave;
+  const int nblk = rb0 < nrb ? (nrb - 1 - rb0) / stride + 1 : 0;
+  const int h = lane >> 5;
+
+  // ---- B: the whole column tile, once
+  {
+    const unsigned char* src = planes + ((long)(n0 >> 6)) * 6144 + (long)lane * 16;
+#pragma unroll
+    for (int q = wave; q < NPIECE; q += 4) {
+      const int ks = q / (K16B / 1024), within = q - ks * (K16B / 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)ks * JB * 6144 + within * 1024),
+                                       (__attribute__((address_space(3))) void*)(smem + q * 1024), 16, 0, 0);
+    }
+  }
+  // ---- A: chunk (block i, step s) = 64 bytes per lane at row (rb0 + i stride) 32 + r, k = 32 s + 16 h
+  const float* a_ptr = p.a + ((long)(nblk ? rb0 : 0) * 32 + (lane & 31)) * p.lda + 16 * h;
+  const long blk_adv = (long)stride * 32 * p.lda - (long)(KS - 1) * 32;
+  int ld_rem = nblk * KS;      // chunks still to load, the next one included
+  f32x4 land[2][4];
+  // the chunk with in-block step CS; then on to the next chunk -- past the last one the pointer stays (the two surplus loads of
+  // the pipeline re-read the last chunk; advancing would read past the end of the tensor).  CS is static at every call site
+  // (the step loop is unrolled): scalar selects, no branches.
+  auto load_chunk = [&](f32x4 (&dst)[4], auto cs) __attribute__((always_inline)) {
+    vr_load_a(dst, a_ptr);
+    const long inc = decltype(cs)::value < KS - 1 ? 32L : blk_adv;
+    a_ptr += ld_rem > 1 ? inc : 0L;
+    ld_rem -= ld_rem > 1 ? 1 : 0;
+  };
+  load_chunk(land[0], IC<0>());
+  load_chunk(land[1], IC<1>());
+  vr_wait_a<0>(land[0]);
+  vr_wait_a<0>(land[1]);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (nblk == 0) return;
+
+  int b_off[TNW];
+#pragma unroll
+  for (int i = 0; i < TNW; ++i) {
+    const int rbn = 32 * i + (lane & 31);
+    b_off[i] = h * K16B + (rbn >> 6) * 6144 + (rbn & 63) * 16;       // + step * ST_BYTES + plane * 2048 + sub-step * 1024
+  }
+  float* stage = reinterpret_cast<float*>(smem + B_BYTES) + wave * (32 * STAGE_LD);
+  A3 s0, s1;
+  vr_split_part<0, 4>(land[0][0], land[0][1], s0);
+  vr_bf16x8 bf[TNW][3];
+#pragma unroll
+  for (int i = 0; i < TNW; ++i)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) bf[i][pl] = *reinterpret_cast<const vr_bf16x8*>(smem + b_off[i] + pl * 2048);
+
+  for (int blk = 0; blk < nblk; ++blk) {
+    f32x16 acc[TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      f32x4(&cur)[4] = land[s & 1];
+      f32x4(&nxt)[4] = land[(s & 1) ^ 1];
+      const unsigned char* B1 = smem + s * ST_BYTES + 1024;                          // sub-step 1 of this step
+      const unsigned char* B0n = smem + ((s + 1) % KS) * ST_BYTES;                   // sub-step 0 of the next step
+      vr_bf16x8 a3[3], bfn[TNW][3];
+      // sub-step 0: MFMAs on s0; beside them the split of the chunk's second half and the B fragments of sub-step 1
+      vr_a3_planes(s0, a3);
+#pragma unroll
+      for (int jn = 0; jn < TNW; ++jn) {
+        acc[jn] = vr_mfma_x6(a3, bf[jn], acc[jn]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bfn[jn][pl] = *reinterpret_cast<const vr_bf16x8*>(B1 + b_off[jn] + pl * 2048);
+        vr_split_chunk<TNW>(jn, cur[2], cur[3], s1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the chunk in `cur` is consumed: its buffer takes chunk s + 2; then chunk s + 1 must have landed (only the load just
+      // issued may be in flight)
+      if ((s + 2) % KS == 0) load_chunk(cur, IC<0>());
+      else if ((s + 2) % KS == 1) load_chunk(cur, IC<1>());
+      else if ((s + 2) % KS == 2) load_chunk(cur, IC<2>());
+      else load_chunk(cur, IC<3>());
+      vr_wait_a<4>(nxt);
+      vr_a3_planes(s1, a3);
+#pragma unroll
+      for (int jn = 0; jn < TNW; ++jn) {
+        acc[jn] = vr_mfma_x6(a3, bfn[jn], acc[jn]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[jn][pl] = *reinterpret_cast<const vr_bf16x8*>(B0n + b_off[jn] + pl * 2048);
+        vr_split_chunk<TNW>(jn, nxt[0], nxt[1], s0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const int row0 = (rb0 + blk * stride) * 32;
+    // (named one by one: a loop around a call that contains wave barriers is not unrolled, and acc[j] would go to scratch)
+    igemm_epilogue_tile(p, acc[0], stage, row0, n0);
+    igemm_epilogue_tile(p, acc[1], stage, row0, n0 + 32);
+    if constexpr (TNW == 4) {
+      igemm_epilogue_tile(p, acc[2], stage, row0, n0 + 64);
+      igemm_epilogue_tile(p, acc[3], stage, row0, n0 + 96);
+    }
+  }
+  // the surplus loads target registers: drain before the wave ends
+  vr_wait_a<0>(land[0]);
+  vr_wait_a<0>(land[1]);
+}
+
 }  // namespace
 
 // internal entry used by vrnet_conv2d_f32 (igemm.hip): variant = 100 * NW + 10 * TN + workgroups per CU.  Returns 0 when
@@ -321,4 +453,26 @@ int vr_igemm_planes_reg_launch(const void* args, const void* planes, int variant
     default: return 1;
   }
 #undef VR_PR
+}
+
+// Resident-B streaming kernel for K = 64 / 128 over >= 32 768 rows (variant 0: the caller's rule).  Returns 0 when launched.
+int vr_igemm_planes_stream_launch(const void* args, const void* planes, long M, hipStream_t st) {
+  const IgemmArgs& p = *reinterpret_cast<const IgemmArgs*>(args);
+  if ((p.CK != 64 && p.CK != 128) || M % 32 != 0 || !p.e_vec || p.ksplit > 1 || p.CN % 4 != 0) return 1;
+  const int JB = (int)(((p.CN + 127) >> 7) << 1);
+  const unsigned char* pl = reinterpret_cast<const unsigned char*>(planes);
+  const int nrb = (int)(M / 32);
+  // column tiles of 64 (the 128-wide form -- 64 accumulator registers more -- spills at two waves per SIMD)
+  const int TN = 1;
+  const int NT = (int)vr_cdiv(p.CN, 64 * TN);
+  const int per_cu = 2;      // 234 registers: two waves per SIMD (the LDS -- 43 / 67 KB -- would admit three / two)
+  // waves per column tile: as many as fit (workgroups in multiples of 8 per column tile), each with the same number of blocks
+  long wg_ct = (256L * per_cu / NT) / 8 * 8;
+  if (wg_ct < 8) wg_ct = 8;
+  const long k = vr_cdiv(nrb, 4 * wg_ct);
+  const int RG = (int)vr_cdiv(vr_cdiv(nrb, k), 32);      // row groups per XCD
+  dim3 grid((unsigned)(8L * RG * NT));
+  if (p.CK == 64) hipLaunchKernelGGL((igemm_planes_stream_kernel<1, 2, 2>), grid, dim3(256), 0, st, p, pl, JB, NT, nrb, RG);
+  else hipLaunchKernelGGL((igemm_planes_stream_kernel<1, 4, 2>), grid, dim3(256), 0, st, p, pl, JB, NT, nrb, RG);
+  return 0;
 }

@@ -109,17 +109,14 @@ class RT:
         self.tape_pos = 0           # index of the top-level tape closure being replayed
         self.concurrent = True      # fork independent chains (image / radar, seg / det, head levels) onto side streams
         self.pair_streams = False   # True: image + radar chain of a backbone stage as ONE two-stream batch (one launch per layer)
-        self.prep = None            # WeightPrep: this forward's weight packs, issued on a side stream (forward_pass)
         self.pending_ab = []        # deferred (d alpha, d beta) reductions of the Cluster modules of the section being replayed
         self.sync_batch_total = None   # SyncBatchNorm: global sample count of THIS forward pass
         self.overlap_fusion = True
         self.mlp_recompute = "auto"  # fused Mlp backward recomputes the pre-activation instead of reading a stored one
-        self.gn_colstats = False
         self.fused_fusion = True    # the fused passes of csrc/fusion.hip in the fusion blocks
         self.fused_upsample = True  # CoCUpsample: BatchNorm + ReLU applied on the taps of the bilinear gather (K11)
         self.early_wgrads = 2       # 1 = behind every section: measured (round 5, same call): 25.87-26.06 ms with it against 25.75-25.92 without -- the weight
                                     # gradients then contend with the small kernels of the critical chain they were meant to fill
-        self.branch_priority = False
         self.stamps = None          # diagnostic: (int64 buffer, [names]) -- rt.stamp(name) writes the device clock in stream order
         self.via_autograd = False   # parameter gradients go back through torch.autograd (stock DistributedDataParallel)
 
@@ -138,13 +135,10 @@ class RT:
 
     def _streams(self, n):
         """n side streams for the current nesting depth (nested sections get their own streams)."""
-        pool = RT._side_streams.setdefault((self.device, self.branch_priority), [])
+        pool = RT._side_streams.setdefault(self.device, [])
         lo = self._depth * 8
         while len(pool) < lo + n:
-            # branch_priority: the SECOND chain of a section (the radar chain of a backbone stage, the detection branch of the
-            # neck -- the longer one since round 5's schedule) on a high-priority stream
-            hi = self.branch_priority and len(pool) % 8 == 1
-            pool.append(torch.cuda.Stream(self.device, priority=-1 if hi else 0))
+            pool.append(torch.cuda.Stream(self.device))      # (the longer chain on a high-priority stream: no effect, round 5)
         return pool[lo:lo + n]
 
     # ---- parameter-gradient kernels off the critical path ---------------------------------------------------
@@ -374,10 +368,6 @@ class RT:
         if kh * kw == 1:
             return w
         p = self.packed.get(conv)
-        if p is None and self.prep is not None:
-            p = self.prep.conv_pack(conv)          # packed at the start of the forward on the preparation stream
-            if p is not None:
-                self.packed[conv] = p
         if p is None:
             p = self.buf(kh * kw, co, ci)
             hip.pack_weight(w, p, co, ci, kh, kw)
@@ -385,12 +375,8 @@ class RT:
         return p
 
     def mlp_packs(self, mlp, C, hid, pmlp, rc=False):
-        """(forward, backward) weight planes of a fused Mlp (hip.mlp_pack): from the preparation stream when it made them.
+        """(forward, backward) weight planes of a fused Mlp (hip.mlp_pack).
         rc: the backward pack of the kernel that recomputes the pre-activation (hip.mlp_pack_rc)."""
-        if self.prep is not None:
-            got = self.prep.mlp_pack(mlp, (pmlp, rc), self.record)
-            if got is not None:
-                return got
         if rc:
             fwd, _ = hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, pmlp, want_bwd=False)
             return fwd, (hip.mlp_pack_rc(mlp.fc1.weight, mlp.fc2.weight, C, hid, pmlp) if self.record else None)
@@ -429,8 +415,6 @@ class RT:
         an x6 tile kernel, or the planes are switched off).  mode 0: w is [J = Cout][K = Cin]; mode 1: [K = Cout][J = Cin]."""
         if self.wplanes is None or self.bf16 or self.fp32_precision != 2 or K % 16 or not hip.conv2d_dma_plan(rows, J, K)[0]:
             return None
-        if self.prep is not None and not self.prep._wait("all", self.prep.ev_all):
-            return None         # (a forked chain ahead of the preparation stream's join: the in-kernel split path)
         sj, sk = (K, 1) if mode == 0 else (1, J)
         return self.wplanes.get((id(w), mode), w, J, K, sj, sk, kscale)
 
@@ -617,7 +601,7 @@ def conv_call(rt, x, conv, out, act=0, ypre=None, res=None, res_scale=None, nchw
 
 
 def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, skip_bias=False, dx_to=None,
-                  defer_ok=True, ls_grad=None, no_dx=False, colstats=None):
+                  defer_ok=True, ls_grad=None, no_dx=False):
     """Gradients of y = conv(x): weight/bias into the parameter table, dx accumulated into x.grad
     (or written to the Act `dx_to`).  dy: tensor whose data_ptr is the (0,0) element, row stride lddy.
     conv / kscale / row_scale / ls_grad may be pairs (two-stream launch).  ls_grad: the layer-scale parameter(s) behind
@@ -681,8 +665,6 @@ def conv_backward(rt, x, conv, dy, lddy, kscale=None, aux=None, row_scale=None, 
             wd1, ks1, prec1 = rt.dgrad_operands(c1, c1.weight, rt.weight(c1), co, ci, kh, kw, ks1, lddy, rows)
             assert prec1 == prec
             kw2 = dict(pair_rows=(x.B // 2) * x.H * x.W, w2=wd1, kscale2=ks1)
-        if colstats is not None:
-            kw2["colstats"] = colstats
         if c1 is None and kh == 1 and kw == 1 and s == 1 and p == 0 and prec == 2:
             kw2["w_planes"] = rt.planes(c0.weight, 1, ci, co, x.B * x.H * x.W, kscale=ks)
         hip.conv2d(dy, lddy, wd, None, buf, ld, x.B, x.H, x.W, ci, OH, OW, co, kh, kw, s, p, d, mode=1,
@@ -841,33 +823,13 @@ def _pgrads_or_scratch(rt, params, sizes):
     return outs, acc
 
 
-def gn_colstats(rt, gn, x):
-    """Buffers for the column statistics a data-gradient conv leaves for the backward pass of the GroupNorm `gn` whose input was
-    `x` (conv2d `colstats` with x2 / gamma: per-channel (sum dy, sum dy x) per 32-row tile + gamma-weighted tile totals), or None
-    when the shape does not qualify.  (Round 3 built this and measured it neutral while both chains saturated the chip; with the
-    radar chain as the critical path -- round 5 -- a launch less on it is worth having: model.gn_colstats.)"""
-    if not rt.gn_colstats or isinstance(gn, tuple) or not hip.colstats_ok(x.HW, x.C, x.ld) or x.t.data_ptr() % 16:
-        return None
-    part, tot = hip.colstats_buffers(x.B, x.HW, x.C, x.t.device, totals=True)
-    return (part, x.t, x.ld, gn.weight, tot)
-
-
-def gn_backward(rt, gn, x, ms, dy, out, accumulate=0, add=None, partials=None):
+def gn_backward(rt, gn, x, ms, dy, out, accumulate=0, add=None):
     """out = dx of y = GN(x) given contiguous dy [+ out (accumulate) | + add (another contiguous tensor)].
     (Round 3 could also take the moments from the epilogue of the data-gradient conv that produced dy -- vrnet_conv_colstats with
-    x2 / gamma, vrnet_gn_apply_bwd_from_partials: measured neutral-to-negative in the step, never on by default; the program path
-    was removed in round 4, the library entry points remain.)"""
+    x2 / gamma, vrnet_gn_apply_bwd_from_partials: measured neutral-to-negative in the step in rounds 3-5, never on by default; the
+    program path was removed in round 6, the library entry points and their tests remain.)"""
     g0, g1 = _pair(gn)
     B, HW, C = x.B, x.HW, x.C
-    if partials is not None and (not accumulate or add is None):
-        # the moments came out of the epilogue of the data-gradient conv that produced dy: ONE launch
-        (gw, gb), accw = _pgrads_or_scratch(rt, (g0.weight, g0.bias), (C, C))
-        hip.gn_apply_bwd_from_partials(dy, C, x.t, x.ld, partials[0], partials[4], ms, g0.weight, B, HW, C, out, C, gw, gb, accw,
-                                       add=out if accumulate else add, ldadd=C if (accumulate or add is not None) else 0)
-        if rt.on_param_grad:
-            rt.on_param_grad(g0.weight)
-            rt.on_param_grad(g0.bias)
-        return
     if g1 is None and hip.gn_apply_ok(C, x.ld) and (not accumulate or add is None):
         # two launches (moments; apply + parameter gradients) where moments, reduce, coefficients and affine were four
         (gw, gb), accw = _pgrads_or_scratch(rt, (g0.weight, g0.bias), (C, C))
@@ -1032,7 +994,6 @@ def cluster_block(rt, x, m, name=None):
         # ---- MLP branch
         du = rt.new(B, H, W, hid)
         dxn2 = rt.new(B, H, W, C)
-        cs2 = None
         if pmlp:
             # one kernel: d(pre-activation) and the recomputed activation are written once for the two weight gradients,
             # which run beside the rest of the block's backward like every other weight gradient
@@ -1045,10 +1006,10 @@ def cluster_block(rt, x, m, name=None):
             conv_backward(rt, xn2, mlp0.fc1, du.t, hid, no_dx=True)
         else:
             conv_backward(rt, h, _attr(mlp, "fc2"), dx2, C, kscale=ls2, aux=u, row_scale=ls2, dx_to=du, ls_grad=ls2)
-            cs2 = None if paired else gn_colstats(rt, m0.norm2, x1)     # d xn2's GroupNorm moments from this conv's epilogue
-            conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2, colstats=cs2)
+            # (GroupNorm-backward moments from this conv's epilogue: built in round 3, neutral in rounds 3-5, removed in round 6)
+            conv_backward(rt, xn2, _attr(mlp, "fc1"), du.t, hid, dx_to=dxn2)
         dx1 = rt.buf(B, H, W, C)
-        gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx1, add=dx2, partials=cs2)   # dx1 = dx2 + d(GN -> Mlp branch)
+        gn_backward(rt, _attr(m, "norm2"), x1, ms2, dxn2.t, dx1, add=dx2)   # dx1 = dx2 + d(GN -> Mlp branch)
         # ---- Cluster branch
         do = rt.new(B, H, W, ED)
         conv_backward(rt, o, _attr(tm, "fc2"), dx1, C, kscale=ls1, row_scale=ls1, dx_to=do, ls_grad=ls1)
@@ -1081,12 +1042,9 @@ def cluster_block(rt, x, m, name=None):
             kwd = dict(pair_rows=rows_half, w2=wd1)
         if not paired and prec == 2:
             kwd["w_planes"] = rt.planes(wcat, 1, C, 2 * ED, B * H * W)
-        cs1 = None if paired else gn_colstats(rt, m0.norm1, x)
-        if cs1 is not None:
-            kwd["colstats"] = cs1
         hip.conv2d(dfv.t, 2 * ED, wd, None, dxn.t, C, B, H, W, C, H, W, 2 * ED, 1, 1, 1, 0, 1, mode=1, precision=prec, **kwd)
         dx = rt.buf(B, H, W, C)
-        gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx, add=dx1, partials=cs1)     # dx = dx1 + d(GN -> Cluster branch)
+        gn_backward(rt, _attr(m, "norm1"), x, ms1, dxn.t, dx, add=dx1)     # dx = dx1 + d(GN -> Cluster branch)
         rt.give_grad(x, dx)
     rt.push(bwd)
     return x2
@@ -1886,8 +1844,6 @@ def backbone_forward(rt, bb, x, r):
     xr = rt.new_pair(2 * B, H // 4, W // 4, dims[0])             # stage-0 input: both patch embeddings
     xh, rh = xr.halves()
     rt.parallel([lambda: embed(xe, bb.patch_embed, out=xh), lambda: embed(re_, bb.patch_embed_radar, out=rh)], site=1)
-    if rt.prep is not None:
-        rt.prep.wait_all()          # the first consumers of the weight planes / Mlp packs / [fc1 ; fc_v] copies: stage 0
     for i in range(4):
         pi, pr = f"backbone.backbone.network.{3 * i}", f"backbone.backbone.network_radar.{3 * i}"
         if can_pair(xr.H, xr.W, i):
@@ -1967,8 +1923,6 @@ def _backbone_overlapped(rt, bb, x, r, embed, chain):
             out = rr, b, chain(b, bb.network_radar[3 * i], pr)
             rt.stamp(f"s{i} B end")
             return out
-        if i == 0 and rt.prep is not None:
-            rt.prep.wait_all()      # the first consumers of the weight planes / Mlp packs / [fc1 ; fc_v] copies: stage 0
         rt.stamp(f"s{i} fork")
         (tap_a, xs), (rr, tap_b, rs) = rt.parallel([branch_a, branch_b], site=2)
         if i == 1:
@@ -2152,103 +2106,6 @@ class PlaneWeights:
         return self.get((id(w), 1), w, ci, co, 1, ci, kscale)
 
 
-class WeightPrep:
-    """The per-step weight preparation of a forward pass -- the [fc1 ; fc_v] copies (FusedQKV), the bf16 planes of every 1x1
-    weight (WeightPlanes / PlaneWeights), the fragment-order planes of the fused Mlps (hip.mlp_pack) and the tap-major packs of
-    the k x k convs (hip.pack_weight) -- issued at the START of the forward on a side stream, where it runs beside the input
-    fusion at full resolution (layout transposes, 3 / 4-channel convs, their BatchNorms: about a millisecond that needs none
-    of it) instead of ahead of it and, for the Mlp / conv packs, in front of each first use on the chain (round 4: ~0.16 ms of
-    plane split exclusive at the head of the step, 16 + 14 small pack launches on the chains).  Two events: `small` (the k x k
-    packs, issued first: the first 3 x 3 conv is the fourth kernel of the forward) and `all`.  A consumer waits for its event
-    on whatever stream it runs on (fork / join edges under hipGraph capture); buffers come from the side stream's pool and
-    are ordered against the next forward by its opening wait_stream."""
-
-    _streams = {}
-
-    def __init__(self, rt, model, refresh):
-        self.rt = weakref.ref(rt)      # (rt -> prep -> rt would be a cycle that keeps a forward's activations alive until the
-        self.device = rt.device        #  collector runs: test_forward_without_backward_frees_its_activations_at_once)
-        dev = rt.device
-        cur = torch.cuda.current_stream(dev)
-        st = WeightPrep._streams.get(dev)
-        if st is None:
-            st = WeightPrep._streams[dev] = torch.cuda.Stream(dev)
-        self.convs, self.mlps = {}, {}
-        self.waited = {}            # event name -> True: only the MAIN chain ever waits (_wait refuses elsewhere), and a chain
-                                    # that is told True was forked behind that wait, so the order is inherited through the fork
-        st.wait_stream(cur)
-        self.first_conv = None
-        with torch.cuda.stream(st):
-            for mod in model.modules():
-                w = getattr(mod, "weight", None)
-                if isinstance(mod, torch.nn.Conv2d) and mod.groups == 1 and w.shape[2] * w.shape[3] > 1 and \
-                        w.shape[2] != mod.stride[0]:        # (k == stride: the patch embeddings, which run as gather + GEMM)
-                    co, ci, kh, kw = w.shape
-                    p = rt.buf(kh * kw, co, ci)
-                    hip.pack_weight(w, p, co, ci, kh, kw)
-                    self.convs[mod] = p
-                    if self.first_conv is None:
-                        # the 3 x 3 conv of the first ImageEnhanceByRadar (registered first) is the fourth kernel of the forward:
-                        # it only waits for ITS pack; every other pack is first used behind wait_all()
-                        self.first_conv = mod
-                        self.ev_small = torch.cuda.Event()
-                        self.ev_small.record(st)
-            if self.first_conv is None:
-                self.ev_small = torch.cuda.Event()
-                self.ev_small.record(st)
-            refresh()
-            if rt.fused_mlp and (rt.bf16 or rt.fp32_precision == 2):
-                prec = 1 if rt.bf16 else 2
-                for mod in model.modules():
-                    mlp = getattr(mod, "mlp", None)
-                    if mlp is None or not hasattr(mod, "token_mixer"):
-                        continue
-                    hid, C = mlp.fc1.weight.shape[0], mlp.fc1.weight.shape[1]
-                    if hip.mlp_fused_ok(C, hid, 32):
-                        # (bf16 mode: the blocks run at precision 4 when their hidden tensors are bf16 -- same planes as 1)
-                        rc = rt.mlp_rc(C, hid, rt.bf16)
-                        if rc:
-                            fwd, _ = hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, prec, want_bwd=False)
-                            packs = (fwd, hip.mlp_pack_rc(mlp.fc1.weight, mlp.fc2.weight, C, hid, prec))
-                        else:
-                            packs = hip.mlp_pack(mlp.fc1.weight, mlp.fc2.weight, C, hid, prec, want_bwd=rt.record)
-                        self.mlps[mlp] = ((prec, rc), packs)
-            self.ev_all = torch.cuda.Event()
-            self.ev_all.record(st)
-        self.stream = st
-
-    def _wait(self, name, ev):
-        """Orders the packs behind `ev` before whatever the MAIN chain's stream runs next; False when called from a forked
-        chain before the main chain has waited (hipGraph capture on ROCm 7 only takes a star of streams: a side stream must
-        not wait for another side stream -- the caller then does without the prepared pack)."""
-        if name in self.waited or "all" in self.waited:
-            return True
-        rt = self.rt()
-        if rt is None or rt._chain != "main":
-            return False
-        torch.cuda.current_stream(self.device).wait_event(ev)
-        self.waited[name] = True
-        return True
-
-    def conv_pack(self, conv):
-        p = self.convs.get(conv)
-        if p is None:
-            return None
-        ok = self._wait("small", self.ev_small) if conv is self.first_conv else self._wait("all", self.ev_all)
-        return p if ok else None
-
-    def mlp_pack(self, mlp, pmlp, record):
-        ent = self.mlps.get(mlp)
-        if ent is None or ent[0] != pmlp or not self._wait("all", self.ev_all):
-            return None
-        return ent[1]
-
-    def wait_all(self):
-        """On the main chain, before the first ClusterBlock: the [fc1 ; fc_v] copies, the weight planes and the Mlp packs."""
-        ok = self._wait("all", self.ev_all)
-        assert ok, "WeightPrep.wait_all() belongs on the main chain"
-
-
 class FusedQKV:
     """Concatenated [fc1 ; fc_v] weights and biases of every Cluster module (vr_coc.py:145-147): both 1x1 convs read
     the same normalised input, so each block runs them as ONE GEMM with 2*E*D output channels (twice the tiles of the
@@ -2315,7 +2172,6 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         # measured (A/B inside one gpurun call, phi=l bs 8 512 px): two chains on two streams 30.8 ms/step, one
         # two-stream chain 31.6 ms/step (and 1 480 instead of 2 070 launches): the default is the faster one
         rt.pair_streams = bool(getattr(model, "pair_streams", False))
-        rt.branch_priority = bool(getattr(model, "branch_priority", False))
         if getattr(model, "debug_stamps", False):
             if getattr(model, "_stamp_buf", None) is None:
                 model._stamp_buf = torch.zeros(512, dtype=torch.int64, device=x.device)
@@ -2324,7 +2180,6 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         rt.early_wgrads = int(getattr(model, "early_wgrads", 2))
         rt.fused_fusion = bool(getattr(model, "fused_fusion", True))
         rt.fused_upsample = bool(getattr(model, "fused_upsample", True))
-        rt.gn_colstats = bool(getattr(model, "gn_colstats", False))
         rt.mlp_recompute = getattr(model, "mlp_recompute", "auto")
         rt.overlap_fusion = bool(getattr(model, "overlap_fusion", True))     # RadarEnhanceByImage beside the image chain (round 5)
         rt.fused_mlp = bool(getattr(model, "fused_mlp", True))
@@ -2384,12 +2239,12 @@ def forward_pass(model, x, x_radar, record, need_dx=False, need_dr=False):
         xa = Act(torch.empty((B, H, W, 3), device=x.device), need_grad=need_dx)
         ra = Act(torch.empty((B, H, W, 4), device=x.device), need_grad=need_dr)
         rt.stamp("step start")
-        hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)      # (issued before the preparation stream's ~35 launches: a
-        hip.nchw_to_nhwc(x_radar.contiguous(), ra.t, 4, B, 4, H * W)  #  replayed graph enqueues its nodes in capture order)
-        if rt.concurrent and getattr(model, "weight_prep_stream", True):
-            rt.prep = WeightPrep(rt, model, refresh_all)      # on a side stream, beside the input fusion
-        else:
-            refresh_all()
+        hip.nchw_to_nhwc(x.contiguous(), xa.t, 3, B, 3, H * W)
+        hip.nchw_to_nhwc(x_radar.contiguous(), ra.t, 4, B, 4, H * W)
+        # (round 5 issued the per-step weight preparation -- [fc1 ; fc_v] copies, plane splits, Mlp and k x k packs -- on a side
+        # stream beside the input fusion; same-call A/B in rounds 5 and 6, fp32 / bf16 bs 16 / nano: 25.00-25.03 vs 24.95-25.09,
+        # 29.31-29.50 vs 29.42-29.47, 11.43-11.52 vs 11.40-11.51 ms -- neutral everywhere, removed: profiles/r06_ab_switches.txt)
+        refresh_all()
         nc, ns = model.num_classes, model.num_seg_classes
         seg = torch.empty((B, ns, H, W), device=x.device)
         dets = [torch.empty((B, 5 + nc, H // s, W // s), device=x.device) for s in (8, 16, 32)]

@@ -364,14 +364,11 @@ def main():
     ap.add_argument("--no-weight-planes", action="store_true", help="x6 kernels split the weights themselves (A/B aid)")
     ap.add_argument("--no-bn-colstats", action="store_true", help="BatchNorm statistics by a pass over z (A/B aid)")
     ap.add_argument("--no-overlap-fusion", action="store_true", help="RadarEnhanceByImage in front of both chains, as rounds 1-4 (A/B aid)")
-    ap.add_argument("--branch-priority", action="store_true", help="second chain of a section on a high-priority stream (experiment)")
     ap.add_argument("--early-wgrads", type=int, default=2, help="a section's deferred weight gradients start right behind it: 0 never, "
                     "1 every section (measured slower), 2 the last section only (default)")
     ap.add_argument("--no-fused-fusion", action="store_true", help="fusion blocks without the fused passes of csrc/fusion.hip (A/B aid)")
     ap.add_argument("--no-fused-upsample", action="store_true", help="A/B: CoCUpsample as conv -> BN apply -> upsample (three launches)")
-    ap.add_argument("--gn-colstats", action="store_true", help="GroupNorm-backward moments from the data-gradient conv's epilogue (experiment)")
     ap.add_argument("--mlp-recompute", default="auto", help="fused Mlp backward recomputes the pre-activation: auto (default), all, off")
-    ap.add_argument("--no-weight-prep", action="store_true", help="per-step weight packs on the main chain, as rounds 1-4 (A/B aid)")
     ap.add_argument("--diagnostic", action="store_true",
                     help="allow VRNET_* environment knobs and the diagnostic library build (tools/sweep_env.sh ablations); the "
                          "line is then marked `diagnostic`, its metric string says so, and it is not a measurement")
@@ -426,12 +423,9 @@ def main():
     model.bn_colstats = not args.no_bn_colstats
     model.overlap_fusion = not args.no_overlap_fusion
     model.mlp_recompute = {"off": False, "all": True}.get(args.mlp_recompute, "auto")
-    model.gn_colstats = args.gn_colstats
     model.fused_fusion = not args.no_fused_fusion
     model.fused_upsample = not args.no_fused_upsample
     model.early_wgrads = args.early_wgrads
-    model.branch_priority = args.branch_priority
-    model.weight_prep_stream = not args.no_weight_prep
     net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 

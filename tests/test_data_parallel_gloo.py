@@ -396,6 +396,21 @@ def test_n8_plan_at_l():
         for bi, flat in enumerate(bk.buckets):
             assert flat.numel() * 4 <= (32 << 20) + biggest
             assert len({bk.bucket_segment[bk.bucket_of[p]] for p in bk.params if bk.bucket_of[p] == bi}) == 1
+        # (round-5 review, item 9) a segment bigger than one bucket is itself cut into <= 32 MiB buckets that complete one after
+        # another in execution order: in eager mode the all-reduce of its first bucket starts while the rest of the segment is
+        # still being computed, and under capture the collective behind graph k runs bucket by bucket
+        for k in range(3):
+            seg = [bi for bi in range(len(bk.buckets)) if bk.bucket_segment[bi] == k]
+            seg_bytes = sum(bk.buckets[bi].numel() * 4 for bi in seg)
+            assert seg == list(range(seg[0], seg[-1] + 1)), "a segment's buckets are consecutive"
+            assert len(seg) >= -(-seg_bytes // ((32 << 20) + biggest)), (k, seg_bytes, len(seg))
+            if seg_bytes > (32 << 20) + biggest:
+                assert len(seg) >= 2, (k, seg_bytes, len(seg))
+            done_at = [max(bk._rec_order[p] for p in bk.params if bk.bucket_of[p] == bi) for bi in seg]
+            assert done_at == sorted(done_at), "buckets of a segment must complete in arena order"
+        if phi == "l":      # 200 MB of gradients: the two overlapped segments hold several buckets each or one
+            nb = [sum(1 for bi in range(len(bk.buckets)) if bk.bucket_segment[bi] == k) for k in range(3)]
+            assert nb[0] + nb[1] >= 6 and max(nb[0], nb[1]) >= 3, nb
         inv = {p: k for k, p in names.items()}
         assert inv[bk.params[0]].startswith("head.") and "initial" in inv[bk.params[-1]] or "patch_embed" in inv[bk.params[-1]] \
             or "enhance" in inv[bk.params[-1]], inv[bk.params[-1]]

@@ -1527,7 +1527,8 @@ def _planes(hip, w2d, J, K, sj, sk, kscale=None):
 
 @pytest.mark.parametrize("case", [(2, 128, 128, 64, 128), (2, 128, 128, 64, 512), (2, 128, 128, 512, 64), (8, 32, 32, 320, 1280),
                                   (8, 32, 32, 1280, 320), (4, 64, 64, 128, 96), (8, 64, 64, 256, 192), (2, 128, 128, 80, 64),
-                                  (8, 16, 16, 2048, 512), (8, 16, 16, 512, 2048), (8, 16, 16, 1024, 512)])      # split contraction (4, 4, 2 splits)
+                                  (8, 16, 16, 2048, 512), (8, 16, 16, 512, 2048), (8, 16, 16, 1024, 512),      # split contraction (4, 4, 2 splits)
+                                  (8, 64, 64, 128, 256), (8, 128, 128, 64, 128), (3, 128, 128, 64, 192), (2, 128, 128, 128, 128)])      # K = 64 / 128 over >= 32 768 rows: resident-B streaming kernel
 def test_x6_conv_with_presplit_weights(hip, case):
     """precision 2 with `w_planes` (weights split once into bf16 planes by vrnet_conv_planes_pack_f32, kernel family 9):
     forward with the full epilogue and data gradient with the layer scale folded into the pack, against fp64 ATen."""
