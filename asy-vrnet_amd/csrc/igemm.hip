@@ -1914,13 +1914,18 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
     *cfg = 10 * tn + tc; *bn = 64 * tc;
     *n_tiles = (int)vr_cdiv(Cout, 64 * tn); *c_tiles = (int)vr_cdiv(Cin, 64 * tc);
     const long tiles = (long)*n_tiles * *c_tiles * T;
-    long s = vr_cdiv(768, tiles);
+    static const int x6_target = vr_tune("VRNET_X6_WGRAD_TARGET", 768);      // tuning aid: workgroups wanted when tiles > 96
+    long s = vr_cdiv(x6_target, tiles);
     long smax = vr_cdiv(M, 256);
     const long sbytes = (48L << 20) / (wsz * 4);
-    // XCD-grouped launch (wgrad_rows_xcd): all tiles of a row split on one XCD, 8 k splits, and at most the 96
-    // workgroups an XCD holds at once (32 CUs x 3) per XCD -- otherwise its second round would run nearly empty
+    // XCD-grouped launch (wgrad_rows_xcd): all tiles of a row split on one XCD, 8 k splits per group, `per_xcd` workgroups per XCD.
+    // Rounds 2-5 filled an XCD (96 = 32 CUs x 3 workgroups: the fastest launch ALONE).  Round 6, in the step: a third of that.
+    // Every split costs a slab of |dW| written and read back (8 192 x 320 x 1 280: 24 splits = 79 MB of slab traffic beside 52 MB
+    // of operands), and the weight gradients run beside the chains, not on them: thinner launches leave the chains the CUs and
+    // the bytes.  Same call, ms per step, fp32 bs 8 (profiles/r06_wgrad_split_sweep.txt): 96: 25.08-25.15 / 24.73-24.94 on a
+    // second box; 64: 24.53-24.97; 48: 24.68-24.84; **32: 24.93-24.98 / 24.37-24.47**; 24: 24.97-25.03; 16: 25.15-25.39; 8: 26.6.
     static const int s8 = vr_tune("VRNET_X6_WGRAD_S8", 1);      // tuning aid
-    static const int per_xcd = vr_tune("VRNET_X6_WGRAD_PER_XCD", 96);      // tuning aid
+    static const int per_xcd = vr_tune("VRNET_X6_WGRAD_PER_XCD", 32);      // tuning aid
     if (s8 && tiles <= 96) {
       long g = 8 * (per_xcd / tiles);
       if (g < 8) g = 8;
@@ -1934,8 +1939,9 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
     *rows = (int)r; *S = (int)vr_cdiv(M, r);
     return;
   }
+  static const int wg_target = vr_tune("VRNET_WGRAD_TARGET", 1024);      // tuning aid
   auto splits = [&](long tiles) {
-    long s = vr_cdiv(1024, tiles);
+    long s = vr_cdiv(wg_target, tiles);
     // >= 512 rows per split on the big maps (the reduce pass is serial in S); down to 128 rows, at most 64
     // splits, on the small ones (M <= 8192), which otherwise cannot fill the chip
     long smax = vr_cdiv(M, 512);
