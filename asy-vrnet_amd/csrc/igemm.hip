@@ -1926,8 +1926,9 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* cfg, int* bn, int*
     // second box; 64: 24.53-24.97; 48: 24.68-24.84; **32: 24.93-24.98 / 24.37-24.47**; 24: 24.97-25.03; 16: 25.15-25.39; 8: 26.6.
     static const int s8 = vr_tune("VRNET_X6_WGRAD_S8", 1);      // tuning aid
     static const int per_xcd = vr_tune("VRNET_X6_WGRAD_PER_XCD", 32);      // tuning aid
+    static const int per_xcd_small = vr_tune("VRNET_X6_WGRAD_PER_XCD_SMALL", 0);      // tuning aid: for <= 16 tiles (0 = per_xcd)
     if (s8 && tiles <= 96) {
-      long g = 8 * (per_xcd / tiles);
+      long g = 8 * ((per_xcd_small && tiles <= 16 ? per_xcd_small : per_xcd) / tiles);
       if (g < 8) g = 8;
       while (g > 8 && (g > smax || g > sbytes)) g -= 8;
       if (g <= smax && g <= sbytes) s = g;

@@ -26,10 +26,10 @@ cp $out/x6_issue_ceiling_micro.txt profiles/${R}_x6_issue_ceiling_micro.txt
 (echo "# python tools/cluster_probe.py  (Cluster kernels alone, phi = l, bs 8, 512 px)"; timeout 300 python3 tools/cluster_probe.py 2>&1 | grep -v amdgpu.ids) > $out/cluster_probe.txt
 # ---- same-call A/B against the previous round's head (a worktree under .ab/base, built), when present
 if [ -d .ab/base ]; then
-  (echo "# tools/ab.sh 3: ms per step, the round-4 head (.ab/base) against this tree, alternating runs of one call"; bash tools/ab.sh 3 "round4-head|.ab/base|" "round5|.|" 2>&1) > $out/ab_vs_round4_head.txt
-  (echo "# the switches of round 5, one at a time (ms per step, same call)"
+  (echo "# tools/ab.sh 3: ms per step, the previous round's head (.ab/base) against this tree, alternating runs of one call"; bash tools/ab.sh 3 "previous-head|.ab/base|" "this-tree|.|" 2>&1) > $out/ab_vs_previous_head.txt
+  (echo "# the schedule switches, one at a time (ms per step, same call)"
    for f in "" "--no-overlap-fusion" "--no-fused-fusion" "--early-wgrads 0" "--mlp-recompute off" ""; do
-     ms=$(python3 bench.py --no-cpu-baseline --no-roofline $f 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])"); echo "[$f] $ms"; done) > $out/ab_round5_switches.txt
+     ms=$(python3 bench.py --no-cpu-baseline --no-roofline $f 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])"); echo "[$f] $ms"; done) > $out/ab_schedule_switches.txt
 fi
 # ---- diagnostic build: launch-skipping ablations of the step
 export VRNET_HIP_LIB=$PWD/asy-vrnet_amd/csrc/libvrnet_hip_tuning.so
