@@ -372,6 +372,8 @@ def main():
     ap.add_argument("--diagnostic", action="store_true",
                     help="allow VRNET_* environment knobs and the diagnostic library build (tools/sweep_env.sh ablations); the "
                          "line is then marked `diagnostic`, its metric string says so, and it is not a measurement")
+    ap.add_argument("--plane-gemms", default=None, help="ClusterBlock GEMMs on bf16-plane operands (csrc/pgemm.hip): off, fwd, wgrad, fwd+wgrad "
+                    "(default: off in fp32, fwd+wgrad in bf16 mode) (A/B aid)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     args = ap.parse_args()
 
@@ -426,6 +428,8 @@ def main():
     model.fused_fusion = not args.no_fused_fusion
     model.fused_upsample = not args.no_fused_upsample
     model.early_wgrads = args.early_wgrads
+    if args.plane_gemms is not None:
+        model.plane_gemms = False if args.plane_gemms == "off" else args.plane_gemms
     net = DataParallelVRNet(model, force_collective=force_dp) if (world > 1 or dist.is_initialized()) else model
     batches = make_batches(args.warmup + args.steps, args.batch, args.size, rank, dev)
 
