@@ -203,6 +203,7 @@ class RT:
     def _launch_deferred_wgrads(self, cur, streams):
         """Issues the pending deferred weight gradients round-robin on `streams` (already forked from `cur`)."""
         work, self._deferred_wgrads = self._deferred_wgrads, []
+        # (newest first -- the operands most likely still in the Infinity Cache -- measured neutral: 24.70-24.93 vs 24.75-24.93 ms)
         for i, (fn, _) in enumerate(work):
             with torch.cuda.stream(streams[i % len(streams)]):
                 fn()
