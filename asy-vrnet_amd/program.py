@@ -70,6 +70,7 @@ class Act:
 
 ASIDE_LAG = int(os.environ.get("VRNET_ASIDE_LAG", "1"))           # tape closures a main-chain weight gradient may trail by
 _SERIAL_SITES = int(os.environ.get("VRNET_SERIAL_SITES", "0"), 0)   # diagnostic: parallel sections (bit = site id) run serially
+FUSED_MLP_MIN_ROWS = int(os.environ.get("VRNET_FUSED_MLP_MIN_ROWS", "16384"))      # (diagnostic override)
 WGRAD_STREAMS = int(os.environ.get("VRNET_WGRAD_STREAMS", "2"))   # side streams for weight gradients (measured: 2 < 1 < 4 ms/step)
 
 
@@ -405,7 +406,10 @@ class RT:
     def prec_mlp(self, C, hid, rows, HW):
         """precision flag of the fused fc1 -> GELU -> fc2 kernels (hip.mlp_fwd / mlp_bwd) for a block, 0 = not fused:
         2 = x6 (compute_dtype "f32"), 1 = bf16-rounded operands (compute_dtype "bf16"); "f32-mfma" keeps the two convs."""
-        if not self.fused_mlp or HW % 32 or not hip.mlp_fused_ok(C, hid, rows):
+        # (rows: one workgroup per 128 pixels -- below 16 384 rows the launch leaves most CUs empty: at phi = nano the fused kernels
+        # ran the 16 x 16 / 32 x 32 stages (C = 128 / 64) at 7.6 TFLOP/s, 71 us for a 0.5 GFLOP GEMM pair; two tile launches are faster
+        # there: 11.50 -> 11.24 ms per step, profiles/r06_nano_variants.txt.  phi = s / m / l have C = 64 / 128 only on the big maps)
+        if not self.fused_mlp or HW % 32 or rows < FUSED_MLP_MIN_ROWS or not hip.mlp_fused_ok(C, hid, rows):
             return 0
         if self.bf16:
             return 1
